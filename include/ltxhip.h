@@ -1,0 +1,177 @@
+/* ltxhip.h - C ABI of libltxhip.so: the MI355X-native LTX-2 denoise + VAE-decode path.
+ *
+ * This is the drop-in boundary for the hot path of VincentGourbin/ltx-video-swift-mlx. The reference has no FFI of
+ * its own (it is a Swift library calling MLX directly); each entry point below replaces the Swift seam named in
+ * its comment (file:line in the reference tree), so that a Swift `LTXPipeline` can keep its public surface and call
+ * HIP through this header (see INTEGRATION.md for the module map and the Swift wrapper).
+ *
+ * Conventions
+ *   - plain C types only; bf16 tensors are `uint16_t` bit patterns; all tensors are dense row-major.
+ *   - every function returns an `ltx_status` (0 = ok). Codes mirror the reference's `LTXError` cases
+ *     (LTXVideo.swift:66-141); `ltx_last_error(ctx)` returns the message the Swift wrapper re-throws.
+ *   - ownership: the caller owns every buffer it passes; `ltx_ctx` owns all device memory. Entry points without a
+ *     `_dev` suffix take HOST pointers and stage through HBM; `_dev` variants take DEVICE pointers valid on the
+ *     context's GPU and run asynchronously on the context's stream (`ltx_ctx_set_stream`).
+ *   - threading: one in-flight call per `ltx_ctx` (the reference's `LTXPipeline` is an actor; its models are not
+ *     re-entrant: LTXTransformer.swift:30-31, LTXTransformerBlock.swift:117-123, LTXScheduler.swift:49-55).
+ *   - the library fails loudly: there is no CPU fallback behind any of these calls.
+ */
+#ifndef LTXHIP_H
+#define LTXHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ltx_ctx ltx_ctx;
+
+/* LTXError (LTXVideo.swift:66-141) -> status code */
+typedef enum ltx_status {
+    LTX_OK = 0,
+    LTX_ERR_MODEL_NOT_LOADED = 1,      /* .modelNotLoaded */
+    LTX_ERR_INVALID_CONFIGURATION = 2, /* .invalidConfiguration */
+    LTX_ERR_INSUFFICIENT_MEMORY = 3,   /* .insufficientMemory */
+    LTX_ERR_WEIGHT_LOADING_FAILED = 4, /* .weightLoadingFailed */
+    LTX_ERR_GENERATION_FAILED = 5,     /* .generationFailed */
+    LTX_ERR_GENERATION_CANCELLED = 6,  /* .generationCancelled */
+    LTX_ERR_INVALID_FRAME_COUNT = 7,   /* .invalidFrameCount */
+    LTX_ERR_INVALID_DIMENSIONS = 8,    /* .invalidDimensions */
+    LTX_ERR_FILE_NOT_FOUND = 9,        /* .fileNotFound */
+    LTX_ERR_INVALID_LORA = 10,         /* .invalidLoRA */
+    LTX_ERR_HIP = 11                   /* device/runtime failure (no reference counterpart) */
+} ltx_status;
+
+/* LTXTransformerConfig (LTXConfig.swift:83-177) */
+typedef struct ltx_transformer_config {
+    int num_layers;                  /* 48 */
+    int num_attention_heads;         /* 32 */
+    int attention_head_dim;          /* 128 */
+    int in_channels;                 /* 128 */
+    int out_channels;                /* 128 */
+    int cross_attention_dim;         /* 4096 */
+    int caption_channels;            /* 3840 */
+    float rope_theta;                /* 10000 */
+    int max_pos[3];                  /* 20, 2048, 2048 */
+    float timestep_scale_multiplier; /* 1000 */
+    float norm_eps;                  /* 1e-6 */
+} ltx_transformer_config;
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Library / context
+ * ---------------------------------------------------------------------------------------------------------- */
+/* LTXVideo.version (LTXVideo.swift, asserted by Tests/LTXVideoTests/LTXVideoTests.swift:9-11) */
+const char* ltx_version(void);
+/* Filled with the reference defaults (LTXConfig.swift:83-177). */
+void ltx_transformer_config_default(ltx_transformer_config* cfg);
+/* Replaces `LTXPipeline.init` device/bookkeeping (LTXPipeline.swift:189-200). Fails with LTX_ERR_HIP when no
+ * gfx950 device is usable. */
+int ltx_ctx_create(int device, ltx_ctx** out);
+void ltx_ctx_destroy(ltx_ctx* ctx);
+const char* ltx_last_error(const ltx_ctx* ctx);
+/* Run all work of this context on an existing HIP stream (hipStream_t passed as void*); NULL = context's own. */
+int ltx_ctx_set_stream(ltx_ctx* ctx, void* hip_stream);
+int ltx_ctx_synchronize(ltx_ctx* ctx);
+/* Counts of the last load call: tensors applied / model parameters absent from the file (left at the reference's
+ * initial values) / mapped file keys with no parameter (dropped), as logged at ModelDownloader.swift:992-1017. */
+int ltx_load_report(const ltx_ctx* ctx, int* n_loaded, int* n_missing, int* n_unmatched);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Pure host logic (no GPU needed): shapes, schedules, tables, key mapping
+ * ---------------------------------------------------------------------------------------------------------- */
+/* LTXVideoGenerationConfig.validate (LTXConfig.swift:310-353) + two-stage %64 rule (LTXPipeline.swift:2443).
+ * On failure writes the reference's message into msg (if non-NULL). */
+int ltx_validate_generation_config(int width, int height, int num_frames, int num_steps, float cfg_scale,
+                                   int two_stage, char* msg, int msg_cap);
+/* latentFrames/Height/Width (LTXConfig.swift:356-361; VideoLatentShape.fromPixelDimensions :95-111) */
+int ltx_latent_shape(int width, int height, int num_frames, int* latent_frames, int* latent_height,
+                     int* latent_width);
+/* LTXScheduler.setTimesteps (LTXScheduler.swift:74-182). token_count <= 0 means "not provided".
+ * Writes up to cap values, returns the number of sigmas (9 for distilled, num_steps+1 for dev) or <0 on error. */
+int ltx_sigmas(int distilled, int num_steps, int token_count, float* out, int cap);
+/* STAGE_2_DISTILLED_SIGMA_VALUES (LTXScheduler.swift:31-36); returns 4. */
+int ltx_stage2_sigmas(float* out, int cap);
+/* createPositionGrid + precomputeFreqsCis(doublePrecision:true) (LTXRoPE.swift:552-610,375-527).
+ * cos_out/sin_out: [F*H*W][inner_dim/2] f32; head h owns columns h*64..h*64+63 (the reference's [B,H,T,64]). */
+int ltx_rope_tables(const ltx_transformer_config* cfg, int F, int H, int W, float* cos_out, float* sin_out);
+/* decodeWithTemporalTiling's tile walk and blended frame count (VideoDecoder.swift:517-592).
+ * Returns the number of tiles (<= cap written) or <0 on error. */
+int ltx_vae_tile_plan(int latent_frames, int tile, int overlap, int* starts, int* ends, int cap, int* out_frames);
+/* mapTransformerKey + loadTransformerWeights filters (ModelDownloader.swift:605-639,756-803). Returns 1 and writes
+ * the module key, 0 when the file key is skipped, <0 when out is too small. */
+int ltx_map_transformer_key(const char* file_key, char* out, int cap);
+/* mapVAEWeights (ModelDownloader.swift:808-899). */
+int ltx_map_vae_key(const char* file_key, char* out, int cap);
+/* LoRAKeyMapper.loraKeyToModelKey (LoRALoader.swift:209-243). */
+int ltx_map_lora_key(const char* lora_key, char* out, int cap);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * DiT (LTXTransformer)
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Replaces LTXTransformer(config:) + LTXWeightLoader.loadTransformerWeights/applyTransformerWeights
+ * (LTXPipeline.swift:293-314, ModelDownloader.swift:605-639,972-1019). cfg NULL = reference defaults.
+ * quant_bits: 16 (bf16). */
+int ltx_dit_load(ltx_ctx* ctx, const char* safetensors_path, const ltx_transformer_config* cfg, int quant_bits,
+                 int group_size);
+/* Random-init weights of the given architecture, generated on device (bench / property tests). */
+int ltx_dit_init_synthetic(ltx_ctx* ctx, const ltx_transformer_config* cfg, uint64_t seed);
+/* `transformer = nil` (LTXPipeline.swift:989-999) */
+int ltx_dit_unload(ltx_ctx* ctx);
+/* Replaces transformer(latent:context:timesteps:contextMask:latentShape:) (LTXTransformer.swift:235).
+ *   latent   [B][T][in_channels] bf16, T = F*H*W, token t = (f*H+h)*W+w
+ *   context  [B][S][caption_channels] bf16
+ *   timesteps[B] f32 (sigma; scaled by timestep_scale_multiplier inside)
+ *   mask     [B][S] int32 (1 attend, 0 pad) or NULL
+ *   velocity [B][T][out_channels] f32 (out)
+ * HOST pointers. */
+int ltx_dit_forward(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* context, const float* timesteps,
+                    const int32_t* mask, int B, int F, int H, int W, int S, float* velocity);
+/* Same with DEVICE pointers, asynchronous on the context stream. ctx_version: non-zero value that changes whenever
+ * the context/mask contents change (lets the library keep the projected caption and cross-attention K/V resident
+ * across denoise steps - output-identical to recomputing them); 0 = recompute every call.
+ * mask_all_ones: caller asserts the mask is all ones (connector output, LTXTextEncoder.swift:622-626). */
+int ltx_dit_forward_dev(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* context, const float* timesteps,
+                        const int32_t* mask, int mask_all_ones, int B, int F, int H, int W, int S,
+                        uint64_t ctx_version, float* velocity);
+/* setCrossAttentionScale (LTXTransformer.swift:497); block range inclusive, (0,-1) = all blocks. */
+int ltx_dit_set_cross_attn_scale(ltx_ctx* ctx, float scale, int first_block, int last_block);
+/* setSTGSkipFlags / clearSTGSkipFlags (LTXTransformer.swift:512-526) */
+int ltx_dit_set_stg(ltx_ctx* ctx, const int* blocks, int n_blocks, int skip_self_attention, int skip_feed_forward);
+int ltx_dit_clear_stg(ltx_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Kernel-level entry points (DEVICE pointers). These expose the individual gfx950 kernels so that parity tests can
+ * pin each one against the oracle; they are not needed by a pipeline caller.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* C[M,N] = A[M,K] . B[N,K]^T (+bias[N]) ; act: 0 none, 1 gelu-tanh, 2 silu; tile_cfg: -1 auto, 0/1/2 forced.
+ * Exactly one of out_f32/out_bf16 may be NULL. */
+int ltx_op_gemm_bf16(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb, const float* bias, int M,
+                     int N, int K, int act, int tile_cfg, float* out_f32, long ld_f32, uint16_t* out_bf16,
+                     long ld_bf16);
+/* x[m][n] += gate[n] * (A.B^T + bias) in place on an f32 stream, optional bf16 mirror of the result */
+int ltx_op_gemm_bf16_gated_residual(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                                    const float* bias, const float* gate, float gate_scalar, int M, int N, int K,
+                                    float* x, long ldx, uint16_t* mirror_bf16, long ld_mirror);
+/* out[m][n] = sum_k in_act(a[m][k]) W[n][k] + bias[n], f32 x bf16 -> f32, M <= 8 */
+int ltx_op_gemv_f32(ltx_ctx* ctx, const float* a, long lda, const uint16_t* W, long ldw, const float* bias, float* out,
+                    long ldo, int M, int N, int K, int in_act);
+/* O = softmax(Q K^T * scale + bias) V ; Q [B][Tq][H*128], K [B][Tk][H*128], Vt [B][H*128][ldvt] (keys contiguous,
+ * ldvt >= roundup(Tk,64)), bias [B][Tk] f32 or NULL, O [B][Tq][H*128] ; all bf16 */
+int ltx_op_attention(ltx_ctx* ctx, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, long ldvt,
+                     const float* bias, int B, int H, int Tq, int Tk, float scale, uint16_t* O);
+/* adaLN: out = norm(x) * (1+scale) + shift -> bf16 ; norm_kind 0 RMS, 1 LayerNorm; scale/shift [D] or NULL */
+int ltx_op_norm_mod(ltx_ctx* ctx, const float* x, const float* scale, const float* shift, int rows, int D,
+                    int norm_kind, float eps, int round_norm_bf16, uint16_t* out);
+/* q/k RMSNorm (weight w[D]) + split RoPE (cos/sin [T][D/2] or NULL) -> bf16 */
+int ltx_op_qknorm_rope(ltx_ctx* ctx, const float* x, long ldx, const float* w, const float* cos_t, const float* sin_t,
+                       int T, int rows, int D, float eps, uint16_t* out);
+/* deterministic device fills used by bench.py to create synthetic inputs */
+int ltx_op_fill_normal_bf16(ltx_ctx* ctx, uint16_t* p, long n, uint64_t seed, float mean, float stddev);
+int ltx_op_fill_normal_f32(ltx_ctx* ctx, float* p, long n, uint64_t seed, float mean, float stddev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTXHIP_H */

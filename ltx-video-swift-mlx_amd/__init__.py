@@ -1,0 +1,259 @@
+"""ltx-video-swift-mlx_amd - MI355X-native LTX-2 denoise + VAE-decode path.
+
+The product is ``csrc/build/libltxhip.so`` (hand-written gfx950 HIP kernels behind the C ABI of
+``include/ltxhip.h``). This Python package is the thin host-side mirror used by the test-suite and ``bench.py``:
+``Context`` wraps an ``ltx_ctx``; device buffers are torch tensors used purely as HBM allocations (their
+``data_ptr()`` is what crosses the ABI).
+
+The directory name contains hyphens (it is the repo's mandated package name), so import it with
+``importlib.import_module("ltx-video-swift-mlx_amd")`` - ``tests/conftest.py`` and ``bench.py`` do that and alias it
+as ``ltx_amd``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import LTXError, TransformerConfig, lib
+
+__version__ = lib.ltx_version().decode()
+
+
+def _check(rc, ctx=None):
+    if rc != 0:
+        msg = lib.ltx_last_error(ctx).decode(errors="replace") if True else ""
+        raise LTXError(rc, msg)
+
+
+def default_transformer_config(**overrides):
+    cfg = TransformerConfig()
+    lib.ltx_transformer_config_default(C.byref(cfg))
+    for k, v in overrides.items():
+        if k == "max_pos":
+            for i in range(3):
+                cfg.max_pos[i] = v[i]
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# pure-host helpers (no GPU)
+# ---------------------------------------------------------------------------------------------------------------
+def validate_generation_config(width, height, num_frames, num_steps, cfg_scale, two_stage=False):
+    """``LTXVideoGenerationConfig.validate()``: raises LTXError.invalidConfiguration with the reference's text."""
+    buf = C.create_string_buffer(256)
+    rc = lib.ltx_validate_generation_config(width, height, num_frames, num_steps, cfg_scale, int(two_stage), buf, 256)
+    if rc != 0:
+        raise LTXError(rc, buf.value.decode())
+
+
+def latent_shape(width, height, num_frames):
+    f, h, w = C.c_int(), C.c_int(), C.c_int()
+    _check(lib.ltx_latent_shape(width, height, num_frames, C.byref(f), C.byref(h), C.byref(w)))
+    return f.value, h.value, w.value
+
+
+def sigmas(distilled, num_steps, token_count=0):
+    out = (C.c_float * 128)()
+    n = lib.ltx_sigmas(int(distilled), num_steps, token_count or 0, out, 128)
+    if n < 0:
+        raise LTXError(-n, "invalid sigma request")
+    return np.array(out[:n], dtype=np.float32)
+
+
+def stage2_sigmas():
+    out = (C.c_float * 4)()
+    lib.ltx_stage2_sigmas(out, 4)
+    return np.array(out[:], dtype=np.float32)
+
+
+def rope_tables(cfg, F, H, W):
+    D = cfg.num_attention_heads * cfg.attention_head_dim
+    T = F * H * W
+    cos = np.empty((T, D // 2), dtype=np.float32)
+    sin = np.empty((T, D // 2), dtype=np.float32)
+    _check(lib.ltx_rope_tables(C.byref(cfg), F, H, W, cos.ctypes.data, sin.ctypes.data))
+    return cos, sin
+
+
+def vae_tile_plan(latent_frames, tile, overlap):
+    starts, ends = (C.c_int * 256)(), (C.c_int * 256)()
+    out = C.c_int()
+    n = lib.ltx_vae_tile_plan(latent_frames, tile, overlap, starts, ends, 256, C.byref(out))
+    if n < 0:
+        raise LTXError(-n, "invalid tiling request")
+    return [(starts[i], ends[i]) for i in range(n)], out.value
+
+
+def _map_key(fn, key):
+    buf = C.create_string_buffer(1024)
+    rc = fn(key.encode(), buf, 1024)
+    if rc < 0:
+        raise LTXError(2, "key too long")
+    return buf.value.decode() if rc == 1 else None
+
+
+def map_transformer_key(key):
+    return _map_key(lib.ltx_map_transformer_key, key)
+
+
+def map_vae_key(key):
+    return _map_key(lib.ltx_map_vae_key, key)
+
+
+def map_lora_key(key):
+    return _map_key(lib.ltx_map_lora_key, key)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# device context
+# ---------------------------------------------------------------------------------------------------------------
+def _ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"]
+        return t.ctypes.data
+    assert t.is_contiguous()
+    return t.data_ptr()
+
+
+class Context:
+    """Owns an ``ltx_ctx``. All ``*_dev`` methods take torch tensors resident on this context's GPU."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        h = C.c_void_p()
+        rc = lib.ltx_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise LTXError(rc, lib.ltx_last_error(None).decode(errors="replace"))
+        self._h = h
+        self.device = device
+        if use_torch_stream:
+            import torch
+
+            self.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def close(self):
+        if self._h:
+            lib.ltx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise LTXError(rc, lib.ltx_last_error(self._h).decode(errors="replace"))
+
+    def set_stream(self, stream_handle):
+        self._ck(lib.ltx_ctx_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self._ck(lib.ltx_ctx_synchronize(self._h))
+
+    def load_report(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._ck(lib.ltx_load_report(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"loaded": a.value, "missing": b.value, "unmatched": c.value}
+
+    # ---- DiT ----
+    def dit_load(self, path, cfg=None, quant_bits=16, group_size=64):
+        self._ck(lib.ltx_dit_load(self._h, str(path).encode(), C.byref(cfg) if cfg is not None else None, quant_bits, group_size))
+
+    def dit_init_synthetic(self, cfg=None, seed=1234):
+        self._ck(lib.ltx_dit_init_synthetic(self._h, C.byref(cfg) if cfg is not None else None, seed))
+
+    def dit_unload(self):
+        self._ck(lib.ltx_dit_unload(self._h))
+
+    def dit_forward(self, latent_bf16, context_bf16, timesteps, mask, F, H, W):
+        """Host-pointer path. latent [B,T,C] / context [B,S,Cc] as uint16 bf16 bit arrays, returns f32 [B,T,Cout]."""
+        B, T, _ = latent_bf16.shape
+        S = context_bf16.shape[1]
+        assert T == F * H * W
+        out_c = self._out_channels if hasattr(self, "_out_channels") else latent_bf16.shape[2]
+        vel = np.empty((B, T, out_c), dtype=np.float32)
+        ts = np.ascontiguousarray(timesteps, dtype=np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.int32)
+        self._ck(lib.ltx_dit_forward(self._h, _ptr(np.ascontiguousarray(latent_bf16)), _ptr(np.ascontiguousarray(context_bf16)),
+                                     _ptr(ts), _ptr(m), B, F, H, W, S, _ptr(vel)))
+        return vel
+
+    def dit_forward_dev(self, latent, context, timesteps, mask, F, H, W, velocity, ctx_version=0, mask_all_ones=False):
+        B, T = latent.shape[0], latent.shape[1]
+        S = context.shape[1]
+        self._ck(lib.ltx_dit_forward_dev(self._h, _ptr(latent), _ptr(context), _ptr(timesteps), _ptr(mask),
+                                         int(mask_all_ones), B, F, H, W, S, ctx_version, _ptr(velocity)))
+
+    def dit_set_cross_attn_scale(self, scale, first=0, last=-1):
+        self._ck(lib.ltx_dit_set_cross_attn_scale(self._h, scale, first, last))
+
+    def dit_set_stg(self, blocks, skip_self_attention=True, skip_feed_forward=False):
+        arr = (C.c_int * len(blocks))(*blocks)
+        self._ck(lib.ltx_dit_set_stg(self._h, arr, len(blocks), int(skip_self_attention), int(skip_feed_forward)))
+
+    def dit_clear_stg(self):
+        self._ck(lib.ltx_dit_clear_stg(self._h))
+
+    # ---- kernel-level hooks (device tensors) ----
+    def op_gemm(self, A, B, bias=None, act=0, tile_cfg=-1, out_f32=None, out_bf16=None):
+        M, K = A.shape
+        N = B.shape[0]
+        self._ck(lib.ltx_op_gemm_bf16(self._h, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(bias), M, N, K, act, tile_cfg,
+                                      _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
+                                      _ptr(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0))
+
+    def op_gemm_gated_residual(self, A, B, bias, gate, gate_scalar, x, mirror=None):
+        M, K = A.shape
+        N = B.shape[0]
+        self._ck(lib.ltx_op_gemm_bf16_gated_residual(self._h, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(bias), _ptr(gate),
+                                                     gate_scalar, M, N, K, _ptr(x), x.stride(0), _ptr(mirror),
+                                                     mirror.stride(0) if mirror is not None else 0))
+
+    def op_gemv(self, a, W, bias, out, in_act=0):
+        M, K = a.shape
+        N = W.shape[0]
+        self._ck(lib.ltx_op_gemv_f32(self._h, _ptr(a), a.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(out), out.stride(0), M, N, K, in_act))
+
+    def op_attention(self, Q, K, Vt, bias, H, O, scale=None):
+        B, Tq, _ = Q.shape
+        Tk = K.shape[1]
+        ldvt = Vt.shape[2]
+        if scale is None:
+            scale = 1.0 / (128.0 ** 0.5)
+        self._ck(lib.ltx_op_attention(self._h, _ptr(Q), _ptr(K), _ptr(Vt), ldvt, _ptr(bias), B, H, Tq, Tk, scale, _ptr(O)))
+
+    def op_norm_mod(self, x, scale, shift, out, norm_kind=0, eps=1e-6, round_norm_bf16=False):
+        rows, D = x.shape
+        self._ck(lib.ltx_op_norm_mod(self._h, _ptr(x), _ptr(scale), _ptr(shift), rows, D, norm_kind, eps, int(round_norm_bf16), _ptr(out)))
+
+    def op_qknorm_rope(self, x, w, cos, sin, T, out, eps=1e-6):
+        rows, D = out.shape
+        self._ck(lib.ltx_op_qknorm_rope(self._h, _ptr(x), x.stride(0), _ptr(w), _ptr(cos), _ptr(sin), T, rows, D, eps, _ptr(out)))
+
+    def op_fill_normal_bf16(self, t, seed, mean=0.0, std=1.0):
+        self._ck(lib.ltx_op_fill_normal_bf16(self._h, _ptr(t), t.numel(), seed, mean, std))
+
+    def op_fill_normal_f32(self, t, seed, mean=0.0, std=1.0):
+        self._ck(lib.ltx_op_fill_normal_f32(self._h, _ptr(t), t.numel(), seed, mean, std))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 helpers for host arrays (bit patterns as uint16)
+# ---------------------------------------------------------------------------------------------------------------
+def f32_to_bf16_bits(x):
+    """Round-to-nearest-even f32 -> bf16 bit patterns (uint16), numpy."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    return r.reshape(x.shape)
+
+
+def bf16_bits_to_f32(b):
+    b = np.ascontiguousarray(b, dtype=np.uint16)
+    return (b.astype(np.uint32) << 16).view(np.float32).reshape(b.shape)

@@ -1,0 +1,451 @@
+// abi.cpp - extern "C" surface of libltxhip.so (declared in include/ltxhip.h). Every entry point converts C++
+// exceptions into an ltx_status + message; nothing here computes on the CPU on behalf of the GPU path.
+#include <string.h>
+
+#include "../../include/ltxhip.h"
+#include "attention.h"
+#include "dit.h"
+#include "elementwise.h"
+#include "gemm.h"
+#include "hostmath.h"
+#include "runtime.h"
+
+namespace {
+
+thread_local std::string g_noctx_error;
+
+template <class Fn>
+int guarded(ltx_ctx* ctx, Fn&& fn) {
+    try {
+        if (ctx) HIP_CHECK(hipSetDevice(ctx->device));
+        fn();
+        return LTX_OK;
+    } catch (const LtxError& e) {
+        if (ctx) ctx->last_error = e.msg; else g_noctx_error = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->last_error = e.what(); else g_noctx_error = e.what();
+        return LTX_ERR_GENERATION_FAILED;
+    }
+}
+
+TransformerConfig to_cfg(const ltx_transformer_config* c) {
+    TransformerConfig t;
+    if (!c) return t;
+    t.num_layers = c->num_layers;
+    t.num_heads = c->num_attention_heads;
+    t.head_dim = c->attention_head_dim;
+    t.in_channels = c->in_channels;
+    t.out_channels = c->out_channels;
+    t.cross_attention_dim = c->cross_attention_dim;
+    t.caption_channels = c->caption_channels;
+    t.rope_theta = c->rope_theta;
+    for (int i = 0; i < 3; ++i) t.max_pos[i] = c->max_pos[i];
+    t.timestep_scale_multiplier = c->timestep_scale_multiplier;
+    t.norm_eps = c->norm_eps;
+    return t;
+}
+
+int copy_str(const std::string& s, char* out, int cap) {
+    if (!out || cap <= (int)s.size()) return -1;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return 1;
+}
+
+// FNV-1a over 8-byte words: cheap change detector for host-pointer context buffers
+uint64_t hash_bytes(const void* p, size_t n, uint64_t h) {
+    const uint8_t* b = (const uint8_t*)p;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, b + i, 8);
+        h = (h ^ w) * 0x100000001B3ull;
+        h ^= h >> 29;
+    }
+    for (; i < n; ++i) h = (h ^ b[i]) * 0x100000001B3ull;
+    return h ? h : 1;
+}
+
+DiTModel* need_dit(ltx_ctx* ctx) {
+    if (!ctx->dit) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model component not loaded: transformer");
+    return ctx->dit;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ltx_version(void) { return "0.1.0"; }
+
+void ltx_transformer_config_default(ltx_transformer_config* c) {
+    if (!c) return;
+    TransformerConfig t;
+    c->num_layers = t.num_layers;
+    c->num_attention_heads = t.num_heads;
+    c->attention_head_dim = t.head_dim;
+    c->in_channels = t.in_channels;
+    c->out_channels = t.out_channels;
+    c->cross_attention_dim = t.cross_attention_dim;
+    c->caption_channels = t.caption_channels;
+    c->rope_theta = t.rope_theta;
+    for (int i = 0; i < 3; ++i) c->max_pos[i] = t.max_pos[i];
+    c->timestep_scale_multiplier = t.timestep_scale_multiplier;
+    c->norm_eps = t.norm_eps;
+}
+
+int ltx_ctx_create(int device, ltx_ctx** out) {
+    if (!out) return LTX_ERR_INVALID_CONFIGURATION;
+    *out = nullptr;
+    ltx_ctx* ctx = nullptr;
+    const int rc = guarded(nullptr, [&] {
+        int n = 0;
+        HIP_CHECK(hipGetDeviceCount(&n));
+        if (device < 0 || device >= n) LTX_THROW(LTXS_HIP_ERROR, "no HIP device %d (found %d)", device, n);
+        HIP_CHECK(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            LTX_THROW(LTXS_HIP_ERROR, "libltxhip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+        ctx = new ltx_ctx();
+        ctx->device = device;
+        HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    });
+    if (rc != LTX_OK) {
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return LTX_OK;
+}
+
+void ltx_ctx_destroy(ltx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->dit) dit_destroy(ctx->dit);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* ltx_last_error(const ltx_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_noctx_error.c_str(); }
+
+int ltx_ctx_set_stream(ltx_ctx* ctx, void* hip_stream) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        if (ctx->own_stream && ctx->stream) {
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            HIP_CHECK(hipStreamDestroy(ctx->stream));
+        }
+        if (hip_stream) {
+            ctx->stream = (hipStream_t)hip_stream;
+            ctx->own_stream = false;
+        } else {
+            HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+            ctx->own_stream = true;
+        }
+    });
+}
+
+int ltx_ctx_synchronize(ltx_ctx* ctx) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { HIP_CHECK(hipStreamSynchronize(ctx->stream)); });
+}
+
+int ltx_load_report(const ltx_ctx* ctx, int* n_loaded, int* n_missing, int* n_unmatched) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    if (n_loaded) *n_loaded = ctx->n_loaded;
+    if (n_missing) *n_missing = ctx->n_missing;
+    if (n_unmatched) *n_unmatched = ctx->n_unmatched;
+    return LTX_OK;
+}
+
+// ---- pure host ----
+int ltx_validate_generation_config(int width, int height, int num_frames, int num_steps, float cfg_scale,
+                                   int two_stage, char* msg, int msg_cap) {
+    std::string m;
+    const int rc = validate_generation_config(width, height, num_frames, num_steps, cfg_scale, two_stage, &m);
+    if (msg && msg_cap > 0) {
+        strncpy(msg, m.c_str(), msg_cap - 1);
+        msg[msg_cap - 1] = 0;
+    }
+    return rc;
+}
+
+int ltx_latent_shape(int width, int height, int num_frames, int* F, int* H, int* W) {
+    if (!F || !H || !W) return LTX_ERR_INVALID_CONFIGURATION;
+    latent_shape(width, height, num_frames, F, H, W);
+    return LTX_OK;
+}
+
+int ltx_sigmas(int distilled, int num_steps, int token_count, float* out, int cap) {
+    if (!out || (!distilled && num_steps < 1)) return -LTX_ERR_INVALID_CONFIGURATION;
+    const std::vector<float> s = compute_sigmas(distilled != 0, num_steps, token_count);
+    for (int i = 0; i < (int)s.size() && i < cap; ++i) out[i] = s[i];
+    return (int)s.size();
+}
+
+int ltx_stage2_sigmas(float* out, int cap) {
+    for (int i = 0; i < 4 && i < cap; ++i) out[i] = kStage2DistilledSigmas[i];
+    return 4;
+}
+
+int ltx_rope_tables(const ltx_transformer_config* cfg, int F, int H, int W, float* cos_out, float* sin_out) {
+    if (!cos_out || !sin_out || F < 1 || H < 1 || W < 1) return LTX_ERR_INVALID_CONFIGURATION;
+    const TransformerConfig t = to_cfg(cfg);
+    std::vector<float> c, s;
+    rope_tables(t, F, H, W, 24.0f, &c, &s);
+    memcpy(cos_out, c.data(), c.size() * 4);
+    memcpy(sin_out, s.data(), s.size() * 4);
+    return LTX_OK;
+}
+
+int ltx_vae_tile_plan(int latent_frames, int tile, int overlap, int* starts, int* ends, int cap, int* out_frames) {
+    if (latent_frames < 1) return -LTX_ERR_INVALID_CONFIGURATION;
+    const TilePlan p = vae_tile_plan(latent_frames, tile, overlap);
+    if (p.start.empty()) return -LTX_ERR_INVALID_CONFIGURATION;
+    for (int i = 0; i < (int)p.start.size() && i < cap; ++i) {
+        if (starts) starts[i] = p.start[i];
+        if (ends) ends[i] = p.end[i];
+    }
+    if (out_frames) *out_frames = p.out_frames;
+    return (int)p.start.size();
+}
+
+int ltx_map_transformer_key(const char* file_key, char* out, int cap) {
+    std::string mk;
+    if (!file_key || !map_transformer_file_key(file_key, &mk)) return 0;
+    return copy_str(mk, out, cap);
+}
+int ltx_map_vae_key(const char* file_key, char* out, int cap) {
+    std::string mk;
+    if (!file_key || !map_vae_file_key(file_key, &mk)) return 0;
+    return copy_str(mk, out, cap);
+}
+int ltx_map_lora_key(const char* lora_key, char* out, int cap) {
+    std::string mk;
+    if (!lora_key || !map_lora_key(lora_key, &mk)) return 0;
+    return copy_str(mk, out, cap);
+}
+
+// ---- DiT ----
+int ltx_dit_load(ltx_ctx* ctx, const char* path, const ltx_transformer_config* cfg, int quant_bits, int group_size) {
+    if (!ctx || !path) return LTX_ERR_INVALID_CONFIGURATION;
+    (void)group_size;
+    return guarded(ctx, [&] {
+        LTX_REQUIRE(quant_bits == 16 || quant_bits == 0, "transformer quantization %d bits is not available in this build (bf16 only)", quant_bits);
+        if (ctx->dit) {
+            dit_destroy(ctx->dit);
+            ctx->dit = nullptr;
+        }
+        DiTModel* m = dit_create(to_cfg(cfg));
+        try {
+            dit_load_safetensors(ctx, m, path);
+        } catch (...) {
+            dit_destroy(m);
+            throw;
+        }
+        ctx->dit = m;
+    });
+}
+
+int ltx_dit_init_synthetic(ltx_ctx* ctx, const ltx_transformer_config* cfg, uint64_t seed) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        if (ctx->dit) {
+            dit_destroy(ctx->dit);
+            ctx->dit = nullptr;
+        }
+        DiTModel* m = dit_create(to_cfg(cfg));
+        try {
+            dit_init_synthetic(ctx, m, seed);
+        } catch (...) {
+            dit_destroy(m);
+            throw;
+        }
+        ctx->dit = m;
+    });
+}
+
+int ltx_dit_unload(ltx_ctx* ctx) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->dit) dit_destroy(ctx->dit);
+        ctx->dit = nullptr;
+    });
+}
+
+int ltx_dit_forward_dev(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* context, const float* timesteps,
+                        const int32_t* mask, int mask_all_ones, int B, int F, int H, int W, int S,
+                        uint64_t ctx_version, float* velocity) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        DiTModel* m = need_dit(ctx);
+        DiTForwardArgs a;
+        a.latent = latent;
+        a.context = context;
+        a.timesteps = timesteps;
+        a.mask = mask;
+        a.mask_all_ones = mask_all_ones;
+        a.B = B; a.F = F; a.H = H; a.W = W; a.S = S;
+        a.ctx_version = ctx_version;
+        a.velocity = velocity;
+        dit_forward(ctx, m, a);
+    });
+}
+
+int ltx_dit_forward(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* context, const float* timesteps,
+                    const int32_t* mask, int B, int F, int H, int W, int S, float* velocity) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        DiTModel* m = need_dit(ctx);
+        LTX_REQUIRE(latent && context && timesteps && velocity && B >= 1 && F >= 1 && H >= 1 && W >= 1 && S >= 1, "ltx_dit_forward: bad arguments");
+        const long T = (long)F * H * W;
+        const size_t n_lat = (size_t)B * T * m->cfg.in_channels * 2;
+        const size_t n_ctx = (size_t)B * S * m->cfg.caption_channels * 2;
+        const size_t n_vel = (size_t)B * T * m->cfg.out_channels * 4;
+        ctx->h2d[0].ensure(n_lat);
+        ctx->h2d[1].ensure(n_ctx);
+        ctx->h2d[2].ensure((size_t)B * 4);
+        ctx->h2d[3].ensure((size_t)B * S * 4);
+        ctx->h2d[4].ensure(n_vel);
+        hipStream_t st = ctx->stream;
+        // the context is constant across denoise steps: upload + re-project it only when its bytes change
+        uint64_t hv = hash_bytes(context, n_ctx, 0xCBF29CE484222325ull);
+        int all_ones = 1;
+        if (mask) {
+            hv = hash_bytes(mask, (size_t)B * S * 4, hv);
+            for (long i = 0; i < (long)B * S; ++i)
+                if (mask[i] != 1) { all_ones = 0; break; }
+        }
+        HIP_CHECK(hipMemcpyAsync(ctx->h2d[0].p, latent, n_lat, hipMemcpyHostToDevice, st));
+        if (hv != m->ctx_version || m->ctx_B != B || m->ctx_S != S) {
+            HIP_CHECK(hipMemcpyAsync(ctx->h2d[1].p, context, n_ctx, hipMemcpyHostToDevice, st));
+            if (mask) HIP_CHECK(hipMemcpyAsync(ctx->h2d[3].p, mask, (size_t)B * S * 4, hipMemcpyHostToDevice, st));
+        }
+        HIP_CHECK(hipMemcpyAsync(ctx->h2d[2].p, timesteps, (size_t)B * 4, hipMemcpyHostToDevice, st));
+        DiTForwardArgs a;
+        a.latent = ctx->h2d[0].as<bf16_t>();
+        a.context = ctx->h2d[1].as<bf16_t>();
+        a.timesteps = ctx->h2d[2].as<float>();
+        a.mask = mask ? ctx->h2d[3].as<int32_t>() : nullptr;
+        a.mask_all_ones = all_ones;
+        a.B = B; a.F = F; a.H = H; a.W = W; a.S = S;
+        a.ctx_version = hv;
+        a.velocity = ctx->h2d[4].as<float>();
+        dit_forward(ctx, m, a);
+        HIP_CHECK(hipMemcpyAsync(velocity, ctx->h2d[4].p, n_vel, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    });
+}
+
+int ltx_dit_set_cross_attn_scale(ltx_ctx* ctx, float scale, int first_block, int last_block) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        DiTModel* m = need_dit(ctx);
+        if (last_block < 0) last_block = m->L - 1;
+        for (int i = first_block; i <= last_block; ++i)
+            if (i >= 0 && i < m->L) m->blocks[i].cross_scale = scale;
+    });
+}
+
+int ltx_dit_set_stg(ltx_ctx* ctx, const int* blocks, int n_blocks, int skip_attn, int skip_ff) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        DiTModel* m = need_dit(ctx);
+        for (int j = 0; j < n_blocks; ++j) {
+            const int i = blocks[j];
+            if (i < 0 || i >= m->L) continue;
+            m->blocks[i].skip_attn = skip_attn != 0;
+            m->blocks[i].skip_ff = skip_ff != 0;
+        }
+    });
+}
+
+int ltx_dit_clear_stg(ltx_ctx* ctx) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        DiTModel* m = need_dit(ctx);
+        for (auto& b : m->blocks) b.skip_attn = b.skip_ff = false;
+    });
+}
+
+// ---- kernel-level hooks ----
+int ltx_op_gemm_bf16(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb, const float* bias, int M,
+                     int N, int K, int act, int tile_cfg, float* out_f32, long ld_f32, uint16_t* out_bf16,
+                     long ld_bf16) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        GemmArgs g;
+        g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+        g.ep.bias_n = bias;
+        g.ep.act = act;
+        g.ep.out_f32 = out_f32; g.ep.ld_f32 = ld_f32;
+        g.ep.out_bf16 = out_bf16; g.ep.ld_bf16 = ld_bf16;
+        if (tile_cfg < 0) launch_gemm_bf16(g, ctx->stream); else launch_gemm_bf16_cfg(g, tile_cfg, ctx->stream);
+    });
+}
+
+int ltx_op_gemm_bf16_gated_residual(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                                    const float* bias, const float* gate, float gate_scalar, int M, int N, int K,
+                                    float* x, long ldx, uint16_t* mirror, long ld_mirror) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        GemmArgs g;
+        g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+        g.ep.bias_n = bias;
+        g.ep.out_f32 = x; g.ep.ld_f32 = ldx;
+        g.ep.resid = 1;
+        g.ep.gate = gate; g.ep.gate_bstride = 0; g.ep.rows_per_batch = M; g.ep.gate_scalar = gate_scalar;
+        g.ep.out_bf16 = mirror; g.ep.ld_bf16 = ld_mirror;
+        launch_gemm_bf16(g, ctx->stream);
+    });
+}
+
+int ltx_op_gemv_f32(ltx_ctx* ctx, const float* a, long lda, const uint16_t* W, long ldw, const float* bias, float* out,
+                    long ldo, int M, int N, int K, int in_act) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { launch_gemv_f32(a, lda, W, ldw, bias, out, ldo, M, N, K, in_act, ctx->stream); });
+}
+
+int ltx_op_attention(ltx_ctx* ctx, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, long ldvt,
+                     const float* bias, int B, int H, int Tq, int Tk, float scale, uint16_t* O) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        AttnArgs a;
+        const long D = (long)H * 128;
+        a.Q = Q; a.ldq = D; a.q_bstride = (long)Tq * D;
+        a.K = K; a.ldk = D; a.k_bstride = (long)Tk * D;
+        a.Vt = Vt; a.ldvt = ldvt; a.vt_bstride = D * ldvt;
+        a.O = O; a.ldo = D; a.o_bstride = (long)Tq * D;
+        a.bias = bias; a.bias_bstride = Tk;
+        a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale;
+        launch_attention(a, ctx->stream);
+    });
+}
+
+int ltx_op_norm_mod(ltx_ctx* ctx, const float* x, const float* scale, const float* shift, int rows, int D,
+                    int norm_kind, float eps, int round_norm_bf16, uint16_t* out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        launch_norm_mod(x, D, scale, shift, 0, rows, out, D, rows, D, norm_kind, eps, round_norm_bf16, ctx->stream);
+    });
+}
+
+int ltx_op_qknorm_rope(ltx_ctx* ctx, const float* x, long ldx, const float* w, const float* cos_t, const float* sin_t,
+                       int T, int rows, int D, float eps, uint16_t* out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { launch_qknorm_rope(x, ldx, w, cos_t, sin_t, T, out, D, rows, D, eps, ctx->stream); });
+}
+
+int ltx_op_fill_normal_bf16(ltx_ctx* ctx, uint16_t* p, long n, uint64_t seed, float mean, float stddev) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { launch_fill_normal_bf16(p, n, seed, mean, stddev, ctx->stream); });
+}
+int ltx_op_fill_normal_f32(ltx_ctx* ctx, float* p, long n, uint64_t seed, float mean, float stddev) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { launch_fill_normal_f32(p, n, seed, mean, stddev, 0, ctx->stream); });
+}
+
+}  // extern "C"

@@ -1,0 +1,20 @@
+// attention.h - launch interface of the flash attention forward kernel (attention.hip).
+#pragma once
+#include "common.h"
+
+struct AttnArgs {
+    const bf16_t* Q = nullptr;   // [B][Tq][ldq], head h occupies columns h*128 .. h*128+127
+    long ldq = 0, q_bstride = 0;
+    const bf16_t* K = nullptr;   // [B][Tk][ldk]
+    long ldk = 0, k_bstride = 0;
+    const bf16_t* Vt = nullptr;  // [B][H*128][ldvt], keys contiguous, ldvt >= roundup(Tk,64), pad columns finite
+    long ldvt = 0, vt_bstride = 0;
+    bf16_t* O = nullptr;         // [B][Tq][ldo]
+    long ldo = 0, o_bstride = 0;
+    const float* bias = nullptr;  // optional additive key mask [B][Tk] (reference: (1-m)*-10000, LTXTransformer.swift:141-156)
+    long bias_bstride = 0;
+    int B = 0, H = 0, Tq = 0, Tk = 0;
+    float scale = 0.08838834764831845f;  // 1/sqrt(128)
+};
+
+void launch_attention(const AttnArgs& args, hipStream_t stream);

@@ -1,0 +1,142 @@
+// common.h - shared device/host helpers for libltxhip (gfx950 / CDNA4 only).
+//
+// Conventions used by every kernel in this directory:
+//   * wavefront = 64 lanes, workgroups are multiples of 64 threads
+//   * bf16 is carried as raw uint16_t/short bits in HBM; arithmetic is f32
+//   * "tokens" are rows of the DiT latent sequence (t = (f*H'+h)*W'+w), "text keys" are rows of the
+//     projected caption context, "positions" are (f,y,x) voxels of a VAE feature map (channels-last)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LTX_DEVFN __device__ __forceinline__
+
+// f32 -> bf16 round-to-nearest-even (NaN stays NaN: plain cast lowers to v_cvt_pk_bf16_f32 on gfx950).
+LTX_DEVFN bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+LTX_DEVFN float bf16_to_f32(bf16_t b) {
+    return __builtin_bit_cast(float, ((uint32_t)b) << 16);
+}
+LTX_DEVFN uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// Host-side bf16 conversions (RNE), used by loaders and synthetic weight generation.
+static inline bf16_t host_f32_to_bf16(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+static inline float host_bf16_to_f32(bf16_t b) {
+    uint32_t u = ((uint32_t)b) << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+static inline float host_f16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1f;
+    uint32_t man = h & 0x3ffu;
+    uint32_t u;
+    if (exp == 0) {
+        if (man == 0) {
+            u = sign;
+        } else {
+            int e = -1;
+            do { e++; man <<= 1; } while ((man & 0x400u) == 0);
+            man &= 0x3ffu;
+            u = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+        }
+    } else if (exp == 31) {
+        u = sign | 0x7f800000u | (man << 13);
+    } else {
+        u = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+LTX_DEVFN float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+LTX_DEVFN float wave_reduce_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// tanh-approximate GELU exactly as the reference's MLXNN.geluApproximate formula
+// (LTXFeedForward.swift:13-17): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3))).
+LTX_DEVFN float gelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f;
+    const float k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+LTX_DEVFN float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// Bijective XCD-aware remap of a linear workgroup id (guide T1): blocks b and b+8 share an XCD under
+// round-robin dispatch, so give each XCD a contiguous chunk of the tile grid. Speed only.
+LTX_DEVFN int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// Status codes mirror LTXError (reference LTXVideo.swift:66-141); keep in sync with include/ltxhip.h.
+enum {
+    LTXS_OK = 0,
+    LTXS_MODEL_NOT_LOADED = 1,
+    LTXS_INVALID_CONFIGURATION = 2,
+    LTXS_INSUFFICIENT_MEMORY = 3,
+    LTXS_WEIGHT_LOADING_FAILED = 4,
+    LTXS_GENERATION_FAILED = 5,
+    LTXS_GENERATION_CANCELLED = 6,
+    LTXS_INVALID_FRAME_COUNT = 7,
+    LTXS_INVALID_DIMENSIONS = 8,
+    LTXS_FILE_NOT_FOUND = 9,
+    LTXS_INVALID_LORA = 10,
+    LTXS_HIP_ERROR = 11,
+};
+
+struct LtxError {
+    int code;
+    std::string msg;
+};
+
+#define LTX_THROW(code_, ...)                                  \
+    do {                                                       \
+        char _buf[512];                                        \
+        snprintf(_buf, sizeof(_buf), __VA_ARGS__);             \
+        throw LtxError{(code_), std::string(_buf)};            \
+    } while (0)
+
+#define HIP_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            LTX_THROW(_e == hipErrorOutOfMemory ? LTXS_INSUFFICIENT_MEMORY : LTXS_HIP_ERROR,     \
+                      "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+    } while (0)
+
+#define LTX_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) LTX_THROW(LTXS_INVALID_CONFIGURATION, __VA_ARGS__); \
+    } while (0)

@@ -1,0 +1,86 @@
+// dit.h - host graph of the video-only LTX-2 DiT (reference LTXTransformer.swift / LTXTransformerBlock.swift /
+// LTXAttention.swift / LTXFeedForward.swift / LTXTimestepEmbedding.swift), sequenced over hand-written gfx950
+// kernels. Weights are resident in one HBM arena in a kernel-friendly layout chosen at load time (q/k projection
+// rows fused so one GEMM feeds the q/k-norm+RoPE pass; biases, norm weights and scale-shift tables as f32 copies
+// of their bf16 values). The safetensors key layout is only the file contract.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "hostmath.h"
+#include "runtime.h"
+
+struct LinearW {
+    bf16_t* w = nullptr;  // [out][in] bf16
+    float* b = nullptr;   // [out] f32 (bf16-representable values)
+    int out = 0, in = 0;
+};
+
+struct DiTBlock {
+    LinearW qk1, v1, o1;  // attn1 (self): to_q|to_k fused [2D][D], to_v, to_out
+    float* qn1 = nullptr;
+    float* kn1 = nullptr;
+    LinearW q2, k2, v2, o2;  // attn2 (text cross-attention)
+    float* qn2 = nullptr;
+    float* kn2 = nullptr;
+    LinearW ff1, ff2;
+    float cross_scale = 1.0f;  // setCrossAttentionScale (LTXTransformer.swift:497)
+    bool skip_attn = false;    // STG flags (LTXTransformer.swift:512-526)
+    bool skip_ff = false;
+};
+
+enum SlotKind { SLOT_BF16 = 0, SLOT_F32 = 1 };
+struct ParamSlot {
+    void* dst = nullptr;
+    int kind = SLOT_BF16;
+    long numel = 0;
+    long rows = 0, cols = 0;  // expected shape (cols = 0 -> vector)
+    int init = 0;             // 0: zeros, 1: ones (reference initialisers for parameters absent from the file)
+    bool loaded = false;
+};
+
+struct DiTModel {
+    TransformerConfig cfg;
+    int D = 0, L = 0;
+    DeviceArena arena;
+    LinearW patchify, ada_l1, ada_l2, ada_lin, cap_l1, cap_l2, proj_out;
+    float* sst_blocks = nullptr;  // [L][6][D]
+    float* sst_out = nullptr;     // [2][D]
+    std::vector<DiTBlock> blocks;
+    std::map<std::string, ParamSlot> slots;  // module key -> destination
+    size_t weight_bytes = 0;
+
+    // ---- caches ----
+    DevBuf rope_cos, rope_sin;  // [T][D/2] f32
+    int rope_F = 0, rope_H = 0, rope_W = 0;
+    // projected caption context and per-layer cross-attention K / V^T (constant across denoise steps:
+    // recomputing them every step as the reference does is output-identical - SURVEY 9.2)
+    DevBuf ctx_proj, ctx_k, ctx_vt, ctx_bias, ctx_tmp_h, ctx_tmp_kraw;
+    uint64_t ctx_version = 0;
+    int ctx_B = 0, ctx_S = 0, ctx_Spad = 0;
+    bool ctx_has_bias = false;
+
+    // ---- activation workspace (grown on demand, never freed inside a step) ----
+    DevBuf ws_x, ws_xn, ws_xb, ws_qk, ws_q, ws_k, ws_vt, ws_ao, ws_ffh, ws_qc;
+    DevBuf ws_ts, ws_emb256, ws_h1, ws_embts, ws_ada, ws_mod, ws_modout;
+    int ws_rows = 0, ws_B = 0, ws_Tpad = 0;
+};
+
+DiTModel* dit_create(const TransformerConfig& cfg);
+void dit_destroy(DiTModel* m);
+// Fill every parameter from a safetensors file using the reference's key mapping; returns counts via ctx.
+void dit_load_safetensors(ltx_ctx* ctx, DiTModel* m, const std::string& path);
+void dit_init_synthetic(ltx_ctx* ctx, DiTModel* m, uint64_t seed);
+
+struct DiTForwardArgs {
+    const bf16_t* latent = nullptr;   // device [B][T][in_channels] bf16
+    const bf16_t* context = nullptr;  // device [B][S][caption_channels] bf16
+    const float* timesteps = nullptr; // device [B] f32 (sigma, unscaled)
+    const int32_t* mask = nullptr;    // device [B][S] int32 or null
+    int mask_all_ones = 0;            // host hint: skip the additive bias entirely (bit-identical: +0.0)
+    int B = 1, F = 0, H = 0, W = 0, S = 0;
+    uint64_t ctx_version = 0;         // 0 = recompute context every call; else cache key
+    float* velocity = nullptr;        // device [B][T][out_channels] f32
+};
+void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a);

@@ -1,0 +1,72 @@
+// elementwise.h - HBM-bound helper kernels around the GEMM/attention cores (elementwise.hip).
+// Every kernel is vectorised (16 B per lane where the layout allows) and fuses the full chain of pointwise work
+// between two matrix products, so each activation tensor is read once and written once.
+#pragma once
+#include "common.h"
+
+enum { LTX_NORM_RMS = 0, LTX_NORM_LAYER = 1 };
+
+// y = norm(x) * (1 + scale[b]) + shift[b]  -> bf16            (adaLN: LTXTransformerBlock.swift:72-83;
+//                                                              final head: LTXTransformer.swift:208-224)
+// x: f32 [rows][D]; scale/shift: f32 [B][mod_bstride] rows (b = row / rows_per_batch), nullable (plain norm).
+// round_norm_bf16: round norm(x) to bf16 before the modulation (block 0 sees a bf16 residual stream in the
+// reference, so MLXFast.rmsNorm returns bf16 there - SURVEY R10 dtype column).
+void launch_norm_mod(const float* x, long ldx, const float* scale, const float* shift, long mod_bstride,
+                     int rows_per_batch, bf16_t* out, long ldo, int rows, int D, int norm_kind, float eps,
+                     int round_norm_bf16, hipStream_t stream);
+
+// q/k RMSNorm across ALL heads with learnable weight, then split-RoPE per head (LTXAttention.swift:179-189,
+// LTXRoPE.swift:84-149). x: f32 [rows][ldx] (D valid columns), w: f32 [D], cos/sin: f32 [T][D/2] indexed by
+// (row % T) with per-head slices of 64 (nullable -> no RoPE, cross-attention). out: bf16 [rows][ldo].
+void launch_qknorm_rope(const float* x, long ldx, const float* w, const float* cosT, const float* sinT, int T,
+                        bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t stream);
+
+void launch_cast_f32_bf16(const float* x, bf16_t* out, long n, hipStream_t stream);
+void launch_cast_bf16_f32(const bf16_t* x, float* out, long n, hipStream_t stream);
+
+// Sinusoidal timestep embedding [cos(t f_i), sin(t f_i)], f_i = exp(-ln(10000) i/128), t = sigma*mult
+// (LTXTimestepEmbedding.swift:17-54). ts: f32 [n], out: f32 [n][256].
+void launch_timestep_embedding(const float* ts, float mult, float* out, int n, int dim, hipStream_t stream);
+
+// mod[b][l][j][d] = table[l][j][d] + ada[b][j][d]   (getAdaValues, LTXTransformerBlock.swift:163-185)
+void launch_make_mod(const float* tables, const float* ada, float* mod, int B, int L, int J, int D, hipStream_t stream);
+
+// int mask -> additive f32 bias (1-m)*-10000 (LTXTransformer.swift:141-156)
+void launch_mask_to_bias(const int32_t* mask, float* bias, long n, hipStream_t stream);
+
+// latent f32 [B][C][F*H*W] -> tokens bf16 [B][T][C] (patchify + .asType(.bfloat16): LatentUtils.swift:20-34,
+// LTXPipeline.swift:815) and the inverse in f32 (LatentUtils.swift:42-54).
+void launch_patchify_bf16(const float* latent, bf16_t* tokens, int B, int C, int T, hipStream_t stream);
+void launch_unpatchify_f32(const float* tokens, float* latent, int B, int C, int T, hipStream_t stream);
+
+// Euler flow-matching update (LTXScheduler.swift:305-327): den = x - s*v; x' = s_next>0 ? den + s_next*(x-den)/s : den
+void launch_euler_step(float* latent, const float* velocity, float sigma, float sigma_next, long n, hipStream_t stream);
+// CFG combine v = cond + (scale-1)*(cond-uncond) (LatentUtils.swift:131-141)
+void launch_cfg_combine(const float* uncond, const float* cond, float scale, float* out, long n, hipStream_t stream);
+// out = a + s*(a - b)   (STG: LTXPipeline.swift:920) ; out = g*(a-b)+b (GE: :924-927) share one kernel
+void launch_axpby(const float* a, const float* b, float ca, float cb, float* out, long n, hipStream_t stream);
+// per-batch population mean/variance over n elements -> stats[b] = {mean, var}
+void launch_mean_var(const float* x, long n_per_batch, int B, float* stats, hipStream_t stream);
+// guidance rescale (LatentUtils.swift:164-183): out = phi*cfg*(std_cond/std_cfg) + (1-phi)*cfg
+void launch_guidance_rescale(float* cfg, const float* stats_cfg, const float* stats_cond, float phi, long n_per_batch,
+                             int B, hipStream_t stream);
+// AdaIN (LatentUtils.swift:201-227): per (b,c) over F*H*W; x <- (x-mu)/(sd+1e-8)*sd_ref + mu_ref, blended by factor
+void launch_adain(float* x, const float* stats_x, const float* stats_ref, float factor, long n_per_chan, int BC,
+                  hipStream_t stream);
+void launch_scale_inplace(float* x, float s, long n, hipStream_t stream);
+// out = ca*a + cb*b
+void launch_lincomb(const float* a, const float* b, float ca, float cb, float* out, long n, hipStream_t stream);
+
+// ---- VAE decoder helpers (channels-last f32 stream [P][C]) ----
+// latent [C][P] f32 (+ optional noise blend) * std + mean -> channels-last bf16 [P][C] (VideoDecoder.swift:366-381)
+void launch_vae_prepare(const float* latent, const float* noise, float noise_scale, const float* mean, const float* std_,
+                        bf16_t* out, int C, long P, hipStream_t stream);
+// pixel-norm over channels (eps 1e-8) * scale + shift -> SiLU -> bf16 (VideoDecoder.swift:29-32,118-127,419-436).
+// scale already contains the +1. x: f32 [P][C].
+void launch_pixelnorm_silu(const float* x, const float* scale, const float* shift, bf16_t* out, long P, int C,
+                           hipStream_t stream);
+// conv_out [F*H*W][ldx] f32 (48 valid channels) -> frames (F, 4H, 4W, 3) f32 = clip((x+1)/2, 0, 1)
+// (unpatchify VideoDecoder.swift:257-275 + decodeVideo :501-505). When blend_w >= 0 nothing is blended here;
+// temporal-tile blending is done by launch_blend_frames on the (F,H,W,3) tensors.
+void launch_vae_unpatchify_frames(const float* x, long ldx, float* frames, int F, int H, int W, int apply_clip,
+                                  hipStream_t stream);

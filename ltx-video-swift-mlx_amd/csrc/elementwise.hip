@@ -1,0 +1,534 @@
+// elementwise.hip - HBM-bound kernels of the DiT / VAE path (see elementwise.h for the reference call sites).
+// All are streaming kernels: 16-B (or 8-B bf16) accesses per lane, one pass over the data, reductions via
+// wave shuffles + one LDS hop. Roofline for each is HBM bytes / 8 TB/s; none of them is reshaped into a GEMM.
+#include "elementwise.h"
+
+namespace {
+
+constexpr int MAXV = 8;  // float4 chunks per thread kept in registers by the row kernels (D <= 8192)
+
+LTX_DEVFN float block_reduce_sum(float v, float* red) {
+    v = wave_reduce_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` from a previous use
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// one workgroup (256 threads) per row
+__global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__ x, long ldx,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, long mod_bstride,
+                                                       int rows_per_batch, bf16_t* __restrict__ out, long ldo, int D,
+                                                       int norm_kind, float eps, int round_norm_bf16) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const float* xr = x + (long)row * ldx;
+    f32x4 v[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+    const int nchunk = D >> 2;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < nchunk) {
+            v[j] = *(const f32x4*)(xr + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1 += v[j][e];
+                s2 += v[j][e] * v[j][e];
+            }
+        }
+    }
+    float mean = 0.f, rstd;
+    if (norm_kind == LTX_NORM_LAYER) {
+        mean = block_reduce_sum(s1, red) / (float)D;
+        // two-pass variance on the register copy (population variance, as MLXNN.LayerNorm)
+        float sv = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = threadIdx.x + j * 256;
+            if (c < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[j][e] - mean;
+                    sv += d * d;
+                }
+            }
+        }
+        const float var = block_reduce_sum(sv, red) / (float)D;
+        rstd = rsqrtf(var + eps);
+    } else {
+        const float ms = block_reduce_sum(s2, red) / (float)D;
+        rstd = rsqrtf(ms + eps);
+    }
+    const long b = row / rows_per_batch;
+    const float* sc = scale ? scale + b * mod_bstride : nullptr;
+    const float* sh = shift ? shift + b * mod_bstride : nullptr;
+    bf16_t* orow = out + (long)row * ldo;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < nchunk) {
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (v[j][e] - mean) * rstd;
+                if (round_norm_bf16) y[e] = bf16_to_f32(f32_to_bf16(y[e]));
+            }
+            if (sc) {
+                const f32x4 s4 = *(const f32x4*)(sc + c * 4);
+                const f32x4 h4 = *(const f32x4*)(sh + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = y[e] * (1.0f + s4[e]) + h4[e];
+            }
+            uint2 pk;
+            pk.x = pack_bf16x2(y[0], y[1]);
+            pk.y = pack_bf16x2(y[2], y[3]);
+            *(uint2*)(orow + c * 4) = pk;
+        }
+    }
+}
+
+// one workgroup per row; thread handles float4 chunks of the first half `a` of a head and the matching `b` chunk
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(const float* __restrict__ x, long ldx,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ cosT,
+                                                          const float* __restrict__ sinT, int T,
+                                                          bf16_t* __restrict__ out, long ldo, int D, float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const float* xr = x + (long)row * ldx;
+    // pair chunk p (0 .. D/8-1): head = p / 16, i4 = p % 16 ; a at head*128 + i4*4, b at +64
+    const int npair = D >> 3;
+    constexpr int MAXP = MAXV / 2;
+    f32x4 va[MAXP], vb[MAXP];
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+        const int p = threadIdx.x + j * 256;
+        if (p < npair) {
+            const int col = (p >> 4) * 128 + (p & 15) * 4;
+            va[j] = *(const f32x4*)(xr + col);
+            vb[j] = *(const f32x4*)(xr + col + 64);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s2 += va[j][e] * va[j][e] + vb[j][e] * vb[j][e];
+        }
+    }
+    const float rstd = rsqrtf(block_reduce_sum(s2, red) / (float)D + eps);
+    const int t = row % T;
+    bf16_t* orow = out + (long)row * ldo;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+        const int p = threadIdx.x + j * 256;
+        if (p < npair) {
+            const int col = (p >> 4) * 128 + (p & 15) * 4;
+            const f32x4 wa = *(const f32x4*)(w + col);
+            const f32x4 wb = *(const f32x4*)(w + col + 64);
+            f32x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = va[j][e] * rstd * wa[e];
+                b[e] = vb[j][e] * rstd * wb[e];
+            }
+            if (cosT) {
+                // cos/sin rows are [T][D/2]; head h uses columns h*64 .. h*64+63
+                const int fc = (p >> 4) * 64 + (p & 15) * 4;
+                const f32x4 c4 = *(const f32x4*)(cosT + (long)t * (D >> 1) + fc);
+                const f32x4 s4 = *(const f32x4*)(sinT + (long)t * (D >> 1) + fc);
+                // the reference rounds the normed q/k to its storage dtype before the f32 rotation only when that
+                // dtype is bf16 (cross-modal case); in the DiT q,k are f32 here (LTXRoPE.swift:90-92).
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = a[e], b0 = b[e];
+                    a[e] = a0 * c4[e] - b0 * s4[e];
+                    b[e] = b0 * c4[e] + a0 * s4[e];
+                }
+            }
+            uint2 pa, pb;
+            pa.x = pack_bf16x2(a[0], a[1]);
+            pa.y = pack_bf16x2(a[2], a[3]);
+            pb.x = pack_bf16x2(b[0], b[1]);
+            pb.y = pack_bf16x2(b[2], b[3]);
+            *(uint2*)(orow + col) = pa;
+            *(uint2*)(orow + col + 64) = pb;
+        }
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long n) {
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        const f32x4 v = *(const f32x4*)(x + i);
+        uint2 pk;
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
+        *(uint2*)(out + i) = pk;
+    }
+    if (i < n && i + 3 >= n)
+        for (long k = i; k < n; ++k) out[k] = f32_to_bf16(x[k]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = bf16_to_f32(x[i]);
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ ts, float mult, float* __restrict__ out, int n,
+                                          int dim) {
+    const int half = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * half) return;
+    const int r = i / half, k = i - r * half;
+    const float t = ts[r] * mult;
+    const float freq = expf(-logf(10000.0f) * ((float)k / (float)half));
+    const float arg = t * freq;
+    out[(long)r * dim + k] = cosf(arg);
+    out[(long)r * dim + half + k] = sinf(arg);
+}
+
+__global__ void make_mod_kernel(const float* __restrict__ tables, const float* __restrict__ ada,
+                                float* __restrict__ mod, int B, int L, int J, int D) {
+    const long n = (long)B * L * J * D;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int d = i % D;
+        long r = i / D;
+        const int j = r % J;
+        r /= J;
+        const int l = r % L;
+        const int b = r / L;
+        mod[i] = tables[((long)l * J + j) * D + d] + ada[((long)b * J + j) * D + d];
+    }
+}
+
+__global__ void mask_to_bias_kernel(const int32_t* __restrict__ mask, float* __restrict__ bias, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bias[i] = (1.0f - (float)mask[i]) * -10000.0f;
+}
+
+// latent [B][C][T] f32 -> tokens [B][T][C] bf16 through a 32x32 LDS transpose tile
+__global__ __launch_bounds__(256) void patchify_bf16_kernel(const float* __restrict__ latent,
+                                                            bf16_t* __restrict__ tokens, int C, int T) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, t = t0 + tx;
+        tile[k][tx] = (c < C && t < T) ? latent[((long)b * C + c) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int t = t0 + k, c = c0 + tx;
+        if (t < T && c < C) tokens[((long)b * T + t) * C + c] = f32_to_bf16(tile[tx][k]);
+    }
+}
+__global__ __launch_bounds__(256) void unpatchify_f32_kernel(const float* __restrict__ tokens,
+                                                             float* __restrict__ latent, int C, int T) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int t = t0 + k, c = c0 + tx;
+        tile[k][tx] = (t < T && c < C) ? tokens[((long)b * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, t = t0 + tx;
+        if (c < C && t < T) latent[((long)b * C + c) * T + t] = tile[tx][k];
+    }
+}
+
+__global__ void euler_step_kernel(float* __restrict__ latent, const float* __restrict__ vel, float sigma,
+                                  float sigma_next, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = latent[i];
+    const float den = x - sigma * vel[i];
+    latent[i] = (sigma_next > 0.f) ? den + sigma_next * (x - den) / sigma : den;
+}
+__global__ void cfg_combine_kernel(const float* __restrict__ uncond, const float* __restrict__ cond, float sm1,
+                                   float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cond[i] + sm1 * (cond[i] - uncond[i]);
+}
+// out = ca*(a-b) + cb_sel, where the two guidance forms are expressed as out = a*pa + b*pb
+__global__ void lincomb_kernel(const float* __restrict__ a, const float* __restrict__ b, float ca, float cb,
+                               float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ca * a[i] + cb * b[i];
+}
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float ca, float cb,
+                             float* __restrict__ out, long n) {
+    // out = a*1 ... kept separate from lincomb to preserve the reference's operation order:
+    // STG: v + s*(v - vp)  (ca = s, cb = 1 -> out = cb*a + ca*(a-b))
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cb * a[i] + ca * (a[i] - b[i]);
+}
+__global__ void scale_inplace_kernel(float* __restrict__ x, float s, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= s;
+}
+
+// one workgroup per segment: population mean / variance (two-pass over a segment of n elements)
+__global__ __launch_bounds__(1024) void mean_var_kernel(const float* __restrict__ x, long n, float* __restrict__ stats) {
+    __shared__ float red[16];
+    const float* xs = x + (long)blockIdx.x * n;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) s += xs[i];
+    const float mean = block_reduce_sum(s, red) / (float)n;
+    float v = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        const float d = xs[i] - mean;
+        v += d * d;
+    }
+    const float var = block_reduce_sum(v, red) / (float)n;
+    if (threadIdx.x == 0) {
+        stats[blockIdx.x * 2 + 0] = mean;
+        stats[blockIdx.x * 2 + 1] = var;
+    }
+}
+__global__ void guidance_rescale_kernel(float* __restrict__ cfg, const float* __restrict__ st_cfg,
+                                        const float* __restrict__ st_cond, float phi, long n_per_batch) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= n_per_batch) return;
+    const float eps = 1e-8f;
+    const float cfg_std = sqrtf(st_cfg[b * 2 + 1] + eps);
+    const float cond_std = sqrtf(st_cond[b * 2 + 1] + eps);
+    const float v = cfg[(long)b * n_per_batch + i];
+    const float rescaled = v * (cond_std / cfg_std);
+    cfg[(long)b * n_per_batch + i] = phi * rescaled + (1.0f - phi) * v;
+}
+__global__ void adain_kernel(float* __restrict__ x, const float* __restrict__ st_x, const float* __restrict__ st_ref,
+                             float factor, long n_per_chan) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int bc = blockIdx.y;
+    if (i >= n_per_chan) return;
+    const float mu = st_x[bc * 2], sd = sqrtf(st_x[bc * 2 + 1]);
+    const float mur = st_ref[bc * 2], sdr = sqrtf(st_ref[bc * 2 + 1]);
+    const float v = x[(long)bc * n_per_chan + i];
+    const float res = (v - mu) / (sd + 1e-8f) * sdr + mur;
+    x[(long)bc * n_per_chan + i] = (factor >= 1.0f) ? res : factor * res + (1.0f - factor) * v;
+}
+
+// ---- VAE ----
+// latent [C][P] f32 -> channels-last bf16 [P][C], with optional noise blend and per-channel denormalisation
+__global__ __launch_bounds__(256) void vae_prepare_kernel(const float* __restrict__ latent,
+                                                          const float* __restrict__ noise, float noise_scale,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ std_, bf16_t* __restrict__ out,
+                                                          int C, long P) {
+    __shared__ float tile[32][33];
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k;
+        const long p = p0 + tx;
+        float v = 0.f;
+        if (c < C && p < P) {
+            v = latent[(long)c * P + p];
+            if (noise) v = noise[(long)c * P + p] * noise_scale + (1.0f - noise_scale) * v;
+            v = v * std_[c] + mean[c];
+        }
+        tile[k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const long p = p0 + k;
+        const int c = c0 + tx;
+        if (p < P && c < C) out[p * C + c] = f32_to_bf16(tile[tx][k]);
+    }
+}
+
+// one wave per position when C <= 256*... generic: a group of G = C/4 lanes (<= 256) per position
+template <int LANES_PER_POS>
+__global__ __launch_bounds__(256) void pixelnorm_silu_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             bf16_t* __restrict__ out, long P, int C) {
+    // each lane owns C/(4*LANES_PER_POS) float4 chunks; LANES_PER_POS lanes cooperate via shuffles (<= 64)
+    constexpr int POS_PER_BLOCK = 256 / LANES_PER_POS;
+    const int sub = threadIdx.x % LANES_PER_POS;
+    const long p = (long)blockIdx.x * POS_PER_BLOCK + threadIdx.x / LANES_PER_POS;
+    const int nchunk = C >> 2;
+    const bool active = p < P;
+    const float* xr = x + (active ? p : 0) * (long)C;
+    f32x4 v[4];
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = sub + j * LANES_PER_POS;
+        if (c < nchunk) {
+            v[j] = *(const f32x4*)(xr + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s2 += v[j][e] * v[j][e];
+        }
+    }
+#pragma unroll
+    for (int off = LANES_PER_POS >> 1; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+    const float inv = 1.0f / sqrtf(s2 / (float)C + 1e-8f);
+    if (!active) return;
+    bf16_t* orow = out + p * (long)C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = sub + j * LANES_PER_POS;
+        if (c < nchunk) {
+            const f32x4 s4 = *(const f32x4*)(scale + c * 4);
+            const f32x4 h4 = *(const f32x4*)(shift + c * 4);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = silu_f(v[j][e] * inv * s4[e] + h4[e]);
+            uint2 pk;
+            pk.x = pack_bf16x2(y[0], y[1]);
+            pk.y = pack_bf16x2(y[2], y[3]);
+            *(uint2*)(orow + c * 4) = pk;
+        }
+    }
+}
+
+// x: [F*H*W][ldx] f32 with channel = (c*4 + a)*4 + b ; frames (F, 4H, 4W, 3): a -> W offset, b -> H offset
+__global__ void vae_unpatchify_frames_kernel(const float* __restrict__ x, long ldx, float* __restrict__ frames, int F,
+                                             int H, int W, int apply_clip) {
+    const long n = (long)F * H * W * 48;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // enumerate outputs so that consecutive threads write consecutive floats of the (F,4H,4W,3) tensor:
+    // i = (((f*4H + Y)*4W + X)*3 + c)
+    const int c = i % 3;
+    long r = i / 3;
+    const int X = r % (4 * W);
+    r /= (4 * W);
+    const int Y = r % (4 * H);
+    const int f = r / (4 * H);
+    const int w = X >> 2, a = X & 3, h = Y >> 2, b = Y & 3;
+    float v = x[(((long)f * H + h) * W + w) * ldx + (c * 4 + a) * 4 + b];
+    if (apply_clip) v = fminf(fmaxf((v + 1.0f) * 0.5f, 0.f), 1.f);
+    frames[i] = v;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+void launch_norm_mod(const float* x, long ldx, const float* scale, const float* shift, long mod_bstride,
+                     int rows_per_batch, bf16_t* out, long ldo, int rows, int D, int norm_kind, float eps,
+                     int round_norm_bf16, hipStream_t stream) {
+    LTX_REQUIRE(D % 4 == 0 && D <= MAXV * 1024 && ldx % 4 == 0 && ldo % 4 == 0, "norm_mod: D=%d ldx=%ld ldo=%ld", D, ldx, ldo);
+    LTX_REQUIRE((scale == nullptr) == (shift == nullptr), "norm_mod: scale/shift must both be set or both null");
+    hipLaunchKernelGGL(norm_mod_kernel, dim3(rows), dim3(256), 0, stream, x, ldx, scale, shift, mod_bstride,
+                       rows_per_batch < 1 ? 1 : rows_per_batch, out, ldo, D, norm_kind, eps, round_norm_bf16);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_qknorm_rope(const float* x, long ldx, const float* w, const float* cosT, const float* sinT, int T,
+                        bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t stream) {
+    LTX_REQUIRE(D % 128 == 0 && D <= MAXV * 1024 && ldx % 4 == 0 && ldo % 4 == 0, "qknorm_rope: D=%d", D);
+    hipLaunchKernelGGL(qknorm_rope_kernel, dim3(rows), dim3(256), 0, stream, x, ldx, w, cosT, sinT, T < 1 ? 1 : T, out,
+                       ldo, D, eps);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_cast_f32_bf16(const float* x, bf16_t* out, long n, hipStream_t stream) {
+    const int grid = cdiv(n, 4 * 256) < 2048 ? (cdiv(n, 4 * 256) < 1 ? 1 : cdiv(n, 4 * 256)) : 2048;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, stream, x, out, n);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_cast_bf16_f32(const bf16_t* x, float* out, long n, hipStream_t stream) {
+    const int grid = cdiv(n, 256) < 4096 ? (cdiv(n, 256) < 1 ? 1 : cdiv(n, 256)) : 4096;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, stream, x, out, n);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_timestep_embedding(const float* ts, float mult, float* out, int n, int dim, hipStream_t stream) {
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv((long)n * (dim / 2), 256)), dim3(256), 0, stream, ts, mult, out, n, dim);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_make_mod(const float* tables, const float* ada, float* mod, int B, int L, int J, int D, hipStream_t stream) {
+    const long n = (long)B * L * J * D;
+    const int grid = cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048;
+    hipLaunchKernelGGL(make_mod_kernel, dim3(grid), dim3(256), 0, stream, tables, ada, mod, B, L, J, D);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_mask_to_bias(const int32_t* mask, float* bias, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(mask_to_bias_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, mask, bias, n);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_patchify_bf16(const float* latent, bf16_t* tokens, int B, int C, int T, hipStream_t stream) {
+    hipLaunchKernelGGL(patchify_bf16_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, stream, latent, tokens, C, T);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_unpatchify_f32(const float* tokens, float* latent, int B, int C, int T, hipStream_t stream) {
+    hipLaunchKernelGGL(unpatchify_f32_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, stream, tokens, latent, C, T);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_euler_step(float* latent, const float* velocity, float sigma, float sigma_next, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(euler_step_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, latent, velocity, sigma, sigma_next, n);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_cfg_combine(const float* uncond, const float* cond, float scale, float* out, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, uncond, cond, scale - 1.0f, out, n);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_axpby(const float* a, const float* b, float ca, float cb, float* out, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(axpby_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, a, b, ca, cb, out, n);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_lincomb(const float* a, const float* b, float ca, float cb, float* out, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(lincomb_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, a, b, ca, cb, out, n);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_scale_inplace(float* x, float s, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, s, n);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_mean_var(const float* x, long n_per_batch, int B, float* stats, hipStream_t stream) {
+    hipLaunchKernelGGL(mean_var_kernel, dim3(B), dim3(1024), 0, stream, x, n_per_batch, stats);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_guidance_rescale(float* cfg, const float* stats_cfg, const float* stats_cond, float phi, long n_per_batch,
+                             int B, hipStream_t stream) {
+    hipLaunchKernelGGL(guidance_rescale_kernel, dim3(cdiv(n_per_batch, 256), B), dim3(256), 0, stream, cfg, stats_cfg, stats_cond, phi, n_per_batch);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_adain(float* x, const float* stats_x, const float* stats_ref, float factor, long n_per_chan, int BC,
+                  hipStream_t stream) {
+    hipLaunchKernelGGL(adain_kernel, dim3(cdiv(n_per_chan, 256), BC), dim3(256), 0, stream, x, stats_x, stats_ref, factor, n_per_chan);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_vae_prepare(const float* latent, const float* noise, float noise_scale, const float* mean, const float* std_,
+                        bf16_t* out, int C, long P, hipStream_t stream) {
+    hipLaunchKernelGGL(vae_prepare_kernel, dim3(cdiv(P, 32), cdiv(C, 32)), dim3(256), 0, stream, latent, noise, noise_scale, mean, std_, out, C, P);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_pixelnorm_silu(const float* x, const float* scale, const float* shift, bf16_t* out, long P, int C,
+                           hipStream_t stream) {
+    LTX_REQUIRE(C % 4 == 0 && C <= 1024, "pixelnorm: C=%d", C);
+    // lanes per position: enough that each lane holds <= 4 float4 chunks, power of two, <= 64
+    const int nchunk = C / 4;
+    int lpp = 1;
+    while (lpp * 4 < nchunk) lpp <<= 1;
+    if (lpp < 8) lpp = 8;
+    LTX_REQUIRE(lpp <= 64, "pixelnorm: C=%d too wide", C);
+#define PN_LAUNCH(L)                                                                                              \
+    hipLaunchKernelGGL((pixelnorm_silu_kernel<L>), dim3(cdiv(P, 256 / L)), dim3(256), 0, stream, x, scale, shift, out, P, C)
+    if (lpp == 8) PN_LAUNCH(8);
+    else if (lpp == 16) PN_LAUNCH(16);
+    else if (lpp == 32) PN_LAUNCH(32);
+    else PN_LAUNCH(64);
+#undef PN_LAUNCH
+    HIP_CHECK(hipGetLastError());
+}
+void launch_vae_unpatchify_frames(const float* x, long ldx, float* frames, int F, int H, int W, int apply_clip,
+                                  hipStream_t stream) {
+    const long n = (long)F * H * W * 48;
+    hipLaunchKernelGGL(vae_unpatchify_frames_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, ldx, frames, F, H, W, apply_clip);
+    HIP_CHECK(hipGetLastError());
+}

@@ -1,0 +1,64 @@
+// gemm.h - launch interface of the bf16 MFMA GEMM family (gemm.hip).
+//
+// C[M,N] = A[M,K] * B[N,K]^T with both operands K-contiguous (activations [rows,K], weights [out,in] exactly as
+// the reference's Linear stores them: LTXAttention.swift:152-157, "Linear weights are [out,in]" SURVEY R20).
+// The A operand can also be an implicit im2col view of a channels-last VAE feature map (conv3d mode), which is
+// how the 27-tap Conv3dFull of the reference (VideoConvolution.swift:238-347) is realised without materialising
+// padded tensors.
+#pragma once
+#include "common.h"
+
+enum { LTX_ACT_NONE = 0, LTX_ACT_GELU_TANH = 1, LTX_ACT_SILU = 2 };
+
+struct GemmEpilogue {
+    float* out_f32 = nullptr;     // [M, ld_f32]
+    long ld_f32 = 0;
+    bf16_t* out_bf16 = nullptr;   // [M, ld_bf16]
+    long ld_bf16 = 0;
+    const float* bias_n = nullptr;  // per output column (the usual Linear bias)
+    const float* bias_m = nullptr;  // per output row (used when operands are swapped to emit C^T)
+    int act = LTX_ACT_NONE;
+    int round_bf16 = 0;  // round (acc+bias, activated) through bf16 before any f32 store/residual use
+    // residual mode: out_f32[m][n] = resid_src[m][n] + gate(m,n) * (acc + bias); gate(m,n) =
+    //   gate ? gate[(m / rows_per_batch) * gate_bstride + n] : gate_scalar
+    // (reference residualGate: LTXTransformerBlock.swift:86-92; cross-attn scale :211-214)
+    int resid = 0;
+    const float* gate = nullptr;
+    long gate_bstride = 0;
+    int rows_per_batch = 1;
+    float gate_scalar = 1.0f;
+    const float* resid_src = nullptr;  // defaults to out_f32 (in-place) when null
+    long ld_resid = 0;
+    // depth-to-space store (VAE upsampler, VideoDecoder.swift:201-251). When d2s != 0 the output row index is
+    // remapped: see conv3d section in gemm.hip.
+    int d2s = 0;
+};
+
+// Geometry of an implicit-GEMM conv3d A operand: x is [F][H][W][C] bf16 (channels-last), 3x3x3 taps,
+// reflect padding in H/W and replicate padding in T (non-causal) or causal (first frame repeated twice).
+struct Conv3dGeom {
+    int F = 0, H = 0, W = 0, C = 0;
+    int causal = 0;
+    int pad_mode = 0;  // 0 reflect, 1 zeros(not supported by gather: clamps to a zero row), 2 replicate
+};
+
+struct GemmArgs {
+    const bf16_t* A = nullptr;
+    long lda = 0;
+    const bf16_t* B = nullptr;
+    long ldb = 0;
+    int M = 0, N = 0, K = 0;
+    int conv = 0;  // 1: A is an implicit conv3d view described by geom, K = 27*C
+    Conv3dGeom geom;
+    GemmEpilogue ep;
+};
+
+// Launches on `stream`. Picks the tile shape from (M,N). Throws LtxError on invalid shapes.
+void launch_gemm_bf16(const GemmArgs& args, hipStream_t stream);
+// Force a tile config (0: 128x128, 1: 192x128, 2: 256x128) - used by tests/bench sweeps.
+void launch_gemm_bf16_cfg(const GemmArgs& args, int cfg, hipStream_t stream);
+
+// Small-M path (M <= 8): out[m][n] = act_out( sum_k in_act(a[m][k]) * W[n][k] + bias[n] ), f32 activations x bf16
+// weights -> f32, exactly the reference's promotion on the timestep path.
+void launch_gemv_f32(const float* a, long lda, const bf16_t* W, long ldw, const float* bias, float* out, long ldo,
+                     int M, int N, int K, int in_act, hipStream_t stream);

@@ -1,0 +1,396 @@
+// gemm.hip - bf16 MFMA GEMM for gfx950 (CDNA4): C[M,N] = A[M,K] * B[N,K]^T, f32 accumulate, fused epilogues.
+//
+// This is the kernel that carries ~92 % of the DiT step's FLOPs (reference call sites: every `Linear` of
+// LTXAttention.swift:171-175,217, LTXFeedForward.swift:26,49, LTXTransformer.swift:257,223) and, through the
+// implicit-im2col A loader, every Conv3dFull of the VAE decoder (VideoConvolution.swift:238-347).
+//
+// Design (MI355X-first, not a translation of anything):
+//   * 256-thread workgroup = 4 waves (2x2), each wave owns a (BM/2)x(BN/2) output sub-tile as
+//     v_mfma_f32_16x16x32_bf16 accumulators.
+//   * K is walked in 64-element (128-byte) tiles. Both operands are K-contiguous, so A and B tiles are the same
+//     LDS image: [rows][128 B], filled by LDS-DMA (`global_load_lds_dwordx4`, 1 KiB per wave-instruction = 8 rows)
+//     with the bank swizzle applied on the per-lane SOURCE address (16-B chunk c of row r lives at chunk
+//     c ^ ((r>>1)&7)); fragments come back with conflict-free ds_read_b128.
+//   * two LDS stages, one barrier per K-tile (prefetch tile t+1 while the MFMAs of tile t run).
+//   * epilogue through a per-wave LDS transpose so global stores are 16 B/lane, row-contiguous.
+//   * workgroup ids are remapped so that each XCD's L2 sees a contiguous chunk of the tile grid.
+#include "gemm.h"
+
+namespace {
+
+constexpr int BK = 64;            // bf16 elements per K-tile
+constexpr int ROW_BYTES = BK * 2;  // 128 B per tile row
+
+struct RowPos {  // conv3d: decoded output position of an A row
+    int f, y, x;
+};
+
+LTX_DEVFN int reflect_idx(int i, int n) {
+    // reflect padding by 1 (VideoConvolution.swift:258-266): -1 -> 1, n -> n-2
+    i = (i < 0) ? -i : i;
+    return (i >= n) ? (2 * n - 2 - i) : i;
+}
+LTX_DEVFN int clamp_idx(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_PER_WAVE = BM / 32, B_PER_WAVE = BN / 32;  // wave-instructions (8 rows each) per wave
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging: per-lane source pointers (swizzle on the source side, LDS image stays lane-linear) ----
+    const int srow = lane >> 3;  // row inside an 8-row wave-instruction
+    const int pch = lane & 7;    // physical 16-B chunk the lane writes
+    const bf16_t* a_src[A_PER_WAVE];
+    const bf16_t* b_src[B_PER_WAVE];
+    RowPos a_pos[A_PER_WAVE];
+    int a_lch[A_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int row = (wave + 4 * i) * 8 + srow;
+        const int lch = pch ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < g.M ? gm : g.M - 1;
+        a_lch[i] = lch;
+        if constexpr (CONV) {
+            const int hw = g.geom.H * g.geom.W;
+            a_pos[i].f = gm / hw;
+            const int rem = gm - a_pos[i].f * hw;
+            a_pos[i].y = rem / g.geom.W;
+            a_pos[i].x = rem - a_pos[i].y * g.geom.W;
+            a_src[i] = g.A;
+        } else {
+            a_src[i] = g.A + (long)gm * g.lda + lch * 8;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i) {
+        const int row = (wave + 4 * i) * 8 + srow;
+        const int lch = pch ^ ((row >> 1) & 7);
+        int gn = n0 + row;
+        gn = gn < g.N ? gn : g.N - 1;
+        b_src[i] = g.B + (long)gn * g.ldb + lch * 8;
+    }
+    const int nk = g.K / BK;
+    const int cpt = CONV ? (g.geom.C / BK) : 1;  // K-tiles per conv tap
+
+    auto stage = [&](int s, int kt) {
+        char* base = smem + s * STAGE;
+        if constexpr (CONV) {
+            const int tap = kt / cpt;
+            const int cc = kt - tap * cpt;
+            const int dt = tap / 9, dy = (tap - dt * 9) / 3, dx = tap - dt * 9 - dy * 3;
+#pragma unroll
+            for (int i = 0; i < A_PER_WAVE; ++i) {
+                int fi = g.geom.causal ? (a_pos[i].f + dt - 2) : (a_pos[i].f + dt - 1);
+                fi = clamp_idx(fi, g.geom.F);
+                int yi, xi;
+                if (g.geom.pad_mode == 0) {
+                    yi = reflect_idx(a_pos[i].y + dy - 1, g.geom.H);
+                    xi = reflect_idx(a_pos[i].x + dx - 1, g.geom.W);
+                } else {
+                    yi = clamp_idx(a_pos[i].y + dy - 1, g.geom.H);
+                    xi = clamp_idx(a_pos[i].x + dx - 1, g.geom.W);
+                }
+                const long pos = ((long)fi * g.geom.H + yi) * g.geom.W + xi;
+                const bf16_t* src = g.A + pos * g.geom.C + cc * BK + a_lch[i] * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024),
+                                                 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PER_WAVE; ++i) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(a_src[i] + (long)kt * BK),
+                    (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_WAVE; ++i) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(b_src[i] + (long)kt * BK),
+                (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (per lane constants; the row-dependent XOR term only depends on lane&15) ----
+    const int frow = lane & 15;
+    const int fsw = (lane >> 1) & 7;
+    const int foff0 = frow * ROW_BYTES + ((((lane >> 4) + 0) ^ fsw) << 4);
+    const int foff1 = frow * ROW_BYTES + ((((lane >> 4) + 4) ^ fsw) << 4);
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* abase = smem + cur * STAGE + (wr * WM) * ROW_BYTES;
+        const char* bbase = smem + cur * STAGE + A_BYTES + (wc * WN) * ROW_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int fo = kk ? foff1 : foff0;
+            s16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const s16x8*)(abase + i * 16 * ROW_BYTES + fo);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = *(const s16x8*)(bbase + j * 16 * ROW_BYTES + fo);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                        __builtin_bit_cast(bf16x8_t, bfr[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();  // LDS-DMA of the next stage has landed (vmcnt(0)) and every wave is done reading `cur`
+    }
+
+    // ---- epilogue: per-wave LDS transpose (16 rows at a time), then 16-B row-contiguous global accesses ----
+    float* scr = (float*)(smem + wave * (16 * WN * 4));
+    constexpr int LPR = WN / 4;    // lanes per output row
+    constexpr int RPI = 64 / LPR;  // rows per wave-instruction
+    const GemmEpilogue& ep = g.ep;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = acc[mi][ni][r];
+#pragma unroll
+        for (int it = 0; it < 16 / RPI; ++it) {
+            const int row = it * RPI + lane / LPR;
+            const int c4 = (lane % LPR) * 4;
+            f32x4 v = *(const f32x4*)(scr + row * WN + c4);
+            const int gm = m0 + wr * WM + mi * 16 + row;
+            const int gn = n0 + wc * WN + c4;
+            if (gm >= g.M || gn >= g.N) continue;
+            const int nv = (g.N - gn) < 4 ? (g.N - gn) : 4;
+            if (ep.bias_n) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nv) v[e] += ep.bias_n[gn + e];
+            }
+            if (ep.bias_m) {
+                const float bm = ep.bias_m[gm];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bm;
+            }
+            if (ep.act == LTX_ACT_GELU_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+            } else if (ep.act == LTX_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+            }
+            if (ep.round_bf16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
+            }
+            long orow = gm;  // output row (remapped for depth-to-space)
+            int ocol = gn;
+            if (ep.d2s) {
+                // VAE upsampler (VideoDecoder.swift:201-251). Conv output channels were permuted at load time to
+                // n' = sub*Cout + c (sub = dt*4+dh*2+dw), so this 4-wide chunk has one `sub` and consecutive c.
+                const int cout = g.N >> 3;
+                const int sub = gn / cout;
+                const int c = gn - sub * cout;
+                const int dt = sub >> 2, dh = (sub >> 1) & 1, dw = sub & 1;
+                const int hw = g.geom.H * g.geom.W;
+                const int f = gm / hw;
+                const int rem = gm - f * hw;
+                const int y = rem / g.geom.W;
+                const int x = rem - y * g.geom.W;
+                const int fo = 2 * f + dt - 1;  // first frame after D2S is dropped
+                if (fo < 0) continue;
+                orow = ((long)fo * (2 * g.geom.H) + (2 * y + dh)) * (2 * g.geom.W) + (2 * x + dw);
+                ocol = c;
+                if (ep.resid_src) {
+                    // residual = D2S(x)[c mod C/8], tiled along channels (VideoDecoder.swift:219-234)
+                    const int cd2s = g.geom.C >> 3;
+                    const float* rs = ep.resid_src + (long)gm * ep.ld_resid;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e < nv) v[e] += rs[((c + e) % cd2s) * 8 + sub];
+                }
+            } else if (ep.resid) {
+                const float* rs = (ep.resid_src ? ep.resid_src + (long)gm * ep.ld_resid : ep.out_f32 + (long)gm * ep.ld_f32) + gn;
+                f32x4 gt;
+                if (ep.gate) {
+                    const float* gp = ep.gate + (long)(gm / ep.rows_per_batch) * ep.gate_bstride + gn;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gt[e] = (e < nv) ? gp[e] : 0.f;
+                } else {
+                    gt = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nv) v[e] = rs[e] + gt[e] * v[e];
+            }
+            if (ep.out_f32) {
+                float* o = ep.out_f32 + orow * ep.ld_f32 + ocol;
+                if (nv == 4) {
+                    *(f32x4*)o = v;
+                } else {
+                    for (int e = 0; e < nv; ++e) o[e] = v[e];
+                }
+            }
+            if (ep.out_bf16) {
+                bf16_t* o = ep.out_bf16 + orow * ep.ld_bf16 + ocol;
+                if (nv == 4) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)o = pk;
+                } else {
+                    for (int e = 0; e < nv; ++e) o[e] = f32_to_bf16(v[e]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small-M path: one wave per output column, f32 activations x bf16 weights
+// ---------------------------------------------------------------------------------------------------------------
+template <int MMAX>
+__global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ a, long lda,
+                                                       const bf16_t* __restrict__ W, long ldw,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       long ldo, int M, int N, int K, int in_act) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float accv[MMAX];
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) accv[m] = 0.f;
+    const bf16_t* wrow = W + (long)n * ldw;
+    for (int k = lane * 8; k < K; k += 512) {
+        const s16x8 wv = *(const s16x8*)(wrow + k);
+        float wf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wf[e] = bf16_to_f32((bf16_t)wv[e]);
+#pragma unroll
+        for (int m = 0; m < MMAX; ++m) {
+            if (m < M) {
+                const f32x4 a0 = *(const f32x4*)(a + (long)m * lda + k);
+                const f32x4 a1 = *(const f32x4*)(a + (long)m * lda + k + 4);
+                float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = av[e];
+                    if (in_act == LTX_ACT_SILU) x = silu_f(x);
+                    accv[m] += x * wf[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) {
+        const float s = wave_reduce_sum(accv[m]);
+        if (lane == 0 && m < M) out[(long)m * ldo + n] = s + (bias ? bias[n] : 0.f);
+    }
+}
+
+template <int BM, int BN, bool CONV>
+void launch_one(const GemmArgs& a, hipStream_t stream) {
+    constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, CONV>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, CONV>), dim3(tiles), dim3(256), smem, stream, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+void validate(const GemmArgs& a) {
+    LTX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    LTX_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
+    LTX_REQUIRE(a.A && a.B, "gemm: null operand");
+    LTX_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0, "gemm: operands must be 16-B aligned");
+    LTX_REQUIRE(a.ldb % 8 == 0, "gemm: ldb=%ld must be a multiple of 8", a.ldb);
+    if (a.conv) {
+        LTX_REQUIRE(a.geom.C % BK == 0 && a.K == 27 * a.geom.C, "gemm/conv3d: C=%d K=%d", a.geom.C, a.K);
+        LTX_REQUIRE(a.M == a.geom.F * a.geom.H * a.geom.W, "gemm/conv3d: M=%d != F*H*W", a.M);
+        LTX_REQUIRE(a.geom.H >= 2 && a.geom.W >= 2, "gemm/conv3d: reflect padding needs H,W >= 2");
+    } else {
+        LTX_REQUIRE(a.lda % 8 == 0, "gemm: lda=%ld must be a multiple of 8", a.lda);
+    }
+    const GemmEpilogue& e = a.ep;
+    LTX_REQUIRE(e.out_f32 || e.out_bf16, "gemm: no output");
+    if (e.out_f32) LTX_REQUIRE(e.ld_f32 % 4 == 0 && ((uintptr_t)e.out_f32 & 15) == 0, "gemm: f32 output alignment");
+    if (e.out_bf16) LTX_REQUIRE(e.ld_bf16 % 4 == 0 && ((uintptr_t)e.out_bf16 & 7) == 0, "gemm: bf16 output alignment");
+    if (e.resid && !e.d2s) LTX_REQUIRE(e.out_f32 || e.resid_src, "gemm: residual mode needs an f32 stream");
+    if (e.d2s) LTX_REQUIRE(a.conv && a.N % 32 == 0, "gemm: d2s epilogue needs conv mode and N%%32==0");
+}
+
+}  // namespace
+
+void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
+    validate(a);
+    if (a.conv) {
+        switch (cfg) {
+            case 0: launch_one<128, 128, true>(a, stream); break;
+            case 1: launch_one<192, 128, true>(a, stream); break;
+            default: launch_one<256, 128, true>(a, stream); break;
+        }
+    } else {
+        switch (cfg) {
+            case 0: launch_one<128, 128, false>(a, stream); break;
+            case 1: launch_one<192, 128, false>(a, stream); break;
+            default: launch_one<256, 128, false>(a, stream); break;
+        }
+    }
+}
+
+void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
+    // Tile choice: minimise (waves of workgroups over 256 CUs x 2 resident blocks) x tile cost. With M=1536 and
+    // N=4096 (the DiT's most common shape) 192x128 gives exactly 256 workgroups = one per CU.
+    const long n_tiles = (a.N + 127) / 128;
+    auto cost = [&](int bm) {
+        const long tiles = ((a.M + bm - 1) / bm) * n_tiles;
+        const long slots = 512;  // two resident workgroups per CU
+        const long rounds = (tiles + slots - 1) / slots;
+        // a round with <=256 tiles runs one block per CU (faster per block than two co-resident ones)
+        const double per_round = (tiles <= 256) ? 0.62 : 1.0;
+        return (double)rounds * per_round * bm;
+    };
+    int best = 0;
+    double bc = cost(128);
+    if (cost(192) < bc) { best = 1; bc = cost(192); }
+    if (cost(256) < bc) { best = 2; bc = cost(256); }
+    launch_gemm_bf16_cfg(a, best, stream);
+}
+
+void launch_gemv_f32(const float* a, long lda, const bf16_t* W, long ldw, const float* bias, float* out, long ldo,
+                     int M, int N, int K, int in_act, hipStream_t stream) {
+    LTX_REQUIRE(M >= 1 && M <= 8, "gemv: M=%d out of range (1..8)", M);
+    LTX_REQUIRE(K % 8 == 0 && lda % 4 == 0 && ldw % 8 == 0, "gemv: K=%d lda=%ld ldw=%ld alignment", K, lda, ldw);
+    const int grid = (N + 3) / 4;
+    if (M <= 2)
+        hipLaunchKernelGGL((gemv_f32_kernel<2>), dim3(grid), dim3(256), 0, stream, a, lda, W, ldw, bias, out, ldo, M, N, K, in_act);
+    else
+        hipLaunchKernelGGL((gemv_f32_kernel<8>), dim3(grid), dim3(256), 0, stream, a, lda, W, ldw, bias, out, ldo, M, N, K, in_act);
+    HIP_CHECK(hipGetLastError());
+}

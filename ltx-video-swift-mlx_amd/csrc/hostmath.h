@@ -1,0 +1,56 @@
+// hostmath.h - pure host logic of the path: shapes, validation, sigma schedules, RoPE tables, VAE tiling plan and
+// safetensors key mapping. No HIP calls here; everything is exported through the C ABI so the CPU test-suite can
+// pin it against hand-derived known-answer vectors.
+#pragma once
+#include <string>
+#include <vector>
+
+struct TransformerConfig {
+    // defaults = LTXTransformerConfig (reference LTXConfig.swift:83-177)
+    int num_layers = 48;
+    int num_heads = 32;
+    int head_dim = 128;
+    int in_channels = 128;
+    int out_channels = 128;
+    int cross_attention_dim = 4096;
+    int caption_channels = 3840;
+    float rope_theta = 10000.0f;
+    int max_pos[3] = {20, 2048, 2048};
+    float timestep_scale_multiplier = 1000.0f;
+    float norm_eps = 1e-6f;
+    int inner_dim() const { return num_heads * head_dim; }
+};
+
+// LTXVideoGenerationConfig.validate (LTXConfig.swift:310-353) + two-stage %64 rule (LTXPipeline.swift:2443).
+// Returns 0 when valid, else an LTXS_* code; msg receives the reference's error text.
+int validate_generation_config(int width, int height, int num_frames, int num_steps, float cfg_scale, int two_stage,
+                               std::string* msg);
+
+// F' = (F-1)/8+1, H' = H/32, W' = W/32 (VideoLatentShape.swift:34-41, LTXConfig.swift:356-361)
+void latent_shape(int width, int height, int num_frames, int* F, int* H, int* W);
+
+// LTXScheduler.setTimesteps (LTXScheduler.swift:74-182) in f32 scalar arithmetic.
+std::vector<float> compute_sigmas(bool distilled, int num_steps, int token_count /* <=0: none */);
+extern const float kDistilledSigmas[9];
+extern const float kStage2DistilledSigmas[4];
+
+// createPositionGrid + precomputeFreqsCisDoublePrecision (LTXRoPE.swift:552-610, 375-527), split RoPE.
+// cos/sin are written as [T][D/2] f32 (token-major; head h owns columns h*64..h*64+63) - the same values as the
+// reference's [B,H,T,64] tensors, batch-independent.
+void rope_tables(const TransformerConfig& cfg, int F, int H, int W, float fps, std::vector<float>* cos_out,
+                 std::vector<float>* sin_out);
+
+// decodeWithTemporalTiling's chunk walk (VideoDecoder.swift:517-548) and output frame count (:561-592).
+struct TilePlan {
+    std::vector<int> start, end;  // latent-frame ranges [start,end)
+    int out_frames = 0;
+};
+TilePlan vae_tile_plan(int latent_frames, int tile, int overlap);
+
+// mapTransformerKey / loadTransformerWeights filters (ModelDownloader.swift:605-639,756-803).
+// `file_key` is the raw safetensors key. Returns false when the key is skipped.
+bool map_transformer_file_key(const std::string& file_key, std::string* module_key);
+// mapVAEWeights (ModelDownloader.swift:808-899). Accepts keys with or without the unified file's "vae." prefix.
+bool map_vae_file_key(const std::string& file_key, std::string* module_key);
+// LoRA key -> module weight key (LoRALoader.swift:209-243)
+bool map_lora_key(const std::string& lora_base, std::string* module_weight_key);

@@ -1,0 +1,106 @@
+// runtime.h - context, device memory and safetensors plumbing shared by the DiT / VAE host graphs.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+// RAII device allocation that only grows (activation workspaces are sized on first use and then reused: no
+// hipMalloc/hipFree inside a denoise step).
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    // returns true when (re)allocated
+    bool ensure(size_t n, bool zero = false) {
+        if (n <= bytes && p) return false;
+        release();
+        HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+        if (zero) HIP_CHECK(hipMemset(p, 0, n));
+        return true;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+// One big allocation carved into 256-B aligned tensors (weights live here for the lifetime of a model).
+struct DeviceArena {
+    DevBuf buf;
+    size_t used = 0;
+    std::vector<size_t> pending;  // sizes requested before commit
+    void reserve(size_t total) {
+        buf.ensure(total);
+        used = 0;
+    }
+    void* take(size_t n) {
+        const size_t off = (used + 255) & ~(size_t)255;
+        if (off + n > buf.bytes) LTX_THROW(LTXS_INSUFFICIENT_MEMORY, "arena overflow: need %zu, have %zu", off + n, buf.bytes);
+        used = off + n;
+        return (char*)buf.p + off;
+    }
+    static size_t padded(size_t n) { return (n + 255) & ~(size_t)255; }
+};
+
+// ---- safetensors (header JSON + mmap) ----
+struct StTensor {
+    std::string dtype;  // "BF16", "F32", "F16", "I32", ...
+    std::vector<long> shape;
+    size_t begin = 0, end = 0;  // byte offsets into the data section
+    long numel() const {
+        long n = 1;
+        for (long s : shape) n *= s;
+        return n;
+    }
+};
+struct SafeTensors {
+    std::map<std::string, StTensor> tensors;
+    const uint8_t* data = nullptr;  // start of the data section inside the mapping
+    void* map_base = nullptr;
+    size_t map_len = 0;
+    int fd = -1;
+    SafeTensors() = default;
+    SafeTensors(const SafeTensors&) = delete;
+    ~SafeTensors() { close(); }
+    void open(const std::string& path);  // throws LtxError (fileNotFound / weightLoadingFailed)
+    void close();
+    const uint8_t* ptr(const StTensor& t) const { return data + t.begin; }
+};
+// Convert `n` elements of a safetensors tensor to bf16 bits / f32 on the host.
+void st_to_bf16(const SafeTensors& st, const StTensor& t, bf16_t* out);
+void st_to_f32(const SafeTensors& st, const StTensor& t, float* out);
+
+struct DiTModel;
+struct VaeModel;
+struct UpscalerModel;
+
+struct ltx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    DiTModel* dit = nullptr;
+    VaeModel* vae = nullptr;
+    UpscalerModel* upscaler = nullptr;
+    // staging buffers for host-pointer entry points
+    DevBuf h2d[8];
+    // load report of the last *_load call (mirrors the reference's "unmatched/missing" debug logs)
+    int n_loaded = 0, n_missing = 0, n_unmatched = 0;
+};
+
+// synthetic weights (bench / property tests): counter-based normal fill on device
+void launch_fill_normal_bf16(bf16_t* p, long n, uint64_t seed, float mean, float stddev, hipStream_t stream);
+void launch_fill_normal_f32(float* p, long n, uint64_t seed, float mean, float stddev, int round_bf16, hipStream_t stream);
+void launch_fill_const_f32(float* p, long n, float v, hipStream_t stream);

@@ -1,0 +1,763 @@
+"""CPU oracle for the LTX-2 denoise + VAE-decode hot path.  *** TEST INFRASTRUCTURE - NOT THE PRODUCT ***
+
+This file is a numpy restatement of the reference's algorithm (VincentGourbin/ltx-video-swift-mlx, Swift + MLX)
+for the functions listed in SURVEY.md section 8(a). Each function cites the reference file:line it follows.
+Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import it; the product path
+(`libltxhip.so`) never does and has no CPU fallback.
+
+PARITY UNPINNED: the reference ships no golden vectors, fixtures or numeric tests for this path (its only test
+asserts a version string: Tests/LTXVideoTests/LTXVideoTests.swift:9-11) and it cannot be built or run here (Swift +
+Apple MLX, macOS only; arithmetic lives in the un-vendored third-party package mlx-swift exact 0.30.6,
+Package.swift:21). This oracle is therefore pinned only by
+  (1) hand-derived integer / scalar known-answer vectors from the reference source (tests/test_host_logic.py),
+  (2) op-level cross-checks against an independent implementation (torch CPU) - tests/golden/make_golden.py,
+not by outputs of the reference itself.
+
+dtype model: the reference's effective precision (inferred from MLX promotion rules, not
+observable here) is f32 activations x bf16-rounded weights, with bf16 storage only for the patchify projection,
+the caption projection and the cross-attention K/V. `bf16_round` marks those rounding points.
+"""
+import math
+
+import numpy as np
+
+F32 = np.float32
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 helpers
+# ---------------------------------------------------------------------------------------------------------------
+def f32_to_bf16_bits(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16).reshape(x.shape)
+
+
+def bf16_bits_to_f32(b):
+    b = np.ascontiguousarray(b, dtype=np.uint16)
+    return (b.astype(np.uint32) << 16).view(np.float32).reshape(b.shape)
+
+
+def bf16_round(x):
+    """Round f32 values to the nearest bf16 (ties to even), returned as f32."""
+    return bf16_bits_to_f32(f32_to_bf16_bits(x))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R1: configuration validation and latent shapes (LTXConfig.swift:310-361, VideoLatentShape.swift:34-48,95-111)
+# ---------------------------------------------------------------------------------------------------------------
+def validate_generation_config(width, height, num_frames, num_steps, cfg_scale, two_stage=False):
+    """Returns None when valid, else the reference's error message (LTXError.invalidConfiguration)."""
+    if width % 32 != 0:
+        return f"Width must be divisible by 32, got {width}"
+    if height % 32 != 0:
+        return f"Height must be divisible by 32, got {height}"
+    if (num_frames - 1) % 8 != 0:
+        return f"Number of frames must be 8n + 1 (e.g., 9, 17, 25, ..., 121), got {num_frames}"
+    if not (64 <= width <= 2048):
+        return f"Width must be between 64 and 2048, got {width}"
+    if not (64 <= height <= 2048):
+        return f"Height must be between 64 and 2048, got {height}"
+    if not (9 <= num_frames <= 257):
+        return f"Number of frames must be between 9 and 257, got {num_frames}"
+    if not (1 <= num_steps <= 100):
+        return f"Number of steps must be between 1 and 100, got {num_steps}"
+    if not (1.0 <= cfg_scale <= 20.0):
+        return f"CFG scale must be between 1.0 and 20.0, got {cfg_scale:g}"
+    if two_stage and (width % 64 != 0 or height % 64 != 0):  # LTXPipeline.swift:2443
+        return f"Two-stage generation requires width and height divisible by 64, got {width}x{height}"
+    return None
+
+
+def latent_shape(width, height, num_frames):
+    return (num_frames - 1) // 8 + 1, height // 32, width // 32
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R3: sigma schedules (LTXScheduler.swift:10-36,74-182), f32 scalar arithmetic without FMA
+# ---------------------------------------------------------------------------------------------------------------
+DISTILLED_SIGMA_VALUES = [1.0, 0.99375, 0.9875, 0.98125, 0.975, 0.909375, 0.725, 0.421875, 0.0]
+STAGE_2_DISTILLED_SIGMA_VALUES = [0.909375, 0.725, 0.421875, 0.0]
+
+
+def _expf(x):
+    """Correctly rounded f32 exp (what glibc/Apple libm expf return for these arguments); numpy's SIMD float32 exp is
+    1 ulp off for mu = 2.05 and mu = 0.629, which moves two sigmas by 1-2 ulp."""
+    return F32(math.exp(float(x)))
+
+
+def sigmas(distilled, num_steps, token_count=None, max_shift=2.05, base_shift=0.95, terminal=0.1):
+    one = F32(1.0)
+    max_shift, base_shift, terminal = F32(max_shift), F32(base_shift), F32(terminal)
+    x1, x2 = F32(1024), F32(4096)
+    mm = F32(F32(max_shift - base_shift) / F32(x2 - x1))
+    b = F32(base_shift - F32(mm * x1))
+    if distilled:
+        s = [F32(v) for v in DISTILLED_SIGMA_VALUES if v > 0]
+        if token_count:
+            clamped = min(int(token_count), 4096)
+            mu = F32(F32(F32(clamped) * mm) + b)
+            exp_mu = _expf(mu)
+            s = [v if (v == 0 or v == one) else F32(exp_mu / F32(exp_mu + F32(F32(one / v) - one))) for v in s]
+            last_om = F32(one - s[-1])
+            if last_om > 0:
+                sf = F32(last_om / F32(one - terminal))
+                s = [F32(0) if v == 0 else F32(one - F32(F32(one - v) / sf)) for v in s]
+        s.append(F32(0.0))
+        return np.array(s, dtype=F32)
+    tc = min(int(token_count) if token_count else 4096, 4096)
+    s = [F32(one - F32(F32(i) / F32(num_steps))) for i in range(num_steps + 1)]
+    shift = F32(F32(F32(tc) * mm) + b)
+    exp_shift = _expf(shift)
+    s = [F32(0) if v == 0 else F32(exp_shift / F32(exp_shift + F32(F32(one / v) - one))) for v in s]
+    if num_steps > 0:
+        om = [F32(one - v) for v in s]
+        sf = F32(om[num_steps - 1] / F32(one - terminal))
+        s = [F32(0) if v == 0 else F32(one - F32(om[i] / sf)) for i, v in enumerate(s)]
+    return np.array(s, dtype=F32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R4: patchify / unpatchify (LatentUtils.swift:20-54)
+# ---------------------------------------------------------------------------------------------------------------
+def patchify(latent):
+    b, c, f, h, w = latent.shape
+    return latent.transpose(0, 2, 3, 4, 1).reshape(b, f * h * w, c)
+
+
+def unpatchify(x, f, h, w):
+    b, t, c = x.shape
+    return x.reshape(b, f, h, w, c).transpose(0, 4, 1, 2, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R8 + R9: position grid and double-precision split-RoPE tables (LTXRoPE.swift:552-610, 375-527)
+# ---------------------------------------------------------------------------------------------------------------
+def position_grid(frames, height, width, fps=24.0):
+    """(3, T) f32 pixel-space mid coordinates; temporal with causal fix, divided by fps."""
+    ts, ss, fps = F32(8), F32(32), F32(fps)
+    tcv = []
+    for i in range(frames):
+        fi = F32(i)
+        start = max(F32(F32(fi * ts) + F32(1 - ts)), F32(0))
+        end = max(F32(F32(F32(fi + 1) * ts) + F32(1 - ts)), F32(0))
+        tcv.append(F32(F32(F32(start + end) / F32(2)) / fps))
+    hc = [F32(F32(F32(i) * ss) + F32(ss / F32(2))) for i in range(height)]
+    wc = [F32(F32(F32(i) * ss) + F32(ss / F32(2))) for i in range(width)]
+    t = np.broadcast_to(np.array(tcv, F32)[:, None, None], (frames, height, width)).reshape(-1)
+    h = np.broadcast_to(np.array(hc, F32)[None, :, None], (frames, height, width)).reshape(-1)
+    w = np.broadcast_to(np.array(wc, F32)[None, None, :], (frames, height, width)).reshape(-1)
+    return np.stack([t, h, w], 0).astype(F32)
+
+
+def rope_tables(frames, height, width, dim=4096, num_heads=32, theta=10000.0, max_pos=(20, 2048, 2048)):
+    """cos, sin as [T][dim/2] f32 (== the reference's [B,H,T,64] tensors flattened per token: head h owns columns
+    h*64 .. h*64+63)."""
+    grid = position_grid(frames, height, width).astype(np.float64)  # (3, T)
+    n_pos = 3
+    n_elem = 2 * n_pos
+    n_idx = max(1, dim // n_elem)
+    log_start = math.log(1.0) / math.log(theta)
+    log_end = math.log(theta) / math.log(theta)
+    idx = np.array([math.pow(theta, log_start + (log_end - log_start) * i / (n_idx - 1) if n_idx > 1 else log_start)
+                    * (math.pi / 2.0) for i in range(n_idx)], dtype=np.float64)
+    frac = grid / np.array(max_pos, dtype=np.float64)[:, None]
+    scaled = frac * 2.0 - 1.0  # (3, T)
+    freqs = idx[None, :, None] * scaled.T[:, None, :]  # (T, n_idx, 3): index fi*3 + d
+    freqs = freqs.reshape(grid.shape[1], n_idx * n_pos)
+    cosv = np.array([[math.cos(v) for v in row] for row in freqs], dtype=np.float64)
+    sinv = np.array([[math.sin(v) for v in row] for row in freqs], dtype=np.float64)
+    pad = max(0, dim // 2 - n_idx * n_pos)
+    T = grid.shape[1]
+    cos = np.concatenate([np.ones((T, pad), F32), cosv.astype(F32)], axis=1)
+    sin = np.concatenate([np.zeros((T, pad), F32), sinv.astype(F32)], axis=1)
+    assert cos.shape[1] == dim // 2 and (dim // 2) % num_heads == 0
+    return cos, sin
+
+
+def apply_split_rope(x, cos, sin, num_heads):
+    """applySplitRotaryEmb (LTXRoPE.swift:84-149). x [B,T,H*D] f32; cos/sin [T, H*D/2]."""
+    b, t, hd = x.shape
+    d = hd // num_heads
+    xh = x.reshape(b, t, num_heads, 2, d // 2).astype(F32)
+    c = cos.reshape(1, t, num_heads, d // 2)
+    s = sin.reshape(1, t, num_heads, d // 2)
+    first, second = xh[:, :, :, 0], xh[:, :, :, 1]
+    out = np.stack([first * c - second * s, second * c + first * s], axis=3)
+    return out.reshape(b, t, hd).astype(F32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# small ops
+# ---------------------------------------------------------------------------------------------------------------
+def linear(x, w, b=None):
+    """Linear with weights [out,in] (MLXNN.Linear): f32 accumulate."""
+    y = x.astype(F32) @ w.astype(F32).T
+    if b is not None:
+        y = y + b.astype(F32)
+    return y.astype(F32)
+
+
+def rms_norm(x, weight=None, eps=1e-6):
+    """MLXFast.rmsNorm (LTXAttention.swift:12-33): x * rsqrt(mean(x^2) + eps) * w over the last axis."""
+    x = x.astype(F32)
+    ms = np.mean(x.astype(np.float64) ** 2, axis=-1, keepdims=True)
+    y = x * (1.0 / np.sqrt(ms + eps)).astype(F32)
+    if weight is not None:
+        y = y * weight.astype(F32)
+    return y.astype(F32)
+
+
+def layer_norm(x, eps=1e-6):
+    """LayerNorm(affine: false) (LTXTransformer.swift:96)."""
+    x64 = x.astype(np.float64)
+    mu = x64.mean(-1, keepdims=True)
+    var = ((x64 - mu) ** 2).mean(-1, keepdims=True)
+    return ((x64 - mu) / np.sqrt(var + eps)).astype(F32)
+
+
+def gelu_tanh(x):
+    """MLXNN.geluApproximate (LTXFeedForward.swift:13-17)."""
+    x = x.astype(F32)
+    return (F32(0.5) * x * (F32(1.0) + np.tanh(F32(0.7978845608028654) * (x + F32(0.044715) * x * x * x)))).astype(F32)
+
+
+def silu(x):
+    x = x.astype(F32)
+    return (x / (F32(1.0) + np.exp(-x))).astype(F32)
+
+
+def sdpa(q, k, v, num_heads, scale, bias=None):
+    """MLXFast.scaledDotProductAttention on [B,T,H*D] inputs (LTXAttention.swift:192-214). bias [B,S] additive."""
+    b, tq, hd = q.shape
+    tk = k.shape[1]
+    d = hd // num_heads
+    qh = q.reshape(b, tq, num_heads, d).transpose(0, 2, 1, 3).astype(F32)
+    kh = k.reshape(b, tk, num_heads, d).transpose(0, 2, 1, 3).astype(F32)
+    vh = v.reshape(b, tk, num_heads, d).transpose(0, 2, 1, 3).astype(F32)
+    out = np.empty((b, num_heads, tq, d), F32)
+    for bi in range(b):
+        for h in range(num_heads):
+            s = (qh[bi, h] @ kh[bi, h].T) * F32(scale)
+            if bias is not None:
+                s = s + bias[bi][None, :].astype(F32)
+            s = s - s.max(-1, keepdims=True)
+            p = np.exp(s)
+            p = p / p.sum(-1, keepdims=True)
+            out[bi, h] = p @ vh[bi, h]
+    return out.transpose(0, 2, 1, 3).reshape(b, tq, hd)
+
+
+def timestep_embedding(t, dim=256):
+    """getTimestepEmbedding (LTXTimestepEmbedding.swift:17-54): [cos, sin] order, f32."""
+    half = dim // 2
+    freqs = np.exp(-F32(math.log(10000.0)) * (np.arange(half, dtype=F32) / F32(half))).astype(F32)
+    args = np.asarray(t, F32).reshape(-1, 1) * freqs[None, :]
+    return np.concatenate([np.cos(args), np.sin(args)], -1).astype(F32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R5-R14: the DiT (LTXTransformer.swift:235-486). `w` maps module keys to f32 arrays holding
+# bf16-rounded values.
+# ---------------------------------------------------------------------------------------------------------------
+class DiTConfig:
+    def __init__(self, num_layers=48, num_heads=32, head_dim=128, in_channels=128, out_channels=128,
+                 caption_channels=3840, rope_theta=10000.0, max_pos=(20, 2048, 2048), timestep_mult=1000.0,
+                 norm_eps=1e-6):
+        self.num_layers, self.num_heads, self.head_dim = num_layers, num_heads, head_dim
+        self.in_channels, self.out_channels, self.caption_channels = in_channels, out_channels, caption_channels
+        self.rope_theta, self.max_pos, self.timestep_mult, self.norm_eps = rope_theta, max_pos, timestep_mult, norm_eps
+
+    @property
+    def dim(self):
+        return self.num_heads * self.head_dim
+
+
+def dit_param_shapes(cfg):
+    """Module keys and shapes expected after key mapping (LTXTransformer.swift:34-101)."""
+    D = cfg.dim
+    s = {
+        "patchify_proj.weight": (D, cfg.in_channels), "patchify_proj.bias": (D,),
+        "adaln_single.emb.linear_1.weight": (D, 256), "adaln_single.emb.linear_1.bias": (D,),
+        "adaln_single.emb.linear_2.weight": (D, D), "adaln_single.emb.linear_2.bias": (D,),
+        "adaln_single.linear.weight": (6 * D, D), "adaln_single.linear.bias": (6 * D,),
+        "caption_projection.linear_1.weight": (D, cfg.caption_channels), "caption_projection.linear_1.bias": (D,),
+        "caption_projection.linear_2.weight": (D, D), "caption_projection.linear_2.bias": (D,),
+        "scale_shift_table": (2, D),
+        "proj_out.weight": (cfg.out_channels, D), "proj_out.bias": (cfg.out_channels,),
+    }
+    for i in range(cfg.num_layers):
+        p = f"transformer_blocks.{i}."
+        for a in ("attn1", "attn2"):
+            for l in ("to_q", "to_k", "to_v", "to_out"):
+                s[p + f"{a}.{l}.weight"] = (D, D)
+                s[p + f"{a}.{l}.bias"] = (D,)
+            s[p + f"{a}.q_norm.weight"] = (D,)
+            s[p + f"{a}.k_norm.weight"] = (D,)
+        s[p + "ff.project_in.proj.weight"] = (4 * D, D)
+        s[p + "ff.project_in.proj.bias"] = (4 * D,)
+        s[p + "ff.project_out.weight"] = (D, 4 * D)
+        s[p + "ff.project_out.bias"] = (D,)
+        s[p + "scale_shift_table"] = (6, D)
+    return s
+
+
+def attention(w, prefix, x, cfg, context=None, bias=None, rope=None, kv_bf16=False):
+    """LTXAttention.callAsFunction (LTXAttention.swift:160-218)."""
+    H = cfg.num_heads
+    ctx = x if context is None else context
+    q = linear(x, w[prefix + "to_q.weight"], w[prefix + "to_q.bias"])
+    k = linear(ctx, w[prefix + "to_k.weight"], w[prefix + "to_k.bias"])
+    v = linear(ctx, w[prefix + "to_v.weight"], w[prefix + "to_v.bias"])
+    if kv_bf16:  # cross-attention K/V come out of bf16 x bf16 Linears in the reference
+        k, v = bf16_round(k), bf16_round(v)
+    q = rms_norm(q, w[prefix + "q_norm.weight"], cfg.norm_eps)
+    k = rms_norm(k, w[prefix + "k_norm.weight"], cfg.norm_eps)
+    if kv_bf16:
+        k = bf16_round(k)
+    if rope is not None:
+        q = apply_split_rope(q, rope[0], rope[1], H)
+        k = apply_split_rope(k, rope[0], rope[1], H)
+    o = sdpa(q, k, v, H, 1.0 / math.sqrt(cfg.head_dim), bias)
+    return linear(o, w[prefix + "to_out.weight"], w[prefix + "to_out.bias"])
+
+
+def feed_forward(w, prefix, x):
+    """LTXFeedForward (LTXFeedForward.swift:35-52)."""
+    h = gelu_tanh(linear(x, w[prefix + "project_in.proj.weight"], w[prefix + "project_in.proj.bias"]))
+    return linear(h, w[prefix + "project_out.weight"], w[prefix + "project_out.bias"])
+
+
+def transformer_block(w, i, x, ctx, temb, cfg, rope, bias, cross_scale=1.0, skip_attn=False, skip_ff=False,
+                      first_norm_bf16=False):
+    """BasicTransformerBlock.callAsFunction (LTXTransformerBlock.swift:187-232). temb [B,1,6,D]."""
+    p = f"transformer_blocks.{i}."
+    ada = w[p + "scale_shift_table"][None, None].astype(F32) + temb  # [B,1,6,D]
+    shift_msa, scale_msa, gate_msa = ada[:, :, 0], ada[:, :, 1], ada[:, :, 2]
+    shift_mlp, scale_mlp, gate_mlp = ada[:, :, 3], ada[:, :, 4], ada[:, :, 5]
+    if not skip_attn:
+        n = rms_norm(x, None, cfg.norm_eps)
+        if first_norm_bf16:  # block 0 normalises a bf16 stream: MLXFast.rmsNorm returns bf16 there
+            n = bf16_round(n)
+        n = n * (F32(1) + scale_msa) + shift_msa
+        x = x + attention(w, p + "attn1.", n, cfg, rope=rope) * gate_msa
+    cross = attention(w, p + "attn2.", x, cfg, context=ctx, bias=bias, kv_bf16=True)
+    if cross_scale != 1.0:
+        cross = cross * F32(cross_scale)
+    x = x + cross
+    if not skip_ff:
+        n = rms_norm(x, None, cfg.norm_eps) * (F32(1) + scale_mlp) + shift_mlp
+        x = x + feed_forward(w, p + "ff.", n) * gate_mlp
+    return x.astype(F32)
+
+
+def caption_projection(w, context):
+    """PixArtAlphaTextProjection on a bf16 context (LTXTimestepEmbedding.swift:131-152): bf16 at every stage."""
+    h = bf16_round(linear(context, w["caption_projection.linear_1.weight"], w["caption_projection.linear_1.bias"]))
+    h = bf16_round(gelu_tanh(h))
+    return bf16_round(linear(h, w["caption_projection.linear_2.weight"], w["caption_projection.linear_2.bias"]))
+
+
+def mask_to_bias(mask):
+    """prepareAttentionMask (LTXTransformer.swift:141-156): (1-m)*-10000."""
+    if mask is None:
+        return None
+    return ((F32(1) - mask.astype(F32)) * F32(-10000.0)).astype(F32)
+
+
+def dit_forward(w, cfg, latent, context, timesteps, mask, F, H, W, cross_scale=None, stg_blocks=(), skip_ff_blocks=(),
+                num_layers=None):
+    """LTXTransformer.callAsFunction (LTXTransformer.swift:235-486).
+    latent [B,T,C] (bf16-representable f32), context [B,S,Cc] (bf16-representable), timesteps [B] sigma."""
+    D = cfg.dim
+    B = latent.shape[0]
+    x = bf16_round(linear(latent, w["patchify_proj.weight"], w["patchify_proj.bias"]))
+    t = np.asarray(timesteps, F32) * F32(cfg.timestep_mult)
+    e = timestep_embedding(t, 256)
+    e = linear(e, w["adaln_single.emb.linear_1.weight"], w["adaln_single.emb.linear_1.bias"])
+    emb_ts = linear(silu(e), w["adaln_single.emb.linear_2.weight"], w["adaln_single.emb.linear_2.bias"])  # [B,D]
+    ada = linear(silu(emb_ts), w["adaln_single.linear.weight"], w["adaln_single.linear.bias"])  # [B,6D]
+    temb = ada.reshape(B, 1, 6, D)
+    ctx = caption_projection(w, context).reshape(B, -1, D)
+    bias = mask_to_bias(mask)
+    rope = rope_tables(F, H, W, D, cfg.num_heads, cfg.rope_theta, cfg.max_pos)
+    L = cfg.num_layers if num_layers is None else num_layers
+    for i in range(L):
+        cs = 1.0 if cross_scale is None else cross_scale
+        x = transformer_block(w, i, x, ctx, temb, cfg, rope, bias, cs, skip_attn=(i in stg_blocks),
+                              skip_ff=(i in skip_ff_blocks), first_norm_bf16=(i == 0))
+    # processOutput (LTXTransformer.swift:208-224)
+    ss = w["scale_shift_table"][None, None].astype(F32) + emb_ts.reshape(B, 1, 1, D)
+    shift, scale = ss[:, :, 0], ss[:, :, 1]
+    out = layer_norm(x, cfg.norm_eps) * (F32(1) + scale) + shift
+    return linear(out, w["proj_out.weight"], w["proj_out.bias"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R15-R17: guidance and the Euler step
+# ---------------------------------------------------------------------------------------------------------------
+def apply_cfg(uncond, cond, scale):
+    """LatentUtils.swift:131-141."""
+    return (cond + F32(scale - 1.0) * (cond - uncond)).astype(F32)
+
+
+def guidance_rescale(cfg_out, cond_out, phi):
+    """LatentUtils.swift:164-183 (population variance over C,F,H,W; eps inside the sqrt)."""
+    if phi <= 0:
+        return cfg_out
+    ax = tuple(range(1, cfg_out.ndim))
+    cfg_std = np.sqrt(cfg_out.astype(np.float64).var(axis=ax, keepdims=True) + 1e-8)
+    cond_std = np.sqrt(cond_out.astype(np.float64).var(axis=ax, keepdims=True) + 1e-8)
+    rescaled = cfg_out * (cond_std / cfg_std).astype(F32)
+    return (F32(phi) * rescaled + F32(1.0 - phi) * cfg_out).astype(F32)
+
+
+def adain_filter_latent(latent, reference, factor=1.0):
+    """LatentUtils.swift:201-227."""
+    if factor <= 0:
+        return latent
+    ax = (2, 3, 4)
+    lm, ls = latent.mean(ax, keepdims=True), np.sqrt(latent.astype(np.float64).var(ax, keepdims=True)).astype(F32)
+    rm, rs = reference.mean(ax, keepdims=True), np.sqrt(reference.astype(np.float64).var(ax, keepdims=True)).astype(F32)
+    res = (latent - lm) / (ls + F32(1e-8)) * rs + rm
+    if factor >= 1.0:
+        return res.astype(F32)
+    return (F32(factor) * res + F32(1 - factor) * latent).astype(F32)
+
+
+def euler_step(latent, velocity, sigma, sigma_next):
+    """LTXScheduler.step (LTXScheduler.swift:305-327), latent f32."""
+    s = F32(sigma)
+    den = (latent.astype(F32) - s * velocity.astype(F32)).astype(F32)
+    if sigma_next > 0:
+        return (den + F32(sigma_next) * (latent.astype(F32) - den) / s).astype(F32)
+    return den
+
+
+def denoise(w, cfg, latent, sigmas_, context, mask, F, H, W, cfg_scale=1.0, rescale=0.0, stg_scale=0.0,
+            stg_blocks=(29,), ge_gamma=0.0, neg_context=None, neg_mask=None, num_layers=None):
+    """generateVideo's loop (LTXPipeline.swift:800-956), T2V. latent [1,C,F,H,W] f32 already scaled by sigmas[0]."""
+    prev_v = None
+    for step in range(len(sigmas_) - 1):
+        sg, sn = float(sigmas_[step]), float(sigmas_[step + 1])
+        tok = bf16_round(patchify(latent))
+        ts = np.array([sg], F32)
+
+        def fwd(c, m, **kw):
+            v = dit_forward(w, cfg, tok, c, ts, m, F, H, W, num_layers=num_layers, **kw)
+            return unpatchify(v, F, H, W).astype(F32)
+
+        if cfg_scale > 1.0:
+            v_pos, v_neg = fwd(context, mask), fwd(neg_context, neg_mask)
+            v = apply_cfg(v_neg, v_pos, cfg_scale)
+            if rescale > 0:
+                v = guidance_rescale(v, v_pos, rescale)
+        else:
+            v = fwd(context, mask)
+        if stg_scale > 0:
+            vp = fwd(context, mask, stg_blocks=tuple(stg_blocks))
+            v = v + F32(stg_scale) * (v - vp)
+        if ge_gamma > 0 and prev_v is not None:
+            v = F32(ge_gamma) * (v - prev_v) + prev_v
+        prev_v = v
+        latent = euler_step(latent, v, sg, sn)
+    return latent
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R18-R19: VAE decoder (VideoDecoder.swift, VideoConvolution.swift:202-348). Tensors are [B,C,F,H,W] f32.
+# ---------------------------------------------------------------------------------------------------------------
+def conv3d_full(x, weight, bias, causal=False):
+    """Conv3dFull: reflect pad H/W by 1, replicate pad T (1+1, or 2+0 causal), 27 taps, bias."""
+    b, c, t, h, wd = x.shape
+    o = weight.shape[0]
+    xp = np.concatenate([x[:, :, :, 1:2], x, x[:, :, :, h - 2:h - 1]], axis=3)
+    xp = np.concatenate([xp[:, :, :, :, 1:2], xp, xp[:, :, :, :, wd - 2:wd - 1]], axis=4)
+    if causal:
+        xp = np.concatenate([xp[:, :, :1]] * 2 + [xp], axis=2)
+    else:
+        xp = np.concatenate([xp[:, :, :1], xp, xp[:, :, -1:]], axis=2)
+    out = np.zeros((b, o, t, h, wd), F32)
+    wf = weight.astype(F32)
+    for kt in range(3):
+        for kh in range(3):
+            for kw in range(3):
+                patch = xp[:, :, kt:kt + t, kh:kh + h, kw:kw + wd].reshape(b, c, -1).astype(F32)
+                out += np.einsum("oc,bcn->bon", wf[:, :, kt, kh, kw], patch, optimize=True).reshape(b, o, t, h, wd)
+    if bias is not None:
+        out += bias.astype(F32).reshape(1, -1, 1, 1, 1)
+    return out
+
+
+def pixel_norm(x, eps=1e-8):
+    """vaePixelNorm (VideoDecoder.swift:29-32)."""
+    ms = np.mean(x.astype(np.float64) ** 2, axis=1, keepdims=True)
+    return (x / np.sqrt(ms + eps)).astype(F32)
+
+
+def vae_res_block(w, p, x, time_emb=None):
+    """VAEResBlock3d (VideoDecoder.swift:75-131)."""
+    sst = w[p + "scale_shift_table"].astype(F32)  # [4,C]
+    if time_emb is not None:
+        sst = sst[None] + time_emb.reshape(x.shape[0], 4, -1)
+    else:
+        sst = sst[None]
+    r = lambda v: v.reshape(v.shape[0], -1, 1, 1, 1)
+    shift1, scale1, shift2, scale2 = r(sst[:, 0]), r(sst[:, 1] + 1), r(sst[:, 2]), r(sst[:, 3] + 1)
+    h = silu(pixel_norm(x) * scale1 + shift1)
+    h = conv3d_full(h, w[p + "conv1.conv.weight"], w[p + "conv1.conv.bias"])
+    h = silu(pixel_norm(h) * scale2 + shift2)
+    h = conv3d_full(h, w[p + "conv2.conv.weight"], w[p + "conv2.conv.bias"])
+    return (h + x).astype(F32)
+
+
+def depth_to_space(x, c_out):
+    """VAEDepthToSpaceUpsample3d.depthToSpace (VideoDecoder.swift:201-213), factor (2,2,2)."""
+    b, _, t, h, w = x.shape
+    o = x.reshape(b, c_out, 2, 2, 2, t, h, w).transpose(0, 1, 5, 2, 6, 3, 7, 4)
+    return o.reshape(b, c_out, t * 2, h * 2, w * 2)
+
+
+def vae_upsample(w, p, x):
+    """VAEDepthToSpaceUpsample3d.callAsFunction (VideoDecoder.swift:215-251)."""
+    c_in = x.shape[1]
+    res = depth_to_space(x, c_in // 8)[:, :, 1:]
+    res = np.concatenate([res] * 4, axis=1)
+    h = conv3d_full(x, w[p + "conv.conv.weight"], w[p + "conv.conv.bias"])
+    h = depth_to_space(h, c_in // 2)[:, :, 1:]
+    return (h + res).astype(F32)
+
+
+def vae_unpatchify(x, p=4):
+    """unpatchify (VideoDecoder.swift:257-275): channel = (c*4+a)*4+b, a -> W offset, b -> H offset."""
+    b, cp, t, h, w = x.shape
+    c = cp // (p * p)
+    o = x.reshape(b, c, 1, p, p, t, h, w).transpose(0, 1, 5, 2, 6, 4, 7, 3)
+    return o.reshape(b, c, t, h * p, w * p)
+
+
+VAE_CHANNELS = (1024, 512, 256, 128)
+
+
+def vae_param_shapes(channels=VAE_CHANNELS, latent_channels=128, timestep_conditioning=False):
+    """Module keys after mapVAEWeights (VideoDecoder.swift:302-356)."""
+    s = {"conv_in.conv.weight": (channels[0], latent_channels, 3, 3, 3), "conv_in.conv.bias": (channels[0],),
+         "conv_out.conv.weight": (48, channels[3], 3, 3, 3), "conv_out.conv.bias": (48,),
+         "last_scale_shift_table": (2, channels[3]), "mean_of_means": (latent_channels,), "std_of_means": (latent_channels,)}
+    for gi, c in enumerate(channels):
+        g = f"up_blocks_{2 * gi}."
+        for r in range(5):
+            for cv in ("conv1", "conv2"):
+                s[g + f"res_blocks.{r}.{cv}.conv.weight"] = (c, c, 3, 3, 3)
+                s[g + f"res_blocks.{r}.{cv}.conv.bias"] = (c,)
+            s[g + f"res_blocks.{r}.scale_shift_table"] = (4, c)
+        if gi < 3:
+            u = f"up_blocks_{2 * gi + 1}."
+            s[u + "conv.conv.weight"] = (4 * c, c, 3, 3, 3)
+            s[u + "conv.conv.bias"] = (4 * c,)
+    return s
+
+
+def vae_decode_raw(w, latent, channels=VAE_CHANNELS):
+    """VideoDecoder.callAsFunction without timestep conditioning (VideoDecoder.swift:358-449) -> [B,3,F,H,W]."""
+    x = (latent.astype(F32) * w["std_of_means"].astype(F32).reshape(1, -1, 1, 1, 1)
+         + w["mean_of_means"].astype(F32).reshape(1, -1, 1, 1, 1)).astype(F32)
+    x = conv3d_full(x, w["conv_in.conv.weight"], w["conv_in.conv.bias"])
+    for gi in range(4):
+        for r in range(5):
+            x = vae_res_block(w, f"up_blocks_{2 * gi}.res_blocks.{r}.", x)
+        if gi < 3:
+            x = vae_upsample(w, f"up_blocks_{2 * gi + 1}.", x)
+    x = pixel_norm(x)
+    lsst = w["last_scale_shift_table"].astype(F32)
+    x = silu(x * (lsst[1] + 1).reshape(1, -1, 1, 1, 1) + lsst[0].reshape(1, -1, 1, 1, 1))
+    x = conv3d_full(x, w["conv_out.conv.weight"], w["conv_out.conv.bias"])
+    return vae_unpatchify(x, 4)
+
+
+def vae_tile_plan(latent_frames, tile, overlap):
+    """decodeWithTemporalTiling chunk walk + blended frame count (VideoDecoder.swift:517-592)."""
+    if not (tile > 0 and latent_frames > tile):
+        return [(0, latent_frames)], 8 * (latent_frames - 1) + 1
+    stride = tile - overlap
+    tiles, start = [], 0
+    while start < latent_frames:
+        end = min(start + tile, latent_frames)
+        tiles.append((start, end))
+        if end >= latent_frames:
+            break
+        start += stride
+    po = 8 * overlap
+    total = 8 * (tiles[0][1] - tiles[0][0] - 1) + 1
+    for s, e in tiles[1:]:
+        nxt = 8 * (e - s - 1) + 1
+        total = total + nxt - po if (0 < po < total and po < nxt) else total + nxt
+    return tiles, total
+
+
+def decode_video(w, latent, tile=0, overlap=1, channels=VAE_CHANNELS):
+    """decodeVideo (VideoDecoder.swift:466-602) -> (F,H,W,3) f32 in [0,1]."""
+    tiles, _ = vae_tile_plan(latent.shape[2], tile, overlap)
+    chunks = [vae_decode_raw(w, latent[:, :, s:e], channels) for s, e in tiles]
+    result = chunks[0]
+    po = 8 * overlap
+    for nxt in chunks[1:]:
+        rf, nf = result.shape[2], nxt.shape[2]
+        if 0 < po < rf and po < nf:
+            wts = (np.arange(po, dtype=F32) / F32(po)).reshape(1, 1, po, 1, 1)
+            blended = result[:, :, rf - po:] * (1 - wts) + nxt[:, :, :po] * wts
+            result = np.concatenate([result[:, :, :rf - po], blended, nxt[:, :, po:]], axis=2)
+        else:
+            result = np.concatenate([result, nxt], axis=2)
+    frames = np.clip((result + 1.0) / 2.0, 0.0, 1.0)[0]
+    return frames.transpose(1, 2, 3, 0).astype(F32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R20: weight-key mapping (ModelDownloader.swift:605-639,756-899)
+# ---------------------------------------------------------------------------------------------------------------
+def map_transformer_key(key):
+    if key.endswith(".weight_scale") or key.endswith(".input_scale"):
+        return None
+    if "audio" in key or key.startswith("vocoder") or "av_ca_" in key:
+        return None
+    pre = "model.diffusion_model."
+    if not key.startswith(pre):
+        return None
+    if key.startswith(pre + "video_embeddings_connector.") or key.startswith(pre + "audio_embeddings_connector."):
+        return None
+    k = key[len(pre):]
+    if (k.startswith("audio_") or ".audio_" in k or k.startswith("av_cross_attn_") or "video_to_audio" in k
+            or "video_a2v" in k or "a2v_ca" in k or "scale_shift_table_a2v" in k):
+        return None
+    if k.startswith("proj_in."):
+        k = "patchify_proj." + k[len("proj_in."):]
+    if k.startswith("time_embed.emb.timestep_embedder."):
+        k = "adaln_single.emb." + k[len("time_embed.emb.timestep_embedder."):]
+    elif k.startswith("time_embed.linear."):
+        k = "adaln_single." + k[len("time_embed."):]
+    elif k.startswith("adaln_single.emb.timestep_embedder."):
+        k = "adaln_single.emb." + k[len("adaln_single.emb.timestep_embedder."):]
+    k = k.replace(".emb.timestep_embedder.", ".emb.")
+    k = k.replace(".norm_q.", ".q_norm.").replace(".norm_k.", ".k_norm.")
+    k = k.replace(".to_out.0.", ".to_out.")
+    k = k.replace("ff.net.0.proj.", "ff.project_in.proj.").replace("ff.net.2.", "ff.project_out.")
+    return k
+
+
+def map_vae_key(key):
+    if key.startswith("vae."):
+        key = key[4:]
+    if key.startswith("encoder."):
+        return None
+    if "per_channel_statistics" in key:
+        base = key.split(".")[-1]
+        return {"mean-of-means": "mean_of_means", "std-of-means": "std_of_means"}.get(base)
+    if key == "latents_mean":
+        return "mean_of_means"
+    if key == "latents_std":
+        return "std_of_means"
+    k = key[len("decoder."):] if key.startswith("decoder.") else key
+    if k.startswith("mid_block."):
+        k = "up_blocks_0." + k[len("mid_block."):]
+    else:
+        for i in range(3):
+            up, rs = f"up_blocks.{i}.upsamplers.0.", f"up_blocks.{i}.resnets."
+            if k.startswith(up):
+                k = f"up_blocks_{2 * i + 1}." + k[len(up):]
+                break
+            if k.startswith(rs):
+                k = f"up_blocks_{2 * i + 2}.resnets." + k[len(rs):]
+                break
+    for i in range(7):
+        src = f"up_blocks.{i}."
+        if k.startswith(src):
+            k = f"up_blocks_{i}." + k[len(src):]
+            break
+    return k.replace(".resnets.", ".res_blocks.")
+
+
+def map_lora_key(key):
+    """LoRAKeyMapper.loraKeyToModelKey (LoRALoader.swift:209-243)."""
+    k = key[len("diffusion_model."):] if key.startswith("diffusion_model.") else key
+    k = k.replace(".emb.timestep_embedder.", ".emb.").replace(".to_out.0", ".to_out")
+    k = k.replace(".ff.net.0.proj", ".ff.project_in.proj").replace(".ff.net.2", ".ff.project_out")
+    return k + ".weight"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# synthetic parameters for tests: deterministic, bf16-rounded
+# ---------------------------------------------------------------------------------------------------------------
+def synth_dit_weights(cfg, seed=1234):
+    rng = np.random.default_rng(seed)
+    w = {}
+    for k, shp in dit_param_shapes(cfg).items():
+        if k.endswith("_norm.weight"):
+            v = 1.0 + 0.02 * rng.standard_normal(shp)
+        elif k.endswith(".bias"):
+            v = 0.01 * rng.standard_normal(shp)
+        elif k.endswith("scale_shift_table"):
+            v = 0.05 * rng.standard_normal(shp)
+        else:
+            v = rng.standard_normal(shp) / math.sqrt(shp[-1])
+        w[k] = bf16_round(v.astype(F32))
+    return w
+
+
+def synth_vae_weights(channels=VAE_CHANNELS, latent_channels=128, seed=77):
+    rng = np.random.default_rng(seed)
+    w = {}
+    for k, shp in vae_param_shapes(channels, latent_channels).items():
+        if k == "mean_of_means":
+            v = 0.1 * rng.standard_normal(shp)
+        elif k == "std_of_means":
+            v = 1.0 + 0.1 * rng.random(shp)
+        elif k.endswith(".bias"):
+            v = 0.01 * rng.standard_normal(shp)
+        elif "scale_shift_table" in k:
+            v = 0.05 * rng.standard_normal(shp)
+        else:
+            fan_in = shp[1] * 27
+            v = rng.standard_normal(shp) / math.sqrt(fan_in)
+        w[k] = bf16_round(v.astype(F32))
+    return w
+
+
+def dit_file_keys(w):
+    """Module-key dict -> file-key dict in the unified checkpoint's naming (inverse of map_transformer_key)."""
+    out = {}
+    for k, v in w.items():
+        fk = k
+        fk = fk.replace("ff.project_in.proj.", "ff.net.0.proj.").replace("ff.project_out.", "ff.net.2.")
+        fk = fk.replace(".to_out.", ".to_out.0.").replace(".q_norm.", ".norm_q.").replace(".k_norm.", ".norm_k.")
+        if fk.startswith("adaln_single.emb."):
+            fk = "adaln_single.emb.timestep_embedder." + fk[len("adaln_single.emb."):]
+        if fk.startswith("patchify_proj."):
+            fk = "proj_in." + fk[len("patchify_proj."):]
+        out["model.diffusion_model." + fk] = v
+    return out
+
+
+def vae_file_keys(w):
+    """Module-key dict -> Diffusers-style standalone VAE file keys (inverse of map_vae_key)."""
+    out = {}
+    for k, v in w.items():
+        if k == "mean_of_means":
+            out["latents_mean"] = v
+            continue
+        if k == "std_of_means":
+            out["latents_std"] = v
+            continue
+        fk = k.replace(".res_blocks.", ".resnets.")
+        if fk.startswith("up_blocks_0."):
+            fk = "mid_block." + fk[len("up_blocks_0."):]
+        else:
+            for i in range(3):
+                if fk.startswith(f"up_blocks_{2 * i + 1}."):
+                    fk = f"up_blocks.{i}.upsamplers.0." + fk[len(f"up_blocks_{2 * i + 1}."):]
+                    break
+                if fk.startswith(f"up_blocks_{2 * i + 2}.resnets."):
+                    fk = f"up_blocks.{i}.resnets." + fk[len(f"up_blocks_{2 * i + 2}.resnets."):]
+                    break
+        out["decoder." + fk] = v
+    return out

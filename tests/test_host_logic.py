@@ -1,0 +1,246 @@
+"""CPU tests (no GPU): the pure-host part of the path exported by libltxhip.so - shapes, validation, sigma schedules,
+RoPE tables, VAE tiling plan, weight-key mapping - pinned by known-answer vectors derived by hand from the
+reference source, and checked bit-for-bit against the oracle. Also checks the ABI surface itself.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_version(ltx):
+    # the reference's only test: LTXVideo.version == "0.1.0" (Tests/LTXVideoTests/LTXVideoTests.swift:9-11)
+    assert ltx.__version__ == "0.1.0"
+
+
+def test_abi_exports_match_header(ltx):
+    """Every function declared in include/ltxhip.h is exported by the library and bound in _lib.SIGNATURES."""
+    hdr = open(os.path.join(ROOT, "include", "ltxhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ltx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ltx_status"}
+    assert len(declared) >= 30
+    from importlib import import_module
+
+    lib_mod = import_module("ltx-video-swift-mlx_amd._lib")
+    so = ctypes.CDLL(lib_mod.SO_PATH)
+    for name in sorted(declared):
+        assert hasattr(so, name), f"{name} declared in ltxhip.h but not exported"
+        assert name in lib_mod.SIGNATURES, f"{name} not bound in _lib.SIGNATURES"
+    assert set(lib_mod.SIGNATURES) == declared
+
+
+# ---- R1 ----
+@pytest.mark.parametrize("whf,expect", [((256, 256, 9), (2, 8, 8)), ((768, 512, 25), (4, 16, 24)),
+                                        ((1536, 1024, 25), (4, 32, 48)), ((768, 512, 201), (26, 16, 24)),
+                                        ((704, 480, 121), (16, 15, 22))])
+def test_latent_shape_kat(ltx, oracle, whf, expect):
+    assert ltx.latent_shape(*whf) == expect == oracle.latent_shape(*whf)
+
+
+def test_token_counts():
+    # SURVEY section 0 table
+    for (f, h, w), t in {(2, 8, 8): 128, (4, 16, 24): 1536, (4, 32, 48): 6144, (26, 16, 24): 9984}.items():
+        assert f * h * w == t
+
+
+def test_validate_matches_oracle_and_messages(ltx, oracle):
+    cases = [(768, 512, 25, 8, 1.0, False), (770, 512, 25, 8, 1.0, False), (768, 500, 25, 8, 1.0, False),
+             (768, 512, 24, 8, 1.0, False), (32, 512, 25, 8, 1.0, False), (4096, 512, 25, 8, 1.0, False),
+             (768, 32, 25, 8, 1.0, False), (768, 512, 1, 8, 1.0, False), (768, 512, 265, 8, 1.0, False),
+             (768, 512, 25, 0, 1.0, False), (768, 512, 25, 101, 1.0, False), (768, 512, 25, 8, 0.5, False),
+             (768, 512, 25, 8, 21.0, False), (800, 512, 25, 8, 1.0, True), (768, 512, 25, 8, 1.0, True),
+             (770, 500, 24, 0, 0.0, False)]
+    for c in cases:
+        want = oracle.validate_generation_config(*c)
+        try:
+            ltx.validate_generation_config(*c)
+            got = None
+        except ltx.LTXError as e:
+            assert e.case == "invalidConfiguration"
+            got = str(e).split(": ", 1)[1]
+        assert got == want, (c, got, want)
+    # first failing check wins, in the reference's order (LTXConfig.swift:310-353)
+    with pytest.raises(ltx.LTXError, match="Width must be divisible by 32, got 770"):
+        ltx.validate_generation_config(770, 500, 24, 0, 0.0)
+    with pytest.raises(ltx.LTXError, match=r"Number of frames must be 8n \+ 1"):
+        ltx.validate_generation_config(768, 512, 24, 8, 1.0)
+
+
+# ---- R3 ----
+def test_sigma_tables(ltx, oracle):
+    # constants copied by value from LTXScheduler.swift:18-36
+    raw = ltx.sigmas(True, 8, 0)
+    assert raw.tolist() == [np.float32(v) for v in [1.0, 0.99375, 0.9875, 0.98125, 0.975, 0.909375, 0.725, 0.421875, 0.0]]
+    assert ltx.stage2_sigmas().tolist() == [np.float32(v) for v in [0.909375, 0.725, 0.421875, 0.0]]
+    assert oracle.DISTILLED_SIGMA_VALUES[5:] == oracle.STAGE_2_DISTILLED_SIGMA_VALUES
+
+
+def test_sigma_kat_t1536(ltx):
+    # SURVEY R3 known-answer vector (derived from the formulas, f32): T=1536 -> mu = 1.1333333
+    kat = np.array([1.0, 0.99405915, 0.98806733, 0.98202413, 0.97592908, 0.90860569, 0.68004858, 0.10000002, 0.0], np.float32)
+    got = ltx.sigmas(True, 8, 1536)
+    assert np.array_equal(got, kat), got
+    # num_steps is ignored in distilled mode (always the 8-step table: LTXScheduler.swift:86-88)
+    assert np.array_equal(ltx.sigmas(True, 3, 1536), kat)
+
+
+def test_sigma_clamp_and_terminal(ltx):
+    a, b = ltx.sigmas(True, 8, 4096), ltx.sigmas(True, 8, 9984)
+    assert np.array_equal(a, b)  # min(tokens, 4096)
+    for t in (128, 1536, 6144):
+        s = ltx.sigmas(True, 8, t)
+        assert s[0] == 1.0 and s[-1] == 0.0 and abs(s[-2] - 0.1) < 1e-6 and np.all(np.diff(s) < 0)
+    d = ltx.sigmas(False, 40, 1536)
+    assert len(d) == 41 and d[0] == 1.0 and d[-1] == 0.0 and abs(d[-2] - 0.1) < 1e-6 and np.all(np.diff(d) < 0)
+
+
+def test_sigma_matches_oracle_bitwise(ltx, oracle):
+    for t in (0, 128, 1000, 1536, 4096, 6144, 9984):
+        for dist, n in ((True, 8), (False, 40), (False, 8), (False, 3), (False, 1)):
+            a, b = ltx.sigmas(dist, n, t), oracle.sigmas(dist, n, t)
+            assert np.array_equal(a, b, equal_nan=True), (t, dist, n, a, b)
+
+
+# ---- R8 / R9 ----
+def test_position_grid_kat(oracle):
+    # temporal mid-coordinates of latent frames 0..3 at 24 fps, spatial 32j+16
+    g = oracle.position_grid(4, 2, 3)
+    t = g[0].reshape(4, 2, 3)[:, 0, 0]
+    assert np.allclose(t, [1 / 48, 5 / 24, 13 / 24, 21 / 24], rtol=0, atol=1e-7)
+    assert g[1].reshape(4, 2, 3)[0, :, 0].tolist() == [16.0, 48.0]
+    assert g[2].reshape(4, 2, 3)[0, 0, :].tolist() == [16.0, 48.0, 80.0]
+    # token order: w fastest, then h, then f (LatentUtils.swift:20-34)
+    assert g[2][:3].tolist() == [16.0, 48.0, 80.0] and g[1][3] == 48.0
+
+
+def test_rope_tables_structure(ltx, oracle):
+    cfg = ltx.default_transformer_config()
+    F, H, W = 2, 3, 4
+    cos, sin = ltx.rope_tables(cfg, F, H, W)
+    assert cos.shape == (F * H * W, 2048)
+    # 4096/6 = 682 frequency indices x 3 dims = 2046 -> two identity slots padded at the FRONT (head 0)
+    assert np.all(cos[:, :2] == 1.0) and np.all(sin[:, :2] == 0.0)
+    assert np.allclose(cos ** 2 + sin ** 2, 1.0, atol=1e-6)
+    # first frequency index = theta^0 * pi/2 : angle = pi/2 * (2*coord/max - 1)
+    t0 = (1 / 48) / 20 * 2 - 1
+    assert abs(cos[0, 2] - np.float32(np.cos(np.pi / 2 * t0))) <= 1e-7
+    oc, osn = oracle.rope_tables(F, H, W)
+    assert np.array_equal(cos, oc) and np.array_equal(sin, osn)
+
+
+def test_rope_tables_small_dims_match_oracle(ltx, oracle):
+    for heads in (2, 4):
+        cfg = ltx.default_transformer_config(num_attention_heads=heads, cross_attention_dim=heads * 128)
+        cos, sin = ltx.rope_tables(cfg, 2, 5, 7)
+        oc, osn = oracle.rope_tables(2, 5, 7, dim=heads * 128, num_heads=heads)
+        assert np.array_equal(cos, oc) and np.array_equal(sin, osn)
+
+
+# ---- R19 ----
+def test_tile_plan_kats(ltx, oracle):
+    # config 5 (F'=26): tile 8 ov 1 -> 180 frames (not 201); tile 6 ov 1 -> 173; F'=16 tile 8 -> 107
+    assert ltx.vae_tile_plan(26, 8, 1) == ([(0, 8), (7, 15), (14, 22), (21, 26)], 180)
+    assert ltx.vae_tile_plan(26, 6, 1) == ([(0, 6), (5, 11), (10, 16), (15, 21), (20, 26)], 173)
+    assert ltx.vae_tile_plan(16, 8, 1) == ([(0, 8), (7, 15), (14, 16)], 107)
+    assert ltx.vae_tile_plan(4, 8, 1) == ([(0, 4)], 25)     # untiled when F' <= tile
+    assert ltx.vae_tile_plan(26, 0, 1) == ([(0, 26)], 201)  # tiling disabled (default preset)
+    for n in range(1, 40):
+        for tile in (0, 2, 3, 6, 8):
+            for ov in (0, 1, 2):
+                if tile and tile <= ov:
+                    continue
+                assert ltx.vae_tile_plan(n, tile, ov) == tuple(oracle.vae_tile_plan(n, tile, ov)) or \
+                    list(ltx.vae_tile_plan(n, tile, ov)) == list(oracle.vae_tile_plan(n, tile, ov))
+    with pytest.raises(ltx.LTXError):
+        ltx.vae_tile_plan(26, 2, 2)  # stride 0: the reference would never terminate
+
+
+# ---- R20 ----
+KEY_KATS = {
+    "model.diffusion_model.proj_in.weight": "patchify_proj.weight",
+    "model.diffusion_model.adaln_single.emb.timestep_embedder.linear_1.bias": "adaln_single.emb.linear_1.bias",
+    "model.diffusion_model.time_embed.emb.timestep_embedder.linear_2.weight": "adaln_single.emb.linear_2.weight",
+    "model.diffusion_model.time_embed.linear.weight": "adaln_single.linear.weight",
+    "model.diffusion_model.adaln_single.linear.bias": "adaln_single.linear.bias",
+    "model.diffusion_model.caption_projection.linear_1.weight": "caption_projection.linear_1.weight",
+    "model.diffusion_model.scale_shift_table": "scale_shift_table",
+    "model.diffusion_model.proj_out.bias": "proj_out.bias",
+    "model.diffusion_model.transformer_blocks.7.attn1.norm_q.weight": "transformer_blocks.7.attn1.q_norm.weight",
+    "model.diffusion_model.transformer_blocks.7.attn2.norm_k.weight": "transformer_blocks.7.attn2.k_norm.weight",
+    "model.diffusion_model.transformer_blocks.47.attn2.to_out.0.bias": "transformer_blocks.47.attn2.to_out.bias",
+    "model.diffusion_model.transformer_blocks.0.ff.net.0.proj.weight": "transformer_blocks.0.ff.project_in.proj.weight",
+    "model.diffusion_model.transformer_blocks.0.ff.net.2.bias": "transformer_blocks.0.ff.project_out.bias",
+    "model.diffusion_model.transformer_blocks.0.scale_shift_table": "transformer_blocks.0.scale_shift_table",
+    # skipped
+    "model.diffusion_model.transformer_blocks.0.attn1.to_q.weight_scale": None,
+    "model.diffusion_model.transformer_blocks.0.audio_attn1.to_q.weight": None,
+    "model.diffusion_model.audio_proj_in.weight": None,
+    "model.diffusion_model.av_ca_video_scale_shift_adaln_single.linear.weight": None,
+    "model.diffusion_model.video_embeddings_connector.learnable_registers": None,
+    "model.diffusion_model.transformer_blocks.0.scale_shift_table_a2v_ca_video": None,
+    "vocoder.conv_pre.weight": None,
+    "vae.decoder.conv_in.conv.weight": None,
+    "transformer_blocks.0.attn1.to_q.weight": None,  # no model.diffusion_model. prefix -> not a transformer key
+}
+VAE_KATS = {
+    "decoder.conv_in.conv.weight": "conv_in.conv.weight",
+    "vae.decoder.conv_out.conv.bias": "conv_out.conv.bias",
+    "decoder.mid_block.resnets.3.conv2.conv.weight": "up_blocks_0.res_blocks.3.conv2.conv.weight",
+    "decoder.mid_block.time_embedder.timestep_embedder.linear_1.weight": "up_blocks_0.time_embedder.timestep_embedder.linear_1.weight",
+    "decoder.up_blocks.0.upsamplers.0.conv.conv.weight": "up_blocks_1.conv.conv.weight",
+    "decoder.up_blocks.0.resnets.4.scale_shift_table": "up_blocks_2.res_blocks.4.scale_shift_table",
+    "decoder.up_blocks.2.upsamplers.0.conv.conv.bias": "up_blocks_5.conv.conv.bias",
+    "decoder.up_blocks.2.resnets.0.conv1.conv.weight": "up_blocks_6.res_blocks.0.conv1.conv.weight",
+    "decoder.up_blocks.3.conv.conv.weight": "up_blocks_3.conv.conv.weight",  # legacy unified layout
+    "decoder.last_scale_shift_table": "last_scale_shift_table",
+    "decoder.timestep_scale_multiplier": "timestep_scale_multiplier",
+    "latents_mean": "mean_of_means",
+    "latents_std": "std_of_means",
+    "vae.per_channel_statistics.mean-of-means": "mean_of_means",
+    "per_channel_statistics.std-of-means": "std_of_means",
+    "per_channel_statistics.channel": None,
+    "encoder.conv_in.conv.weight": None,
+}
+LORA_KATS = {
+    "diffusion_model.transformer_blocks.0.attn1.to_out.0": "transformer_blocks.0.attn1.to_out.weight",
+    "diffusion_model.transformer_blocks.5.ff.net.0.proj": "transformer_blocks.5.ff.project_in.proj.weight",
+    "diffusion_model.transformer_blocks.5.ff.net.2": "transformer_blocks.5.ff.project_out.weight",
+    "transformer_blocks.1.attn2.to_k": "transformer_blocks.1.attn2.to_k.weight",
+    "diffusion_model.adaln_single.emb.timestep_embedder.linear_1": "adaln_single.emb.linear_1.weight",
+}
+
+
+def test_key_mapping_kats(ltx, oracle):
+    for k, v in KEY_KATS.items():
+        assert ltx.map_transformer_key(k) == v == oracle.map_transformer_key(k), k
+    for k, v in VAE_KATS.items():
+        assert ltx.map_vae_key(k) == v == oracle.map_vae_key(k), k
+    for k, v in LORA_KATS.items():
+        assert ltx.map_lora_key(k) == v == oracle.map_lora_key(k), k
+
+
+def test_key_mapping_roundtrip_covers_all_params(ltx, oracle):
+    """Every module parameter (SURVEY R20 list) is reachable from a checkpoint-style file key."""
+    ocfg = oracle.DiTConfig(num_layers=3, num_heads=2, caption_channels=128)
+    shapes = oracle.dit_param_shapes(ocfg)
+    file_keys = oracle.dit_file_keys({k: None for k in shapes})
+    mapped = {ltx.map_transformer_key(k) for k in file_keys}
+    assert mapped == set(shapes)
+    vshapes = oracle.vae_param_shapes()
+    vfile = oracle.vae_file_keys({k: None for k in vshapes})
+    assert {ltx.map_vae_key(k) for k in vfile} == set(vshapes)
+
+
+def test_ctx_create_without_gpu_fails_loudly(ltx):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ltx.LTXError) as e:
+        ltx.Context(0, use_torch_stream=False)
+    assert e.value.case == "hipError"

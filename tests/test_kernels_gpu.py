@@ -1,0 +1,225 @@
+"""Parity of each hand-written gfx950 kernel against the oracle / an f32 reference, through the C ABI.
+
+Tolerances (stated per test): GEMM and attention take bf16 inputs and accumulate in f32, so against an f32
+reference on the SAME bf16-rounded inputs the only differences are accumulation order (GEMM: rel 1e-5) and, for
+attention, the bf16 rounding of P before the PV product (abs 2e-2 on O(1) outputs). Integer-valued inputs make the
+GEMM exact and catch any fragment-layout error bit for bit.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_bf16(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.bfloat16).cuda()
+
+
+def dev_f32(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+def as_f32(t):
+    return t.float().cpu().numpy()
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (105, 200, 128), (1, 128, 64), (577, 130, 320)])
+def test_gemm_integer_exact(gpu_ctx, cfg, M, N, K):
+    """Small-integer operands: every product and partial sum is exact in f32 -> result must be bit-exact."""
+    rng = np.random.default_rng(M * 7 + N * 3 + K + cfg)
+    A = rng.integers(-3, 4, (M, K)).astype(np.float32)
+    B = rng.integers(-3, 4, (N, K)).astype(np.float32)
+    bias = rng.integers(-5, 6, (N,)).astype(np.float32)
+    out = torch.full((M, N + (4 - N % 4) % 4), -777.0, device="cuda")
+    gpu_ctx.op_gemm(dev_bf16(A), dev_bf16(B), dev_f32(bias), act=0, tile_cfg=cfg, out_f32=out)
+    torch.cuda.synchronize()
+    ref = A @ B.T + bias
+    got = as_f32(out)[:, :N]
+    assert np.array_equal(got, ref), f"max diff {np.abs(got - ref).max()}"
+    if out.shape[1] > N:  # padding columns untouched
+        assert np.all(as_f32(out)[:, N:] == -777.0)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1536, 512, 4096, 0), (300, 256, 1024, 1), (128, 4096, 256, 2)])
+def test_gemm_random_vs_f32(gpu_ctx, M, N, K, act):
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal((N,)).astype(np.float32)
+    Ad, Bd = dev_bf16(A), dev_bf16(B)
+    out = torch.empty((M, N), device="cuda")
+    outb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_gemm(Ad, Bd, dev_f32(bias), act=act, out_f32=out, out_bf16=outb)
+    torch.cuda.synchronize()
+    ref = Ad.float().cpu() @ Bd.float().cpu().T + torch.from_numpy(bias)
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    elif act == 2:
+        ref = torch.nn.functional.silu(ref)
+    ref = ref.numpy()
+    got = as_f32(out)
+    # f32 accumulation order only
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()) + 1e-5
+    gb = as_f32(outb)
+    assert np.abs(gb - ref).max() <= 2 ** -8 * np.abs(ref).max() + 1e-3
+
+
+def test_gemm_gated_residual(gpu_ctx):
+    rng = np.random.default_rng(5)
+    M, N, K = 200, 256, 512
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal((N,)).astype(np.float32)
+    gate = rng.standard_normal((N,)).astype(np.float32)
+    x0 = rng.standard_normal((M, N)).astype(np.float32)
+    Ad, Bd = dev_bf16(A), dev_bf16(B)
+    x = dev_f32(x0)
+    mirror = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_gemm_gated_residual(Ad, Bd, dev_f32(bias), dev_f32(gate), 1.0, x, mirror)
+    torch.cuda.synchronize()
+    ref = x0 + gate[None] * ((Ad.float().cpu() @ Bd.float().cpu().T).numpy() + bias[None])
+    assert np.abs(as_f32(x) - ref).max() <= 5e-5
+    assert np.abs(as_f32(mirror) - ref).max() <= 2 ** -8 * np.abs(ref).max() + 1e-3
+    # scalar gate (cross-attention scale path)
+    x = dev_f32(x0)
+    gpu_ctx.op_gemm_gated_residual(Ad, Bd, dev_f32(bias), None, 0.5, x, None)
+    torch.cuda.synchronize()
+    ref = x0 + 0.5 * ((Ad.float().cpu() @ Bd.float().cpu().T).numpy() + bias[None])
+    assert np.abs(as_f32(x) - ref).max() <= 5e-5
+
+
+@pytest.mark.parametrize("M,in_act", [(1, 0), (2, 2), (5, 2)])
+def test_gemv(gpu_ctx, M, in_act):
+    rng = np.random.default_rng(3)
+    N, K = 300, 1024
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal((N,)).astype(np.float32)
+    Wd = dev_bf16(W)
+    out = torch.empty((M, N), device="cuda")
+    gpu_ctx.op_gemv(dev_f32(a), Wd, dev_f32(bias), out, in_act)
+    torch.cuda.synchronize()
+    ain = a / (1 + np.exp(-a)) if in_act == 2 else a
+    ref = ain.astype(np.float64) @ Wd.float().cpu().numpy().astype(np.float64).T + bias
+    assert np.abs(as_f32(out) - ref).max() <= 1e-4
+
+
+def _attn_ref(q, k, v, H, bias, scale):
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    qh = q.reshape(B, Tq, H, 128).permute(0, 2, 1, 3)
+    kh = k.reshape(B, Tk, H, 128).permute(0, 2, 1, 3)
+    vh = v.reshape(B, Tk, H, 128).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) * scale
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    p = torch.softmax(s, dim=-1)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B, Tq, D)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,use_bias", [(1, 2, 128, 128, False), (2, 2, 105, 77, True), (1, 4, 1536, 1536, False),
+                                                 (1, 3, 300, 1024, True), (1, 1, 32, 64, False), (1, 1, 1, 3, True)])
+def test_attention_vs_f32(gpu_ctx, B, H, Tq, Tk, use_bias):
+    rng = np.random.default_rng(B * 1000 + Tq + Tk)
+    D = H * 128
+    q = dev_bf16(rng.standard_normal((B, Tq, D)))
+    k = dev_bf16(rng.standard_normal((B, Tk, D)))
+    v = dev_bf16(rng.standard_normal((B, Tk, D)))
+    bias = None
+    if use_bias:
+        m = (rng.random((B, Tk)) > 0.3).astype(np.float32)
+        m[:, 0] = 1
+        bias = dev_f32((1 - m) * -10000.0)
+    ldvt = ((Tk + 63) // 64) * 64
+    vt = torch.zeros((B, D, ldvt), device="cuda", dtype=torch.bfloat16)
+    vt[:, :, :Tk] = v.transpose(1, 2)
+    o = torch.empty((B, Tq, D), device="cuda", dtype=torch.bfloat16)
+    scale = 1.0 / math.sqrt(128.0)
+    gpu_ctx.op_attention(q, k, vt, bias, H, o, scale)
+    torch.cuda.synchronize()
+    ref = _attn_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), H, None if bias is None else bias.cpu(), scale).numpy()
+    got = as_f32(o)
+    err = np.abs(got - ref).max()
+    assert err <= 2e-2, f"max abs err {err}"
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert rel <= 1e-2, f"rel l2 {rel}"
+
+
+def test_attention_integer_layout(gpu_ctx):
+    """One-hot style check that pins the key permutation / Vt layout exactly: with q.k = big for exactly one key per
+    query, softmax is a delta and O must equal that key's V row (bf16-exact)."""
+    B, H, Tq, Tk = 1, 2, 160, 200
+    D = H * 128
+    rng = np.random.default_rng(0)
+    sel = rng.integers(0, Tk, (H, Tq))
+    q = np.zeros((B, Tq, D), np.float32)
+    k = np.zeros((B, Tk, D), np.float32)
+    # keys: distinct +-1 codes over 128 dims (Tk <= 2^7 would be needed for binary; use random +-1, near-orthogonal)
+    codes = rng.choice([-1.0, 1.0], (H, Tk, 128)).astype(np.float32)
+    for h in range(H):
+        k[0, :, h * 128:(h + 1) * 128] = codes[h]
+        q[0, :, h * 128:(h + 1) * 128] = codes[h][sel[h]] * 8.0  # q.k_sel = 1024, others ~ N(0, 8*sqrt(128)=90)
+    v = rng.integers(-8, 9, (B, Tk, D)).astype(np.float32)
+    ldvt = ((Tk + 63) // 64) * 64
+    vt = torch.zeros((B, D, ldvt), device="cuda", dtype=torch.bfloat16)
+    vt[:, :, :Tk] = dev_bf16(v).transpose(1, 2)
+    o = torch.empty((B, Tq, D), device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_attention(dev_bf16(q), dev_bf16(k), vt, None, H, o, 1.0 / math.sqrt(128.0))
+    torch.cuda.synchronize()
+    got = as_f32(o)
+    for h in range(H):
+        ref = v[0, sel[h], h * 128:(h + 1) * 128]
+        assert np.abs(got[0, :, h * 128:(h + 1) * 128] - ref).max() <= 1e-2
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("rows,D", [(37, 512), (128, 4096), (5, 1024)])
+def test_norm_mod(gpu_ctx, oracle, kind, rows, D):
+    rng = np.random.default_rng(rows + D + kind)
+    x = (rng.standard_normal((rows, D)) * 3 + 0.5).astype(np.float32)
+    scale = (0.1 * rng.standard_normal((D,))).astype(np.float32)
+    shift = (0.1 * rng.standard_normal((D,))).astype(np.float32)
+    out = torch.empty((rows, D), device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_norm_mod(dev_f32(x), dev_f32(scale), dev_f32(shift), out, norm_kind=kind, eps=1e-6)
+    torch.cuda.synchronize()
+    n = oracle.rms_norm(x, None, 1e-6) if kind == 0 else oracle.layer_norm(x, 1e-6)
+    ref = n * (1 + scale) + shift
+    assert np.abs(as_f32(out) - ref).max() <= 2 ** -8 * np.abs(ref).max() + 1e-4
+    # rounding point of block 0: norm rounded to bf16 before modulation
+    if kind == 0:
+        gpu_ctx.op_norm_mod(dev_f32(x), dev_f32(scale), dev_f32(shift), out, norm_kind=0, eps=1e-6, round_norm_bf16=True)
+        torch.cuda.synchronize()
+        ref2 = oracle.bf16_round(n) * (1 + scale) + shift
+        assert np.abs(as_f32(out) - ref2).max() <= 2 ** -7 * np.abs(ref2).max() + 1e-4
+
+
+@pytest.mark.parametrize("use_rope", [True, False])
+def test_qknorm_rope(gpu_ctx, oracle, ltx, use_rope):
+    F, H, W, heads = 2, 3, 5, 4
+    D = heads * 128
+    T = F * H * W
+    B = 2
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((B * T, 2 * D)).astype(np.float32)  # q | k fused buffer, use the second half
+    w = (1 + 0.1 * rng.standard_normal((D,))).astype(np.float32)
+    cfg = ltx.default_transformer_config(num_attention_heads=heads, cross_attention_dim=D)
+    cos, sin = ltx.rope_tables(cfg, F, H, W)
+    xd = dev_f32(x)
+    out = torch.empty((B * T, D), device="cuda", dtype=torch.bfloat16)
+    xin = xd[:, D:]
+    wd, cd, sd = dev_f32(w), dev_f32(cos), dev_f32(sin)  # keep alive across the call
+    # strided view: pass base pointer of the second half with ldx = 2D
+    rc = ltx.lib.ltx_op_qknorm_rope(gpu_ctx._h, xin.data_ptr(), 2 * D, wd.data_ptr(),
+                                    cd.data_ptr() if use_rope else None,
+                                    sd.data_ptr() if use_rope else None, T, B * T, D, 1e-6, out.data_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = oracle.rms_norm(x[:, D:], w, 1e-6).reshape(B, T, D)
+    if use_rope:
+        ref = oracle.apply_split_rope(ref, cos, sin, heads)
+    ref = ref.reshape(B * T, D)
+    assert np.abs(as_f32(out) - ref).max() <= 2 ** -8 * np.abs(ref).max() + 1e-4
