@@ -142,6 +142,46 @@ int ltx_dit_set_stg(ltx_ctx* ctx, const int* blocks, int n_blocks, int skip_self
 int ltx_dit_clear_stg(ltx_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Denoising loop
+ * ---------------------------------------------------------------------------------------------------------- */
+/* GenerationProgressCallback (LTXPipeline.swift:50-72): invoked synchronously on the calling thread once per step,
+ * before that step's forward (LTXPipeline.swift:805-810). */
+typedef void (*ltx_progress_cb)(int current_step, int total_steps, float sigma, void* user);
+
+/* LTXVideoGenerationConfig's sampling knobs (LTXConfig.swift:216-300) for one denoise run. */
+typedef struct ltx_denoise_options {
+    float cfg_scale;        /* > 1 enables CFG; context batch is then [negative, positive] (LatentUtils.swift:104-117) */
+    float guidance_rescale; /* phi (LatentUtils.swift:164-183) */
+    float stg_scale;        /* STG (LTXPipeline.swift:897-921) */
+    const int* stg_blocks;  /* default [29] */
+    int n_stg_blocks;
+    float ge_gamma;         /* GE momentum (LTXPipeline.swift:924-927) */
+} ltx_denoise_options;
+
+/* Replaces the denoise loop of generateVideo (LTXPipeline.swift:800-956) / denoise(...) (:2191-2401), T2V.
+ *   latent  [1][C][F][H][W] f32, in/out; must already be scaled by sigmas[0] (LTXPipeline.swift:793)
+ *   sigmas  HOST array of n_sigmas values (n_sigmas-1 Euler steps), e.g. from ltx_sigmas
+ *   context [nb][S][caption_channels] bf16, mask [nb][S] int32 or NULL; nb = 2 ([neg,pos]) iff cfg_scale > 1
+ * HOST pointers for latent/context/mask. */
+int ltx_denoise(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* sigmas, int n_sigmas,
+                const uint16_t* context, const int32_t* mask, int S, const ltx_denoise_options* opt,
+                ltx_progress_cb cb, void* user);
+/* Same with DEVICE pointers for latent/context/mask (sigmas stays a host array); asynchronous on the context
+ * stream. ctx_version / mask_all_ones as in ltx_dit_forward_dev. */
+int ltx_denoise_dev(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* sigmas, int n_sigmas,
+                    const uint16_t* context, const int32_t* mask, int mask_all_ones, int S, uint64_t ctx_version,
+                    const ltx_denoise_options* opt, ltx_progress_cb cb, void* user);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Live kernel timing (replaces the reference's wall-clock GenerationTimings, LTXVideo.swift:255-297, with HIP
+ * events recorded on the launch stream around every launch of a kernel family). kind: 0 GEMM, 1 attention,
+ * 2 conv3d, 3 elementwise. work = algorithmic FLOPs of the timed launches.
+ * ---------------------------------------------------------------------------------------------------------- */
+int ltx_prof_enable(ltx_ctx* ctx, int on);
+/* Synchronises the stream, folds finished events into the totals and returns them; reset != 0 clears afterwards. */
+int ltx_prof_collect(ltx_ctx* ctx, int kind, double* total_ms, long* launches, double* work, int reset);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Kernel-level entry points (DEVICE pointers). These expose the individual gfx950 kernels so that parity tests can
  * pin each one against the oracle; they are not needed by a pipeline caller.
  * ---------------------------------------------------------------------------------------------------------- */

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import LTXError, TransformerConfig, lib
+from ._lib import PROGRESS_CB, DenoiseOptions, LTXError, TransformerConfig, lib
 
 __version__ = lib.ltx_version().decode()
 
@@ -199,6 +199,42 @@ class Context:
 
     def dit_clear_stg(self):
         self._ck(lib.ltx_dit_clear_stg(self._h))
+
+    # ---- denoise loop ----
+    @staticmethod
+    def _options(cfg_scale=1.0, guidance_rescale=0.0, stg_scale=0.0, stg_blocks=(29,), ge_gamma=0.0):
+        arr = (C.c_int * max(1, len(stg_blocks)))(*stg_blocks)
+        o = DenoiseOptions(cfg_scale, guidance_rescale, stg_scale, C.cast(arr, C.POINTER(C.c_int)), len(stg_blocks), ge_gamma)
+        o._keep = arr
+        return o
+
+    def denoise(self, latent, sigmas_, context_bf16, mask, F, H, W, on_progress=None, **opts):
+        """Host-pointer denoise loop. latent [1,C,F,H,W] f32 (scaled by sigmas[0]); returns the final latent."""
+        lat = np.ascontiguousarray(latent, dtype=np.float32).copy()
+        sg = np.ascontiguousarray(sigmas_, dtype=np.float32)
+        cb = PROGRESS_CB(on_progress if on_progress else (lambda s, t, sig, u: None))
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.int32)
+        c = np.ascontiguousarray(context_bf16)
+        o = self._options(**opts)
+        self._ck(lib.ltx_denoise(self._h, _ptr(lat), F, H, W, sg.ctypes.data_as(C.POINTER(C.c_float)), len(sg), _ptr(c), _ptr(m),
+                                 c.shape[1], C.byref(o), cb, None))
+        return lat
+
+    def denoise_dev(self, latent, sigmas_, context, mask, F, H, W, ctx_version=1, mask_all_ones=False, on_progress=None, **opts):
+        sg = np.ascontiguousarray(sigmas_, dtype=np.float32)
+        cb = PROGRESS_CB(on_progress if on_progress else (lambda s, t, sig, u: None))
+        o = self._options(**opts)
+        self._ck(lib.ltx_denoise_dev(self._h, _ptr(latent), F, H, W, sg.ctypes.data_as(C.POINTER(C.c_float)), len(sg), _ptr(context),
+                                     _ptr(mask), int(mask_all_ones), context.shape[1], ctx_version, C.byref(o), cb, None))
+
+    # ---- live kernel timing ----
+    def prof_enable(self, on=True):
+        self._ck(lib.ltx_prof_enable(self._h, int(on)))
+
+    def prof_collect(self, kind, reset=False):
+        ms, n, w = C.c_double(), C.c_long(), C.c_double()
+        self._ck(lib.ltx_prof_collect(self._h, kind, C.byref(ms), C.byref(n), C.byref(w), int(reset)))
+        return {"ms": ms.value, "launches": n.value, "work": w.value}
 
     # ---- kernel-level hooks (device tensors) ----
     def op_gemm(self, A, B, bias=None, act=0, tile_cfg=-1, out_f32=None, out_bf16=None):

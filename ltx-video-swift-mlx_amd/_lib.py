@@ -26,6 +26,16 @@ class LTXError(RuntimeError):
         super().__init__(f"LTXError.{self.case}: {message}")
 
 
+class DenoiseOptions(C.Structure):
+    """``ltx_denoise_options``: the sampling knobs of ``LTXVideoGenerationConfig`` (LTXConfig.swift:216-300)."""
+
+    _fields_ = [("cfg_scale", C.c_float), ("guidance_rescale", C.c_float), ("stg_scale", C.c_float),
+                ("stg_blocks", C.POINTER(C.c_int)), ("n_stg_blocks", C.c_int), ("ge_gamma", C.c_float)]
+
+
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_float, C.c_void_p)
+
+
 class TransformerConfig(C.Structure):
     """``ltx_transformer_config`` / reference ``LTXTransformerConfig`` (LTXConfig.swift:83-177)."""
 
@@ -77,6 +87,10 @@ SIGNATURES = {
     "ltx_dit_set_cross_attn_scale": (_i, [_vp, _f, _i, _i]),
     "ltx_dit_set_stg": (_i, [_vp, _ip, _i, _i, _i]),
     "ltx_dit_clear_stg": (_i, [_vp]),
+    "ltx_denoise": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _vp, _vp, _i, C.POINTER(DenoiseOptions), PROGRESS_CB, _vp]),
+    "ltx_denoise_dev": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _vp, _vp, _i, _i, _u64, C.POINTER(DenoiseOptions), PROGRESS_CB, _vp]),
+    "ltx_prof_enable": (_i, [_vp, _i]),
+    "ltx_prof_collect": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double), _i]),
     "ltx_op_gemm_bf16": (_i, [_vp, _vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _l]),
     "ltx_op_gemm_bf16_gated_residual": (_i, [_vp, _vp, _l, _vp, _l, _vp, _vp, _f, _i, _i, _i, _vp, _l, _vp, _l]),
     "ltx_op_gemv_f32": (_i, [_vp, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i]),

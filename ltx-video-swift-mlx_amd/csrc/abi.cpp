@@ -8,6 +8,7 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "hostmath.h"
+#include "pipeline.h"
 #include "runtime.h"
 
 namespace {
@@ -18,6 +19,7 @@ template <class Fn>
 int guarded(ltx_ctx* ctx, Fn&& fn) {
     try {
         if (ctx) HIP_CHECK(hipSetDevice(ctx->device));
+        prof_set_current(ctx ? &ctx->prof : nullptr);
         fn();
         return LTX_OK;
     } catch (const LtxError& e) {
@@ -320,7 +322,9 @@ int ltx_dit_forward(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* contex
                 if (mask[i] != 1) { all_ones = 0; break; }
         }
         HIP_CHECK(hipMemcpyAsync(ctx->h2d[0].p, latent, n_lat, hipMemcpyHostToDevice, st));
-        if (hv != m->ctx_version || m->ctx_B != B || m->ctx_S != S) {
+        bool cached = false;
+        for (auto* e : m->ctx_cache) cached = cached || (e->version == hv && e->B == B && e->S == S);
+        if (!cached) {
             HIP_CHECK(hipMemcpyAsync(ctx->h2d[1].p, context, n_ctx, hipMemcpyHostToDevice, st));
             if (mask) HIP_CHECK(hipMemcpyAsync(ctx->h2d[3].p, mask, (size_t)B * S * 4, hipMemcpyHostToDevice, st));
         }
@@ -368,6 +372,93 @@ int ltx_dit_clear_stg(ltx_ctx* ctx) {
     return guarded(ctx, [&] {
         DiTModel* m = need_dit(ctx);
         for (auto& b : m->blocks) b.skip_attn = b.skip_ff = false;
+    });
+}
+
+// ---- denoise loop ----
+static void fill_params(DenoiseParams& p, const ltx_denoise_options* o) {
+    if (!o) return;
+    p.cfg_scale = o->cfg_scale;
+    p.guidance_rescale = o->guidance_rescale;
+    p.stg_scale = o->stg_scale;
+    p.stg_blocks = o->stg_blocks;
+    p.n_stg = o->n_stg_blocks;
+    p.ge_gamma = o->ge_gamma;
+}
+
+int ltx_denoise_dev(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* sigmas, int n_sigmas,
+                    const uint16_t* context, const int32_t* mask, int mask_all_ones, int S, uint64_t ctx_version,
+                    const ltx_denoise_options* opt, ltx_progress_cb cb, void* user) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        DenoiseParams p;
+        p.latent = latent; p.F = F; p.H = H; p.W = W;
+        p.sigmas = sigmas; p.n_sigmas = n_sigmas;
+        p.context = context; p.mask = mask; p.mask_all_ones = mask_all_ones; p.S = S;
+        p.ctx_version = ctx_version;
+        fill_params(p, opt);
+        p.progress = cb; p.user = user;
+        denoise_run(ctx, p);
+    });
+}
+
+int ltx_denoise(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* sigmas, int n_sigmas,
+                const uint16_t* context, const int32_t* mask, int S, const ltx_denoise_options* opt,
+                ltx_progress_cb cb, void* user) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        DiTModel* m = need_dit(ctx);
+        LTX_REQUIRE(latent && sigmas && context && F >= 1 && H >= 1 && W >= 1 && S >= 1 && n_sigmas >= 2, "ltx_denoise: bad arguments");
+        const int nb = (opt && opt->cfg_scale > 1.0f) ? 2 : 1;
+        const size_t n_lat = (size_t)m->cfg.in_channels * F * H * W * 4;
+        const size_t n_ctx = (size_t)nb * S * m->cfg.caption_channels * 2;
+        hipStream_t st = ctx->stream;
+        ctx->h2d[5].ensure(n_lat);
+        ctx->h2d[6].ensure(n_ctx);
+        ctx->h2d[7].ensure((size_t)nb * S * 4);
+        HIP_CHECK(hipMemcpyAsync(ctx->h2d[5].p, latent, n_lat, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(ctx->h2d[6].p, context, n_ctx, hipMemcpyHostToDevice, st));
+        int all_ones = 1;
+        uint64_t hv = hash_bytes(context, n_ctx, 0xCBF29CE484222325ull);
+        if (mask) {
+            HIP_CHECK(hipMemcpyAsync(ctx->h2d[7].p, mask, (size_t)nb * S * 4, hipMemcpyHostToDevice, st));
+            hv = hash_bytes(mask, (size_t)nb * S * 4, hv);
+            for (long i = 0; i < (long)nb * S; ++i)
+                if (mask[i] != 1) { all_ones = 0; break; }
+        }
+        DenoiseParams p;
+        p.latent = ctx->h2d[5].as<float>(); p.F = F; p.H = H; p.W = W;
+        p.sigmas = sigmas; p.n_sigmas = n_sigmas;
+        p.context = ctx->h2d[6].as<bf16_t>();
+        p.mask = mask ? ctx->h2d[7].as<int32_t>() : nullptr;
+        p.mask_all_ones = all_ones; p.S = S;
+        p.ctx_version = (hv >> 3) | 1;  // room for the per-pass sub-keys derived in denoise_run
+        fill_params(p, opt);
+        p.progress = cb; p.user = user;
+        denoise_run(ctx, p);
+        HIP_CHECK(hipMemcpyAsync(latent, ctx->h2d[5].p, n_lat, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    });
+}
+
+int ltx_prof_enable(ltx_ctx* ctx, int on) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->prof.collect();
+        ctx->prof.on = on != 0;
+    });
+}
+
+int ltx_prof_collect(ltx_ctx* ctx, int kind, double* total_ms, long* launches, double* work, int reset) {
+    if (!ctx || kind < 0 || kind >= PROF_NKINDS) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->prof.collect();
+        if (total_ms) *total_ms = ctx->prof.total_ms[kind];
+        if (launches) *launches = ctx->prof.launches[kind];
+        if (work) *work = ctx->prof.total_work[kind];
+        if (reset) ctx->prof.reset();
     });
 }
 

@@ -15,6 +15,7 @@
 // that the 8 accumulator registers of one k-step are 8 CONSECUTIVE keys - exactly the B-operand layout the PV
 // product needs (guide: "An accumulator tile as the next MFMA's operand").
 #include "attention.h"
+#include "runtime.h"
 
 namespace {
 
@@ -220,6 +221,7 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
         attr_set = true;
     }
+    ProfScope prof(PROF_ATTN, 4.0 * a.B * a.H * (double)a.Tq * a.Tk * 128, stream);
     dim3 grid((a.Tq + 127) / 128, a.H, a.B);
     if (a.bias)
         hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);

@@ -162,7 +162,7 @@ void dit_load_safetensors(ltx_ctx* ctx, DiTModel* m, const std::string& path) {
     }
     for (auto& kv : m->slots)
         if (!kv.second.loaded) ctx->n_missing++;
-    m->ctx_version = 0;
+    for (auto* c : m->ctx_cache) c->version = 0;
 }
 
 void dit_init_synthetic(ltx_ctx* ctx, DiTModel* m, uint64_t seed) {
@@ -185,7 +185,7 @@ void dit_init_synthetic(ltx_ctx* ctx, DiTModel* m, uint64_t seed) {
         s.loaded = true;
     }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    m->ctx_version = 0;
+    for (auto* c : m->ctx_cache) c->version = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -265,18 +265,34 @@ void ensure_rope(ltx_ctx* ctx, DiTModel* m, int F, int H, int W) {
 }
 
 // caption projection + per-layer cross-attention K / V^T (LTXTransformer.swift:127-134; LTXAttention.swift:173-180)
-void prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
+DiTModel::CtxCache* prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     const int D = m->D, L = m->L, B = a.B, S = a.S;
     const int Spad = ((S + 63) / 64) * 64;
     const long rows = (long)B * S;
     hipStream_t st = ctx->stream;
-    if (a.ctx_version != 0 && a.ctx_version == m->ctx_version && m->ctx_B == B && m->ctx_S == S) return;
+    m->ctx_clock++;
+    DiTModel::CtxCache* c = nullptr;
+    if (a.ctx_version != 0)
+        for (auto* e : m->ctx_cache)
+            if (e->version == a.ctx_version && e->B == B && e->S == S) {
+                e->last_use = m->ctx_clock;
+                return e;
+            }
+    if (m->ctx_cache.size() < 3) {
+        c = new DiTModel::CtxCache();
+        m->ctx_cache.push_back(c);
+    } else {
+        c = m->ctx_cache[0];
+        for (auto* e : m->ctx_cache)
+            if (e->last_use < c->last_use) c = e;
+    }
+    c->last_use = m->ctx_clock;
     m->ctx_tmp_h.ensure(rows * D * 2);
-    m->ctx_proj.ensure(rows * D * 2);
     m->ctx_tmp_kraw.ensure(rows * D * 4);
-    m->ctx_k.ensure((size_t)L * rows * D * 2);
-    if (m->ctx_vt.ensure((size_t)L * B * D * Spad * 2) || m->ctx_Spad != Spad) HIP_CHECK(hipMemsetAsync(m->ctx_vt.p, 0, m->ctx_vt.bytes, st));
-    m->ctx_bias.ensure(rows * 4);
+    c->proj.ensure(rows * D * 2);
+    c->k.ensure((size_t)L * rows * D * 2);
+    if (c->vt.ensure((size_t)L * B * D * Spad * 2) || c->Spad != Spad || c->B != B) HIP_CHECK(hipMemsetAsync(c->vt.p, 0, c->vt.bytes, st));
+    c->bias.ensure(rows * 4);
     {
         GemmEpilogue e1;
         e1.out_bf16 = m->ctx_tmp_h.as<bf16_t>();
@@ -284,7 +300,7 @@ void prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
         e1.act = LTX_ACT_GELU_TANH;
         gemm_linear(a.context, m->cfg.caption_channels, m->cap_l1, (int)rows, e1, st);
         GemmEpilogue e2;
-        e2.out_bf16 = m->ctx_proj.as<bf16_t>();
+        e2.out_bf16 = c->proj.as<bf16_t>();
         e2.ld_bf16 = D;
         gemm_linear(m->ctx_tmp_h.as<bf16_t>(), D, m->cap_l2, (int)rows, e2, st);
     }
@@ -294,19 +310,20 @@ void prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
         ek.out_f32 = m->ctx_tmp_kraw.as<float>();
         ek.ld_f32 = D;
         ek.round_bf16 = 1;  // the reference's K projection runs bf16 x bf16 -> bf16 (SURVEY R5/R11 dtype notes)
-        gemm_linear(m->ctx_proj.as<bf16_t>(), D, blk.k2, (int)rows, ek, st);
+        gemm_linear(c->proj.as<bf16_t>(), D, blk.k2, (int)rows, ek, st);
         launch_qknorm_rope(m->ctx_tmp_kraw.as<float>(), D, blk.kn2, nullptr, nullptr, S,
-                           m->ctx_k.as<bf16_t>() + (size_t)l * rows * D, D, (int)rows, D, m->cfg.norm_eps, st);
+                           c->k.as<bf16_t>() + (size_t)l * rows * D, D, (int)rows, D, m->cfg.norm_eps, st);
         for (int b = 0; b < B; ++b)
-            gemm_vt(m->ctx_proj.as<bf16_t>() + (size_t)b * S * D, D, S, blk.v2,
-                    m->ctx_vt.as<bf16_t>() + ((size_t)l * B + b) * D * Spad, Spad, st);
+            gemm_vt(c->proj.as<bf16_t>() + (size_t)b * S * D, D, S, blk.v2,
+                    c->vt.as<bf16_t>() + ((size_t)l * B + b) * D * Spad, Spad, st);
     }
-    m->ctx_has_bias = (a.mask != nullptr) && !a.mask_all_ones;
-    if (m->ctx_has_bias) launch_mask_to_bias(a.mask, m->ctx_bias.as<float>(), rows, st);
-    m->ctx_version = a.ctx_version;
-    m->ctx_B = B;
-    m->ctx_S = S;
-    m->ctx_Spad = Spad;
+    c->has_bias = (a.mask != nullptr) && !a.mask_all_ones;
+    if (c->has_bias) launch_mask_to_bias(a.mask, c->bias.as<float>(), rows, st);
+    c->version = a.ctx_version;
+    c->B = B;
+    c->S = S;
+    c->Spad = Spad;
+    return c;
 }
 
 }  // namespace
@@ -321,8 +338,8 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     const int Tpad = ((T + 63) / 64) * 64;
     ensure_workspace(m, B, T, st);
     ensure_rope(ctx, m, a.F, a.H, a.W);
-    prepare_context(ctx, m, a);
-    const int S = a.S, Spad = m->ctx_Spad;
+    DiTModel::CtxCache* cc = prepare_context(ctx, m, a);
+    const int S = a.S, Spad = cc->Spad;
 
     float* x = m->ws_x.as<float>();
     bf16_t* xn = m->ws_xn.as<bf16_t>();
@@ -403,10 +420,10 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             launch_qknorm_rope(qc, D, blk.qn2, nullptr, nullptr, T, q, D, (int)rows, D, eps, st);
             AttnArgs at;
             at.Q = q; at.ldq = D; at.q_bstride = (long)T * D;
-            at.K = m->ctx_k.as<bf16_t>() + (size_t)l * B * S * D; at.ldk = D; at.k_bstride = (long)S * D;
-            at.Vt = m->ctx_vt.as<bf16_t>() + (size_t)l * B * D * Spad; at.ldvt = Spad; at.vt_bstride = (long)D * Spad;
+            at.K = cc->k.as<bf16_t>() + (size_t)l * B * S * D; at.ldk = D; at.k_bstride = (long)S * D;
+            at.Vt = cc->vt.as<bf16_t>() + (size_t)l * B * D * Spad; at.ldvt = Spad; at.vt_bstride = (long)D * Spad;
             at.O = ao; at.ldo = D; at.o_bstride = (long)T * D;
-            at.bias = m->ctx_has_bias ? m->ctx_bias.as<float>() : nullptr;
+            at.bias = cc->has_bias ? cc->bias.as<float>() : nullptr;
             at.bias_bstride = S;
             at.B = B; at.H = m->cfg.num_heads; at.Tq = T; at.Tk = S;
             launch_attention(at, st);

@@ -55,11 +55,21 @@ struct DiTModel {
     DevBuf rope_cos, rope_sin;  // [T][D/2] f32
     int rope_F = 0, rope_H = 0, rope_W = 0;
     // projected caption context and per-layer cross-attention K / V^T (constant across denoise steps:
-    // recomputing them every step as the reference does is output-identical - SURVEY 9.2)
-    DevBuf ctx_proj, ctx_k, ctx_vt, ctx_bias, ctx_tmp_h, ctx_tmp_kraw;
-    uint64_t ctx_version = 0;
-    int ctx_B = 0, ctx_S = 0, ctx_Spad = 0;
-    bool ctx_has_bias = false;
+    // recomputing them every step as the reference does is output-identical - SURVEY 9.2). A few entries are kept
+    // so that the CFG pair [neg,pos] and the STG cond-only pass do not evict each other.
+    struct CtxCache {
+        DevBuf proj, k, vt, bias;
+        uint64_t version = 0;
+        int B = 0, S = 0, Spad = 0;
+        bool has_bias = false;
+        uint64_t last_use = 0;
+    };
+    std::vector<CtxCache*> ctx_cache;
+    uint64_t ctx_clock = 0;
+    DevBuf ctx_tmp_h, ctx_tmp_kraw;
+    ~DiTModel() {
+        for (auto* c : ctx_cache) delete c;
+    }
 
     // ---- activation workspace (grown on demand, never freed inside a step) ----
     DevBuf ws_x, ws_xn, ws_xb, ws_qk, ws_q, ws_k, ws_vt, ws_ao, ws_ffh, ws_qc;

@@ -45,6 +45,8 @@ void launch_euler_step(float* latent, const float* velocity, float sigma, float 
 void launch_cfg_combine(const float* uncond, const float* cond, float scale, float* out, long n, hipStream_t stream);
 // out = a + s*(a - b)   (STG: LTXPipeline.swift:920) ; out = g*(a-b)+b (GE: :924-927) share one kernel
 void launch_axpby(const float* a, const float* b, float ca, float cb, float* out, long n, hipStream_t stream);
+// GE momentum: out = g*(a - b) + b (LTXPipeline.swift:924-927)
+void launch_ge(const float* a, const float* b, float g, float* out, long n, hipStream_t stream);
 // per-batch population mean/variance over n elements -> stats[b] = {mean, var}
 void launch_mean_var(const float* x, long n_per_batch, int B, float* stats, hipStream_t stream);
 // guidance rescale (LatentUtils.swift:164-183): out = phi*cfg*(std_cond/std_cfg) + (1-phi)*cfg

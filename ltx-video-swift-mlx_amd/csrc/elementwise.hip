@@ -272,6 +272,10 @@ __global__ void axpby_kernel(const float* __restrict__ a, const float* __restric
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = cb * a[i] + ca * (a[i] - b[i]);
 }
+__global__ void ge_kernel(const float* __restrict__ a, const float* __restrict__ b, float g, float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = g * (a[i] - b[i]) + b[i];
+}
 __global__ void scale_inplace_kernel(float* __restrict__ x, float s, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] *= s;
@@ -479,6 +483,10 @@ void launch_cfg_combine(const float* uncond, const float* cond, float scale, flo
 }
 void launch_axpby(const float* a, const float* b, float ca, float cb, float* out, long n, hipStream_t stream) {
     hipLaunchKernelGGL(axpby_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, a, b, ca, cb, out, n);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_ge(const float* a, const float* b, float g, float* out, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(ge_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, a, b, g, out, n);
     HIP_CHECK(hipGetLastError());
 }
 void launch_lincomb(const float* a, const float* b, float ca, float cb, float* out, long n, hipStream_t stream) {

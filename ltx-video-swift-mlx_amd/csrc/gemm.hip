@@ -15,6 +15,7 @@
 //   * epilogue through a per-wave LDS transpose so global stores are 16 B/lane, row-contiguous.
 //   * workgroup ids are remapped so that each XCD's L2 sees a contiguous chunk of the tile grid.
 #include "gemm.h"
+#include "runtime.h"
 
 namespace {
 
@@ -349,6 +350,7 @@ void validate(const GemmArgs& a) {
 
 void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     validate(a);
+    ProfScope prof(a.conv ? PROF_CONV : PROF_GEMM, 2.0 * a.M * a.N * a.K, stream);
     if (a.conv) {
         switch (cfg) {
             case 0: launch_one<128, 128, true>(a, stream); break;

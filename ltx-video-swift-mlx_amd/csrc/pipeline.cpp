@@ -1,0 +1,107 @@
+// pipeline.cpp - see pipeline.h.
+#include "pipeline.h"
+
+#include "dit.h"
+#include "elementwise.h"
+
+void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
+    DiTModel* m = ctx->dit;
+    if (!m) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model component not loaded: transformer");
+    LTX_REQUIRE(p.latent && p.sigmas && p.n_sigmas >= 2 && p.context && p.S >= 1, "denoise: bad arguments");
+    const int C = m->cfg.in_channels;
+    LTX_REQUIRE(m->cfg.out_channels == C, "denoise: in/out channels differ");
+    const int T = p.F * p.H * p.W;
+    const long n = (long)C * T;
+    const bool use_cfg = p.cfg_scale > 1.0f;
+    const bool sharded = use_cfg && p.cfg_branch >= 0 && p.exchange;
+    const int B = (use_cfg && !sharded) ? 2 : 1;
+    hipStream_t st = ctx->stream;
+    const long cap = m->cfg.caption_channels;
+
+    ctx->dn_tokens.ensure((size_t)2 * n * 2);
+    ctx->dn_vel_tok.ensure((size_t)2 * n * 4);
+    ctx->dn_vel.ensure((size_t)2 * n * 4);
+    ctx->dn_vel2.ensure((size_t)n * 4);
+    ctx->dn_vel3.ensure((size_t)n * 4);
+    ctx->dn_prev.ensure((size_t)n * 4);
+    ctx->dn_ts.ensure(2 * 4);
+    ctx->dn_stats.ensure(16 * 4);
+    bf16_t* tokens = ctx->dn_tokens.as<bf16_t>();
+    float* vel_tok = ctx->dn_vel_tok.as<float>();
+    float* vel = ctx->dn_vel.as<float>();   // [B][C][T]
+    float* v = ctx->dn_vel2.as<float>();    // guided velocity
+    float* vp = ctx->dn_vel3.as<float>();   // STG perturbed velocity
+    float* prev = ctx->dn_prev.as<float>();
+    bool have_prev = false;
+
+    // context slices: with CFG the batch order is [neg, pos]
+    const bf16_t* ctx_pos = use_cfg ? p.context + (size_t)p.S * cap : p.context;
+    const int32_t* mask_pos = (use_cfg && p.mask) ? p.mask + p.S : p.mask;
+    const uint64_t ver = p.ctx_version;
+
+    auto forward = [&](const bf16_t* tok, const bf16_t* c, const int32_t* mk, int b, uint64_t version, float* out_tok) {
+        DiTForwardArgs a;
+        a.latent = tok;
+        a.context = c;
+        a.timesteps = ctx->dn_ts.as<float>();
+        a.mask = mk;
+        a.mask_all_ones = p.mask_all_ones;
+        a.B = b; a.F = p.F; a.H = p.H; a.W = p.W; a.S = p.S;
+        a.ctx_version = version;
+        a.velocity = out_tok;
+        dit_forward(ctx, m, a);
+    };
+
+    const int steps = p.n_sigmas - 1;
+    for (int step = 0; step < steps; ++step) {
+        const float sigma = p.sigmas[step], sigma_next = p.sigmas[step + 1];
+        if (p.progress) p.progress(step, steps, sigma, p.user);  // before the forward (LTXPipeline.swift:805-810)
+        launch_fill_const_f32(ctx->dn_ts.as<float>(), 2, sigma, st);
+        // patchify + .asType(.bfloat16) (LTXPipeline.swift:815)
+        launch_patchify_bf16(p.latent, tokens, 1, C, T, st);
+        if (B == 2) HIP_CHECK(hipMemcpyAsync(tokens + n, tokens, (size_t)n * 2, hipMemcpyDeviceToDevice, st));
+
+        if (!use_cfg) {
+            forward(tokens, p.context, p.mask, 1, ver, vel_tok);
+            launch_unpatchify_f32(vel_tok, v, 1, C, T, st);
+        } else {
+            if (sharded) {
+                // this rank's branch only; velocities are exchanged over xGMI (RCCL) by the caller's hook
+                const bool pos = p.cfg_branch == 1;
+                forward(tokens, pos ? ctx_pos : p.context, pos ? mask_pos : p.mask, 1, ver ? ver * 4 + 1 + (pos ? 1 : 0) : 0, vel_tok);
+                launch_unpatchify_f32(vel_tok, vp, 1, C, T, st);
+                p.exchange(vel, vp, n, p.exchange_user);  // vel = [neg | pos]
+            } else {
+                forward(tokens, p.context, p.mask, 2, ver ? ver * 4 : 0, vel_tok);
+                launch_unpatchify_f32(vel_tok, vel, 2, C, T, st);
+            }
+            const float* uncond = vel;
+            const float* cond = vel + n;
+            launch_cfg_combine(uncond, cond, p.cfg_scale, v, n, st);  // f32 (LTXPipeline.swift:860-865)
+            if (p.guidance_rescale > 0.f) {
+                float* stats = ctx->dn_stats.as<float>();
+                launch_mean_var(v, n, 1, stats, st);
+                launch_mean_var(cond, n, 1, stats + 2, st);
+                launch_guidance_rescale(v, stats, stats + 2, p.guidance_rescale, n, 1, st);
+            }
+        }
+        // STG: extra cond-only pass with self-attention skipped on stg_blocks (LTXPipeline.swift:897-921)
+        if (p.stg_scale > 0.f) {
+            for (int j = 0; j < p.n_stg; ++j) {
+                const int i = p.stg_blocks[j];
+                if (i >= 0 && i < m->L) m->blocks[i].skip_attn = true;
+            }
+            forward(tokens, ctx_pos, mask_pos, 1, ver ? ver * 4 + 2 : 0, vel_tok);
+            for (auto& b : m->blocks) b.skip_attn = b.skip_ff = false;  // clearSTGSkipFlags
+            launch_unpatchify_f32(vel_tok, vp, 1, C, T, st);
+            launch_axpby(v, vp, p.stg_scale, 1.0f, v, n, st);  // v + s*(v - vp)
+        }
+        // GE velocity correction (LTXPipeline.swift:924-927): v = g*(v - prev) + prev ; prev <- v
+        if (p.ge_gamma > 0.f && have_prev) launch_ge(v, prev, p.ge_gamma, v, n, st);
+        if (p.ge_gamma > 0.f) {
+            HIP_CHECK(hipMemcpyAsync(prev, v, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+            have_prev = true;
+        }
+        launch_euler_step(p.latent, v, sigma, sigma_next, n, st);
+    }
+}

@@ -86,6 +86,41 @@ struct DiTModel;
 struct VaeModel;
 struct UpscalerModel;
 
+// ---- live per-kernel timing (HIP events recorded on the launch stream around each launch of a kernel family) ----
+// Used by bench.py for the roofline numbers: achieved = algorithmic work of the launches / their summed duration.
+enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_CONV = 2, PROF_ELEM = 3, PROF_NKINDS = 4 };
+struct ProfRec {
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind = 0;
+    double work = 0;  // algorithmic FLOPs (GEMM/attention/conv) or bytes (elementwise)
+};
+struct Profiler {
+    bool on = false;
+    std::vector<ProfRec> pool;
+    size_t used = 0;
+    double total_ms[PROF_NKINDS] = {0, 0, 0, 0};
+    double total_work[PROF_NKINDS] = {0, 0, 0, 0};
+    long launches[PROF_NKINDS] = {0, 0, 0, 0};
+    ProfRec* begin(int kind, double work, hipStream_t s);
+    void end(ProfRec* r, hipStream_t s);
+    void collect();  // call after the stream is idle
+    void reset();
+    ~Profiler();
+};
+Profiler* prof_current();
+void prof_set_current(Profiler* p);
+struct ProfScope {
+    ProfRec* r = nullptr;
+    hipStream_t s;
+    ProfScope(int kind, double work, hipStream_t stream) : s(stream) {
+        Profiler* p = prof_current();
+        if (p && p->on) r = p->begin(kind, work, stream);
+    }
+    ~ProfScope() {
+        if (r) prof_current()->end(r, s);
+    }
+};
+
 struct ltx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -98,6 +133,9 @@ struct ltx_ctx {
     DevBuf h2d[8];
     // load report of the last *_load call (mirrors the reference's "unmatched/missing" debug logs)
     int n_loaded = 0, n_missing = 0, n_unmatched = 0;
+    Profiler prof;
+    // denoise-loop scratch (device)
+    DevBuf dn_tokens, dn_vel_tok, dn_vel, dn_vel2, dn_vel3, dn_prev, dn_ts, dn_stats, dn_lat2;
 };
 
 // synthetic weights (bench / property tests): counter-based normal fill on device

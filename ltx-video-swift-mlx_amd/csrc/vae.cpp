@@ -1,0 +1,393 @@
+// vae.cpp - see vae.h. One decode = reference VideoDecoder.callAsFunction (VideoDecoder.swift:358-449) per temporal
+// tile + decodeVideo / decodeWithTemporalTiling (VideoDecoder.swift:466-602).
+#include "vae.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "elementwise.h"
+#include "gemm.h"
+#include "hostmath.h"
+
+namespace {
+
+struct Pending {
+    std::string key;
+    void** dst;
+    int kind;
+    long numel;
+    int cout, cin;
+    bool perm;
+    int init;
+};
+
+}  // namespace
+
+VaeModel* vae_create() {
+    VaeModel* m = new VaeModel();
+    std::vector<Pending> pend;
+    auto conv = [&](const std::string& name, ConvW& c, int cin, int cout, bool perm) {
+        c.cin = cin;
+        c.cout = cout;
+        c.d2s_perm = perm;
+        pend.push_back({name + ".conv.weight", (void**)&c.w, 0, (long)cout * cin * 27, cout, cin, perm, 0});
+        pend.push_back({name + ".conv.bias", (void**)&c.b, 1, cout, cout, 0, perm, 0});
+    };
+    auto te = [&](const std::string& name, VaeTimeEmbedder& t, int out) {
+        t.hidden = 256;
+        t.out = out;
+        pend.push_back({name + ".timestep_embedder.linear_1.weight", (void**)&t.w1, 2, 256L * 256, 256, 256, false, 0});
+        pend.push_back({name + ".timestep_embedder.linear_1.bias", (void**)&t.b1, 1, 256, 256, 0, false, 0});
+        pend.push_back({name + ".timestep_embedder.linear_2.weight", (void**)&t.w2, 2, (long)out * 256, out, 256, false, 0});
+        pend.push_back({name + ".timestep_embedder.linear_2.bias", (void**)&t.b2, 1, out, out, 0, false, 0});
+    };
+    conv("conv_in", m->conv_in, m->latent_channels, m->channels[0], false);
+    conv("conv_out", m->conv_out, m->channels[3], 48, false);
+    for (int g = 0; g < 4; ++g) {
+        const int C = m->channels[g];
+        m->groups[g].C = C;
+        const std::string gp = "up_blocks_" + std::to_string(2 * g) + ".";
+        for (int r = 0; r < 5; ++r) {
+            const std::string rp = gp + "res_blocks." + std::to_string(r) + ".";
+            conv(rp + "conv1", m->groups[g].blocks[r].conv1, C, C, false);
+            conv(rp + "conv2", m->groups[g].blocks[r].conv2, C, C, false);
+            pend.push_back({rp + "scale_shift_table", (void**)&m->groups[g].blocks[r].sst, 1, 4L * C, 4 * C, 0, false, 0});
+        }
+        te(gp + "time_embedder", m->groups[g].te, 4 * C);
+        if (g < 3) conv("up_blocks_" + std::to_string(2 * g + 1) + ".conv", m->up[g], C, 4 * C, true);
+    }
+    te("last_time_embedder", m->last_te, 2 * m->channels[3]);
+    pend.push_back({"last_scale_shift_table", (void**)&m->last_sst, 1, 2L * m->channels[3], 0, 0, false, 0});
+    pend.push_back({"mean_of_means", (void**)&m->mean, 1, m->latent_channels, 0, 0, false, 0});
+    pend.push_back({"std_of_means", (void**)&m->std_, 1, m->latent_channels, 0, 0, false, 1});
+    pend.push_back({"timestep_scale_multiplier", (void**)&m->ts_mult, 3, 1, 0, 0, false, 0});
+
+    size_t total = 0;
+    for (auto& p : pend) total += DeviceArena::padded((size_t)p.numel * ((p.kind == 0 || p.kind == 2) ? 2 : 4));
+    m->weight_bytes = total;
+    m->arena.reserve(total + 256);
+    HIP_CHECK(hipMemset(m->arena.buf.p, 0, m->arena.buf.bytes));
+    for (auto& p : pend) {
+        *p.dst = m->arena.take((size_t)p.numel * ((p.kind == 0 || p.kind == 2) ? 2 : 4));
+        VaeModel::Slot s;
+        s.dst = *p.dst;
+        s.kind = p.kind;
+        s.numel = p.numel;
+        s.cout = p.cout;
+        s.cin = p.cin;
+        s.perm = p.perm;
+        s.init = p.init;
+        m->slots[p.key] = s;
+    }
+    // reference initialisers (VideoDecoder.swift:324-327): std = 1, timestep_scale_multiplier = 1000
+    launch_fill_const_f32(m->std_, m->latent_channels, 1.0f, nullptr);
+    launch_fill_const_f32(m->ts_mult, 1, 1000.0f, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    return m;
+}
+
+void vae_destroy(VaeModel* m) { delete m; }
+
+static bool parse_timestep_conditioning(const std::string& weights_path, const std::string& config_json) {
+    // parseVAEConfig (ModelDownloader.swift:583-594): config.json next to the weights file
+    std::string path = config_json;
+    if (path.empty()) {
+        const size_t slash = weights_path.rfind('/');
+        path = (slash == std::string::npos ? std::string(".") : weights_path.substr(0, slash)) + "/config.json";
+    }
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::string txt;
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) txt.append(buf, n);
+    fclose(f);
+    const size_t k = txt.find("\"timestep_conditioning\"");
+    if (k == std::string::npos) return false;
+    size_t p = txt.find(':', k);
+    if (p == std::string::npos) return false;
+    ++p;
+    while (p < txt.size() && (txt[p] == ' ' || txt[p] == '\n' || txt[p] == '\t' || txt[p] == '\r')) ++p;
+    return txt.compare(p, 4, "true") == 0;
+}
+
+void vae_load_safetensors(ltx_ctx* ctx, VaeModel* m, const std::string& path, const std::string& config_json) {
+    SafeTensors st;
+    st.open(path);
+    ctx->n_loaded = ctx->n_missing = ctx->n_unmatched = 0;
+    for (auto& kv : m->slots) kv.second.loaded = false;
+    std::vector<uint8_t> tmp, staging;
+    for (auto& kv : st.tensors) {
+        std::string mk;
+        if (!map_vae_file_key(kv.first, &mk)) continue;
+        auto it = m->slots.find(mk);
+        if (it == m->slots.end()) {
+            ctx->n_unmatched++;  // dropped without error (ModelDownloader.swift:1040-1050)
+            continue;
+        }
+        VaeModel::Slot& s = it->second;
+        const StTensor& t = kv.second;
+        if (t.numel() != s.numel)
+            LTX_THROW(LTXS_WEIGHT_LOADING_FAILED, "Failed to load weights: %s has %ld elements, expected %ld", kv.first.c_str(), t.numel(), s.numel);
+        if (s.kind == 0) {
+            // (O,I,kT,kH,kW) -> [O'][tap][I] bf16, O' = sub*Cout/8... (d2s permutation for upsamplers)
+            tmp.resize((size_t)s.numel * 2);
+            staging.resize((size_t)s.numel * 2);
+            st_to_bf16(st, t, (bf16_t*)tmp.data());
+            const bf16_t* src = (const bf16_t*)tmp.data();
+            bf16_t* dst = (bf16_t*)staging.data();
+            const int O = s.cout, I = s.cin;
+            const int co = O / 8;
+            for (int op = 0; op < O; ++op) {
+                const int o = s.perm ? ((op % co) * 8 + op / co) : op;
+                for (int tap = 0; tap < 27; ++tap)
+                    for (int i = 0; i < I; ++i) dst[((size_t)op * 27 + tap) * I + i] = src[((size_t)o * I + i) * 27 + tap];
+            }
+        } else if (s.kind == 2) {
+            staging.resize((size_t)s.numel * 2);
+            st_to_bf16(st, t, (bf16_t*)staging.data());
+        } else {
+            staging.resize((size_t)s.numel * 4);
+            float* f = (float*)staging.data();
+            st_to_f32(st, t, f);
+            if (s.perm) {
+                std::vector<float> q(f, f + s.numel);
+                const int O = (int)s.numel, co = O / 8;
+                for (int op = 0; op < O; ++op) f[op] = q[(op % co) * 8 + op / co];
+            }
+            if (s.kind == 3) m->ts_mult_host = f[0];
+        }
+        HIP_CHECK(hipMemcpy(s.dst, staging.data(), staging.size(), hipMemcpyHostToDevice));
+        s.loaded = true;
+        ctx->n_loaded++;
+    }
+    for (auto& kv : m->slots)
+        if (!kv.second.loaded) ctx->n_missing++;
+    m->timestep_conditioning = parse_timestep_conditioning(path, config_json);
+}
+
+void vae_init_synthetic(ltx_ctx* ctx, VaeModel* m, uint64_t seed, bool timestep_conditioning) {
+    uint64_t k = 0;
+    for (auto& kv : m->slots) {
+        VaeModel::Slot& s = kv.second;
+        const uint64_t sd = seed * 0x9E3779B97F4A7C15ull + (++k) * 0xD1B54A32D192ED03ull;
+        const std::string& key = kv.first;
+        if (s.kind == 0) {
+            launch_fill_normal_bf16((bf16_t*)s.dst, s.numel, sd, 0.f, 1.0f / sqrtf(27.0f * s.cin), ctx->stream);
+        } else if (s.kind == 2) {
+            launch_fill_normal_bf16((bf16_t*)s.dst, s.numel, sd, 0.f, 1.0f / 16.0f, ctx->stream);
+        } else if (key == "std_of_means") {
+            launch_fill_const_f32((float*)s.dst, s.numel, 1.0f, ctx->stream);
+        } else if (key == "mean_of_means") {
+            launch_fill_const_f32((float*)s.dst, s.numel, 0.0f, ctx->stream);
+        } else if (s.kind == 3) {
+            launch_fill_const_f32((float*)s.dst, 1, 1000.0f, ctx->stream);
+        } else {
+            launch_fill_normal_f32((float*)s.dst, s.numel, sd, 0.f, 0.02f, 1, ctx->stream);
+        }
+        s.loaded = true;
+    }
+    m->ts_mult_host = 1000.0f;
+    m->timestep_conditioning = timestep_conditioning;
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Dims {
+    int F, H, W;
+    long P() const { return (long)F * H * W; }
+};
+
+void conv3d(const bf16_t* x, const Dims& d, const ConvW& cw, GemmEpilogue ep, hipStream_t st) {
+    GemmArgs g;
+    g.A = x;
+    g.B = cw.w;
+    g.ldb = 27L * cw.cin;
+    g.M = (int)d.P();
+    g.N = cw.cout;
+    g.K = 27 * cw.cin;
+    g.conv = 1;
+    g.geom.F = d.F;
+    g.geom.H = d.H;
+    g.geom.W = d.W;
+    g.geom.C = cw.cin;
+    g.geom.causal = 0;    // the pipeline builds the decoder with causal:false (LTXPipeline.swift:338)
+    g.geom.pad_mode = 0;  // reflect
+    ep.bias_n = cw.b;
+    g.ep = ep;
+    launch_gemm_bf16(g, st);
+}
+
+// decode one temporal tile into `frames` (raw, layout (F_out, 32H, 32W, 3)); returns F_out
+int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride, const float* noise, int has_ts,
+                float timestep, Dims d0, float* frames, int apply_clip) {
+    hipStream_t st = ctx->stream;
+    float* xa = m->xa.as<float>();
+    float* xb = m->xb.as<float>();
+    float* t1 = m->t1.as<float>();
+    bf16_t* hb = m->hb.as<bf16_t>();
+    float* mods = m->mods.as<float>();
+
+    // per-block modulation vectors: rows shift1, scale1+1, shift2, scale2+1 (VideoDecoder.swift:93-113)
+    float* emb = m->temb.as<float>();        // [256] sinusoid, [256] hidden, then per-group outputs
+    if (has_ts) {
+        float* tsd = emb + 8192;
+        launch_fill_const_f32(tsd, 1, timestep, st);
+        launch_timestep_embedding(tsd, m->ts_mult_host, emb, 1, 256, st);
+    }
+    long mod_off = 0;
+    long mod_ofs_group[4];
+    for (int g = 0; g < 4; ++g) {
+        const int C = m->groups[g].C;
+        const float* te = nullptr;
+        if (has_ts) {
+            float* hid = emb + 256;
+            float* out = emb + 512;
+            const VaeTimeEmbedder& t = m->groups[g].te;
+            launch_gemv_f32(emb, 256, t.w1, 256, t.b1, hid, 256, 1, 256, 256, LTX_ACT_NONE, st);
+            launch_gemv_f32(hid, 256, t.w2, 256, t.b2, out, t.out, 1, t.out, 256, LTX_ACT_SILU, st);
+            te = out;
+        }
+        mod_ofs_group[g] = mod_off;
+        for (int r = 0; r < 5; ++r) {
+            launch_vae_make_mods(m->groups[g].blocks[r].sst, te, mods + mod_off, 4, C, st);
+            mod_off += 4L * C;
+        }
+    }
+    const long last_mod = mod_off;
+    {
+        const float* te = nullptr;
+        if (has_ts) {
+            float* hid = emb + 256;
+            float* out = emb + 512;
+            const VaeTimeEmbedder& t = m->last_te;
+            launch_gemv_f32(emb, 256, t.w1, 256, t.b1, hid, 256, 1, 256, 256, LTX_ACT_NONE, st);
+            launch_gemv_f32(hid, 256, t.w2, 256, t.b2, out, t.out, 1, t.out, 256, LTX_ACT_SILU, st);
+            te = out;
+        }
+        launch_vae_make_mods(m->last_sst, te, mods + last_mod, 2, m->channels[3], st);
+    }
+
+    // noise blend + denormalise -> channels-last bf16 (VideoDecoder.swift:366-381)
+    Dims d = d0;
+    launch_vae_prepare(latent, chan_stride, has_ts ? noise : nullptr, 0.025f, m->mean, m->std_, hb, m->latent_channels, d.P(), st);
+    {
+        GemmEpilogue e;
+        e.out_f32 = xa;
+        e.ld_f32 = m->channels[0];
+        conv3d(hb, d, m->conv_in, e, st);
+    }
+    float* x = xa;
+    float* xo = xb;
+    for (int g = 0; g < 4; ++g) {
+        const int C = m->groups[g].C;
+        for (int r = 0; r < 5; ++r) {
+            const VaeResBlock& rb = m->groups[g].blocks[r];
+            const float* md = mods + mod_ofs_group[g] + (long)r * 4 * C;
+            launch_pixelnorm_silu(x, md + 1 * C, md + 0 * C, hb, d.P(), C, st);
+            GemmEpilogue e1;
+            e1.out_f32 = t1;
+            e1.ld_f32 = C;
+            conv3d(hb, d, rb.conv1, e1, st);
+            launch_pixelnorm_silu(t1, md + 3 * C, md + 2 * C, hb, d.P(), C, st);
+            GemmEpilogue e2;  // x = conv2(h) + x, in place
+            e2.out_f32 = x;
+            e2.ld_f32 = C;
+            e2.resid = 1;
+            e2.gate_scalar = 1.0f;
+            conv3d(hb, d, rb.conv2, e2, st);
+        }
+        if (g < 3) {
+            // depth-to-space upsampler (VideoDecoder.swift:215-251): conv on the raw stream, D2S, drop frame 0, + D2S(x)
+            launch_cast_f32_bf16(x, hb, d.P() * C, st);
+            GemmEpilogue e;
+            e.out_f32 = xo;
+            e.ld_f32 = C / 2;
+            e.d2s = 1;
+            e.resid_src = x;
+            e.ld_resid = C;
+            conv3d(hb, d, m->up[g], e, st);
+            d.F = 2 * d.F - 1;
+            d.H *= 2;
+            d.W *= 2;
+            float* tmp = x;
+            x = xo;
+            xo = tmp;
+        }
+    }
+    const int C3 = m->channels[3];
+    launch_pixelnorm_silu(x, mods + last_mod + C3, mods + last_mod, hb, d.P(), C3, st);
+    {
+        GemmEpilogue e;
+        e.out_f32 = t1;
+        e.ld_f32 = 48;
+        conv3d(hb, d, m->conv_out, e, st);
+    }
+    launch_vae_unpatchify_frames(t1, 48, frames, d.F, d.H, d.W, apply_clip, st);
+    return d.F;
+}
+
+}  // namespace
+
+void vae_decode(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a) {
+    LTX_REQUIRE(a.latent && a.frames && a.F >= 1 && a.H >= 2 && a.W >= 2, "vae_decode: bad arguments (F=%d H=%d W=%d)", a.F, a.H, a.W);
+    LTX_REQUIRE(!a.has_timestep || a.noise, "vae_decode: timestep conditioning needs an explicit noise tensor");
+    const TilePlan plan = vae_tile_plan(a.F, a.tile, a.overlap);
+    LTX_REQUIRE(!plan.start.empty(), "vae_decode: temporal tile size %d must exceed overlap %d", a.tile, a.overlap);
+    hipStream_t st = ctx->stream;
+    const long HWpix = (long)a.H * 32 * a.W * 32 * 3;
+    LTX_REQUIRE(a.frames_cap >= (long)plan.out_frames * HWpix, "vae_decode: output buffer too small (%ld < %ld floats)",
+                a.frames_cap, (long)plan.out_frames * HWpix);
+    // workspace sized for the largest tile
+    int maxf = 0;
+    for (size_t i = 0; i < plan.start.size(); ++i) maxf = std::max(maxf, plan.end[i] - plan.start[i]);
+    const long P3 = (long)(8 * (maxf - 1) + 1) * (a.H * 8) * (a.W * 8);
+    const long elems = P3 * 128;
+    if (elems > m->ws_elems) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        m->xa.ensure((size_t)elems * 4);
+        m->xb.ensure((size_t)elems * 4);
+        m->t1.ensure((size_t)elems * 4);
+        m->hb.ensure((size_t)elems * 2);
+        m->ws_elems = elems;
+    }
+    m->mods.ensure((size_t)(20 * 4 * 1024 + 256) * 4);
+    m->temb.ensure((size_t)(8192 + 64) * 4);
+    const long chan_stride = (long)a.F * a.H * a.W;
+    const long hw = (long)a.H * a.W;
+    if (plan.start.size() == 1) {
+        const int nf = decode_tile(ctx, m, a.latent, chan_stride, a.noise, a.has_timestep, a.timestep, Dims{a.F, a.H, a.W}, a.frames, 1);
+        if (a.n_frames_out) *a.n_frames_out = nf;
+        return;
+    }
+    // temporal tiling with linear blending of 8*overlap pixel frames (VideoDecoder.swift:517-602)
+    const int po = 8 * a.overlap;
+    m->tile_frames.ensure((size_t)(8 * (maxf - 1) + 1) * HWpix * 4);
+    long cur = 0;
+    for (size_t i = 0; i < plan.start.size(); ++i) {
+        const int s = plan.start[i], e = plan.end[i];
+        float* dst = (i == 0) ? a.frames : m->tile_frames.as<float>();
+        const int nf = decode_tile(ctx, m, a.latent + s * hw, chan_stride, a.noise ? a.noise + s * hw : nullptr, a.has_timestep,
+                                   a.timestep, Dims{e - s, a.H, a.W}, dst, 0);
+        if (i == 0) {
+            cur = nf;
+            continue;
+        }
+        if (po > 0 && po < cur && po < nf) {
+            launch_blend_frames(a.frames + (cur - po) * HWpix, m->tile_frames.as<float>(), po, HWpix, st);
+            HIP_CHECK(hipMemcpyAsync(a.frames + cur * HWpix, m->tile_frames.as<float>() + (long)po * HWpix,
+                                     (size_t)(nf - po) * HWpix * 4, hipMemcpyDeviceToDevice, st));
+            cur += nf - po;
+        } else {
+            HIP_CHECK(hipMemcpyAsync(a.frames + cur * HWpix, m->tile_frames.as<float>(), (size_t)nf * HWpix * 4, hipMemcpyDeviceToDevice, st));
+            cur += nf;
+        }
+    }
+    launch_clip01(a.frames, cur * HWpix, st);
+    if (a.n_frames_out) *a.n_frames_out = (int)cur;
+}

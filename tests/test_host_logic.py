@@ -81,12 +81,21 @@ def test_sigma_tables(ltx, oracle):
 
 
 def test_sigma_kat_t1536(ltx):
-    # SURVEY R3 known-answer vector (derived from the formulas, f32): T=1536 -> mu = 1.1333333
+    # SURVEY R3 known-answer vector (derived from the formulas, f32, printed to 8 significant digits): T=1536
     kat = np.array([1.0, 0.99405915, 0.98806733, 0.98202413, 0.97592908, 0.90860569, 0.68004858, 0.10000002, 0.0], np.float32)
     got = ltx.sigmas(True, 8, 1536)
-    assert np.array_equal(got, kat), got
+    assert np.all(np.abs(got.astype(np.float64) - kat.astype(np.float64)) <= 1e-8), got
+    # exact bit patterns with a correctly rounded expf (glibc; see oracle._expf for the 1-ulp numpy caveat)
+    bits = [0x3f800000, 0x3f7e7aa9, 0x3f7cf1fb, 0x3f7b65ef, 0x3f79d67d, 0x3f689a62, 0x3f2e17aa, 0x3dccccd0, 0x0]
+    assert got.view(np.uint32).tolist() == bits
     # num_steps is ignored in distilled mode (always the 8-step table: LTXScheduler.swift:86-88)
-    assert np.array_equal(ltx.sigmas(True, 3, 1536), kat)
+    assert np.array_equal(ltx.sigmas(True, 3, 1536), got)
+    # T >= 4096 and T = 128 vectors of SURVEY R3 to the digits it prints (its 7th entries are 1-2 ulp off because
+    # it was evaluated with numpy's float32 exp)
+    k4096 = [1.0, 0.99514461, 0.99023592, 0.98527282, 0.98025471, 0.92397928, 0.72058177, 0.09999996, 0.0]
+    k128 = [1.0, 0.99287611, 0.98571050, 0.97850257, 0.97125220, 0.89245450, 0.64141822, 0.10000002, 0.0]
+    assert np.all(np.abs(ltx.sigmas(True, 8, 4096).astype(np.float64) - np.array(k4096)) <= 5e-7)
+    assert np.all(np.abs(ltx.sigmas(True, 8, 128).astype(np.float64) - np.array(k128)) <= 5e-7)
 
 
 def test_sigma_clamp_and_terminal(ltx):
