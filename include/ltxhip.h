@@ -142,6 +142,39 @@ int ltx_dit_set_stg(ltx_ctx* ctx, const int* blocks, int n_blocks, int skip_self
 int ltx_dit_clear_stg(ltx_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Video VAE decoder
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Replaces VideoDecoder() + LTXWeightLoader.loadVAEWeights/applyVAEWeights + parseVAEConfig
+ * (LTXPipeline.swift:338-346, ModelDownloader.swift:583-594,648-658,808-899,1022-1064). config_json NULL = look for
+ * `config.json` next to the weights; its "timestep_conditioning" flag selects the conditioned decode. */
+int ltx_vae_load(ltx_ctx* ctx, const char* safetensors_path, const char* config_json);
+/* Random-init decoder of the reference architecture, generated on device (bench / property tests). */
+int ltx_vae_init_synthetic(ltx_ctx* ctx, uint64_t seed, int timestep_conditioning);
+int ltx_vae_unload(ltx_ctx* ctx);
+/* VideoDecoder.timestepConditioning (VideoDecoder.swift:299) of the loaded model: 1/0, <0 on error. */
+int ltx_vae_timestep_conditioning(const ltx_ctx* ctx);
+/* Replaces decodeVideo(latent:decoder:timestep:temporalTileSize:temporalTileOverlap:) (VideoDecoder.swift:466).
+ *   latent  [1][128][F][H][W] f32 (normalised latent, as the denoise loop leaves it)
+ *   has_timestep/timestep: pass (1, 0.05) iff the model is timestep-conditioned (LTXPipeline.swift:1004); then
+ *           `noise` (same shape as latent, N(0,1)) is REQUIRED - the reference draws it from the global MLX RNG
+ *           (VideoDecoder.swift:369), here every noise tensor is an explicit input.
+ *   tile/overlap: MemoryOptimizationConfig.vaeTemporalTileSize/Overlap (0 = untiled)
+ *   frames_out (n_frames, 32H, 32W, 3) f32 in [0,1]; frames_cap = capacity in floats; *n_frames_out = frames written
+ *           (8(F-1)+1 untiled; see ltx_vae_tile_plan for tiled counts, e.g. 26 latent frames, tile 8 -> 180).
+ * HOST pointers. */
+int ltx_vae_decode(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
+                   const float* noise, int tile, int overlap, float* frames_out, long frames_cap, int* n_frames_out);
+/* Same with DEVICE pointers (n_frames_out stays a host pointer); asynchronous on the context stream. */
+int ltx_vae_decode_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
+                       const float* noise, int tile, int overlap, float* frames_out, long frames_cap,
+                       int* n_frames_out);
+/* One Conv3dFull (VideoConvolution.swift:202-348) on a channels-last tensor, exposed for parity tests:
+ * x [F][H][W][Cin] bf16 (device), w [Cout][27][Cin] bf16 (tap = (kt*3+kh)*3+kw), bias [Cout] f32 -> out [F][H][W][Cout] f32.
+ * causal: 0 replicate-pad T on both sides, 1 repeat the first frame twice. */
+int ltx_op_conv3d(ltx_ctx* ctx, const uint16_t* x, int F, int H, int W, int Cin, const uint16_t* w, const float* bias,
+                  int Cout, int causal, float* out);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Denoising loop
  * ---------------------------------------------------------------------------------------------------------- */
 /* GenerationProgressCallback (LTXPipeline.swift:50-72): invoked synchronously on the calling thread once per step,

@@ -200,6 +200,46 @@ class Context:
     def dit_clear_stg(self):
         self._ck(lib.ltx_dit_clear_stg(self._h))
 
+    # ---- VAE ----
+    def vae_load(self, path, config_json=None):
+        self._ck(lib.ltx_vae_load(self._h, str(path).encode(), str(config_json).encode() if config_json else None))
+
+    def vae_init_synthetic(self, seed=77, timestep_conditioning=False):
+        self._ck(lib.ltx_vae_init_synthetic(self._h, seed, int(timestep_conditioning)))
+
+    def vae_unload(self):
+        self._ck(lib.ltx_vae_unload(self._h))
+
+    @property
+    def vae_timestep_conditioning(self):
+        r = lib.ltx_vae_timestep_conditioning(self._h)
+        if r < 0:
+            raise LTXError(-r, "Model component not loaded: vaeDecoder")
+        return bool(r)
+
+    def vae_decode(self, latent, timestep=None, noise=None, tile=0, overlap=1):
+        """Host path: latent [1,128,F,H,W] f32 -> frames (n,32H,32W,3) f32 in [0,1] (decodeVideo)."""
+        lat = np.ascontiguousarray(latent, dtype=np.float32)
+        _, _, F, H, W = lat.shape
+        _, nf = vae_tile_plan(F, tile, overlap)
+        out = np.empty((nf, H * 32, W * 32, 3), dtype=np.float32)
+        n = C.c_int()
+        nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float32)
+        self._ck(lib.ltx_vae_decode(self._h, _ptr(lat), F, H, W, int(timestep is not None), float(timestep or 0.0), _ptr(nz),
+                                    tile, overlap, _ptr(out), out.size, C.byref(n)))
+        return out[:n.value]
+
+    def vae_decode_dev(self, latent, F, H, W, frames, timestep=None, noise=None, tile=0, overlap=1):
+        n = C.c_int()
+        self._ck(lib.ltx_vae_decode_dev(self._h, _ptr(latent), F, H, W, int(timestep is not None), float(timestep or 0.0),
+                                        _ptr(noise), tile, overlap, _ptr(frames), frames.numel(), C.byref(n)))
+        return n.value
+
+    def op_conv3d(self, x, w, bias, out, causal=False):
+        F, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        self._ck(lib.ltx_op_conv3d(self._h, _ptr(x), F, H, W, Cin, _ptr(w), _ptr(bias), Cout, int(causal), _ptr(out)))
+
     # ---- denoise loop ----
     @staticmethod
     def _options(cfg_scale=1.0, guidance_rescale=0.0, stg_scale=0.0, stg_blocks=(29,), ge_gamma=0.0):
@@ -285,8 +325,8 @@ class Context:
 def f32_to_bf16_bits(x):
     """Round-to-nearest-even f32 -> bf16 bit patterns (uint16), numpy."""
     x = np.ascontiguousarray(x, dtype=np.float32)
-    u = x.view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    u = x.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
     return r.reshape(x.shape)
 
 

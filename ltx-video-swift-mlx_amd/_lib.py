@@ -87,6 +87,13 @@ SIGNATURES = {
     "ltx_dit_set_cross_attn_scale": (_i, [_vp, _f, _i, _i]),
     "ltx_dit_set_stg": (_i, [_vp, _ip, _i, _i, _i]),
     "ltx_dit_clear_stg": (_i, [_vp]),
+    "ltx_vae_load": (_i, [_vp, C.c_char_p, C.c_char_p]),
+    "ltx_vae_init_synthetic": (_i, [_vp, _u64, _i]),
+    "ltx_vae_unload": (_i, [_vp]),
+    "ltx_vae_timestep_conditioning": (_i, [_vp]),
+    "ltx_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _l, _ip]),
+    "ltx_vae_decode_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _l, _ip]),
+    "ltx_op_conv3d": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "ltx_denoise": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _vp, _vp, _i, C.POINTER(DenoiseOptions), PROGRESS_CB, _vp]),
     "ltx_denoise_dev": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _vp, _vp, _i, _i, _u64, C.POINTER(DenoiseOptions), PROGRESS_CB, _vp]),
     "ltx_prof_enable": (_i, [_vp, _i]),

@@ -9,6 +9,7 @@
 #include "gemm.h"
 #include "hostmath.h"
 #include "pipeline.h"
+#include "vae.h"
 #include "runtime.h"
 
 namespace {
@@ -126,6 +127,7 @@ void ltx_ctx_destroy(ltx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->dit) dit_destroy(ctx->dit);
+    if (ctx->vae) vae_destroy(ctx->vae);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -372,6 +374,123 @@ int ltx_dit_clear_stg(ltx_ctx* ctx) {
     return guarded(ctx, [&] {
         DiTModel* m = need_dit(ctx);
         for (auto& b : m->blocks) b.skip_attn = b.skip_ff = false;
+    });
+}
+
+// ---- VAE ----
+static VaeModel* need_vae(ltx_ctx* ctx) {
+    if (!ctx->vae) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model component not loaded: vaeDecoder");
+    return ctx->vae;
+}
+
+int ltx_vae_load(ltx_ctx* ctx, const char* path, const char* config_json) {
+    if (!ctx || !path) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        if (ctx->vae) {
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            vae_destroy(ctx->vae);
+            ctx->vae = nullptr;
+        }
+        VaeModel* m = vae_create();
+        try {
+            vae_load_safetensors(ctx, m, path, config_json ? config_json : "");
+        } catch (...) {
+            vae_destroy(m);
+            throw;
+        }
+        ctx->vae = m;
+    });
+}
+
+int ltx_vae_init_synthetic(ltx_ctx* ctx, uint64_t seed, int timestep_conditioning) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        if (ctx->vae) {
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            vae_destroy(ctx->vae);
+            ctx->vae = nullptr;
+        }
+        VaeModel* m = vae_create();
+        try {
+            vae_init_synthetic(ctx, m, seed, timestep_conditioning != 0);
+        } catch (...) {
+            vae_destroy(m);
+            throw;
+        }
+        ctx->vae = m;
+    });
+}
+
+int ltx_vae_unload(ltx_ctx* ctx) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->vae) vae_destroy(ctx->vae);
+        ctx->vae = nullptr;
+    });
+}
+
+int ltx_vae_timestep_conditioning(const ltx_ctx* ctx) {
+    if (!ctx || !ctx->vae) return -LTX_ERR_MODEL_NOT_LOADED;
+    return ctx->vae->timestep_conditioning ? 1 : 0;
+}
+
+int ltx_vae_decode_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
+                       const float* noise, int tile, int overlap, float* frames_out, long frames_cap,
+                       int* n_frames_out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        VaeModel* m = need_vae(ctx);
+        VaeDecodeArgs a;
+        a.latent = latent; a.F = F; a.H = H; a.W = W;
+        a.has_timestep = has_timestep; a.timestep = timestep; a.noise = noise;
+        a.tile = tile; a.overlap = overlap;
+        a.frames = frames_out; a.frames_cap = frames_cap; a.n_frames_out = n_frames_out;
+        vae_decode(ctx, m, a);
+    });
+}
+
+int ltx_vae_decode(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
+                   const float* noise, int tile, int overlap, float* frames_out, long frames_cap, int* n_frames_out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        VaeModel* m = need_vae(ctx);
+        LTX_REQUIRE(latent && frames_out && F >= 1 && H >= 1 && W >= 1, "ltx_vae_decode: bad arguments");
+        const size_t n_lat = (size_t)128 * F * H * W * 4;
+        hipStream_t st = ctx->stream;
+        DevBuf dl, dn, df;
+        dl.ensure(n_lat);
+        HIP_CHECK(hipMemcpyAsync(dl.p, latent, n_lat, hipMemcpyHostToDevice, st));
+        if (has_timestep && noise) {
+            dn.ensure(n_lat);
+            HIP_CHECK(hipMemcpyAsync(dn.p, noise, n_lat, hipMemcpyHostToDevice, st));
+        }
+        df.ensure((size_t)frames_cap * 4);
+        int nf = 0;
+        VaeDecodeArgs a;
+        a.latent = dl.as<float>(); a.F = F; a.H = H; a.W = W;
+        a.has_timestep = has_timestep; a.timestep = timestep; a.noise = (has_timestep && noise) ? dn.as<float>() : nullptr;
+        a.tile = tile; a.overlap = overlap;
+        a.frames = df.as<float>(); a.frames_cap = frames_cap; a.n_frames_out = &nf;
+        vae_decode(ctx, m, a);
+        HIP_CHECK(hipMemcpyAsync(frames_out, df.p, (size_t)nf * H * 32 * W * 32 * 3 * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (n_frames_out) *n_frames_out = nf;
+    });
+}
+
+int ltx_op_conv3d(ltx_ctx* ctx, const uint16_t* x, int F, int H, int W, int Cin, const uint16_t* w, const float* bias,
+                  int Cout, int causal, float* out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        GemmArgs g;
+        g.A = x; g.B = w; g.ldb = 27L * Cin;
+        g.M = F * H * W; g.N = Cout; g.K = 27 * Cin;
+        g.conv = 1;
+        g.geom.F = F; g.geom.H = H; g.geom.W = W; g.geom.C = Cin; g.geom.causal = causal; g.geom.pad_mode = 0;
+        g.ep.bias_n = bias;
+        g.ep.out_f32 = out; g.ep.ld_f32 = Cout;
+        launch_gemm_bf16(g, ctx->stream);
     });
 }
 

@@ -61,8 +61,15 @@ void launch_lincomb(const float* a, const float* b, float ca, float cb, float* o
 
 // ---- VAE decoder helpers (channels-last f32 stream [P][C]) ----
 // latent [C][P] f32 (+ optional noise blend) * std + mean -> channels-last bf16 [P][C] (VideoDecoder.swift:366-381)
-void launch_vae_prepare(const float* latent, const float* noise, float noise_scale, const float* mean, const float* std_,
-                        bf16_t* out, int C, long P, hipStream_t stream);
+// latent/noise element (c,p) lives at [c*chan_stride + p] (lets a temporal tile be a strided view of the full latent)
+void launch_vae_prepare(const float* latent, long chan_stride, const float* noise, float noise_scale, const float* mean,
+                        const float* std_, bf16_t* out, int C, long P, hipStream_t stream);
+// out[r][c] = table[r][c] + (te ? te[r][c] : 0) + (r odd ? 1 : 0): rows shift,scale+1[,shift2,scale2+1]
+// (VAEResBlock3d modulation, VideoDecoder.swift:93-113; final norm :421-434)
+void launch_vae_make_mods(const float* table, const float* te, float* out, int rows, int C, hipStream_t stream);
+// temporal-tile blend (VideoDecoder.swift:561-592): r[i] = r[i]*(1-i/n) + nx[i]*(i/n) for frame i < n
+void launch_blend_frames(float* r, const float* nx, int n_frames, long frame_elems, hipStream_t stream);
+void launch_clip01(float* x, long n, hipStream_t stream);
 // pixel-norm over channels (eps 1e-8) * scale + shift -> SiLU -> bf16 (VideoDecoder.swift:29-32,118-127,419-436).
 // scale already contains the +1. x: f32 [P][C].
 void launch_pixelnorm_silu(const float* x, const float* scale, const float* shift, bf16_t* out, long P, int C,

@@ -325,7 +325,7 @@ __global__ void adain_kernel(float* __restrict__ x, const float* __restrict__ st
 
 // ---- VAE ----
 // latent [C][P] f32 -> channels-last bf16 [P][C], with optional noise blend and per-channel denormalisation
-__global__ __launch_bounds__(256) void vae_prepare_kernel(const float* __restrict__ latent,
+__global__ __launch_bounds__(256) void vae_prepare_kernel(const float* __restrict__ latent, long chan_stride,
                                                           const float* __restrict__ noise, float noise_scale,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ std_, bf16_t* __restrict__ out,
@@ -339,8 +339,8 @@ __global__ __launch_bounds__(256) void vae_prepare_kernel(const float* __restric
         const long p = p0 + tx;
         float v = 0.f;
         if (c < C && p < P) {
-            v = latent[(long)c * P + p];
-            if (noise) v = noise[(long)c * P + p] * noise_scale + (1.0f - noise_scale) * v;
+            v = latent[(long)c * chan_stride + p];
+            if (noise) v = noise[(long)c * chan_stride + p] * noise_scale + (1.0f - noise_scale) * v;
             v = v * std_[c] + mean[c];
         }
         tile[k][tx] = v;
@@ -417,6 +417,27 @@ __global__ void vae_unpatchify_frames_kernel(const float* __restrict__ x, long l
     float v = x[(((long)f * H + h) * W + w) * ldx + (c * 4 + a) * 4 + b];
     if (apply_clip) v = fminf(fmaxf((v + 1.0f) * 0.5f, 0.f), 1.f);
     frames[i] = v;
+}
+
+__global__ void vae_make_mods_kernel(const float* __restrict__ table, const float* __restrict__ te, float* __restrict__ out,
+                                     int rows, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * C) return;
+    const int r = i / C;
+    out[i] = table[i] + (te ? te[i] : 0.f) + ((r & 1) ? 1.0f : 0.f);
+}
+__global__ void blend_frames_kernel(float* __restrict__ r, const float* __restrict__ nx, int n_frames, long frame_elems) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (i >= frame_elems) return;
+    const float w = (float)f / (float)n_frames;
+    const long o = (long)f * frame_elems + i;
+    r[o] = r[o] * (1.0f - w) + nx[o] * w;
+}
+__global__ void clip01_kernel(float* __restrict__ x, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) x[i] = fminf(fmaxf((x[i] + 1.0f) * 0.5f, 0.f), 1.f);
 }
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
@@ -511,9 +532,22 @@ void launch_adain(float* x, const float* stats_x, const float* stats_ref, float 
     hipLaunchKernelGGL(adain_kernel, dim3(cdiv(n_per_chan, 256), BC), dim3(256), 0, stream, x, stats_x, stats_ref, factor, n_per_chan);
     HIP_CHECK(hipGetLastError());
 }
-void launch_vae_prepare(const float* latent, const float* noise, float noise_scale, const float* mean, const float* std_,
-                        bf16_t* out, int C, long P, hipStream_t stream) {
-    hipLaunchKernelGGL(vae_prepare_kernel, dim3(cdiv(P, 32), cdiv(C, 32)), dim3(256), 0, stream, latent, noise, noise_scale, mean, std_, out, C, P);
+void launch_vae_prepare(const float* latent, long chan_stride, const float* noise, float noise_scale, const float* mean,
+                        const float* std_, bf16_t* out, int C, long P, hipStream_t stream) {
+    hipLaunchKernelGGL(vae_prepare_kernel, dim3(cdiv(P, 32), cdiv(C, 32)), dim3(256), 0, stream, latent, chan_stride, noise, noise_scale, mean, std_, out, C, P);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_vae_make_mods(const float* table, const float* te, float* out, int rows, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(vae_make_mods_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, stream, table, te, out, rows, C);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_blend_frames(float* r, const float* nx, int n_frames, long frame_elems, hipStream_t stream) {
+    hipLaunchKernelGGL(blend_frames_kernel, dim3(cdiv(frame_elems, 256), n_frames), dim3(256), 0, stream, r, nx, n_frames, frame_elems);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_clip01(float* x, long n, hipStream_t stream) {
+    const int grid = cdiv(n, 256) < 65535 * 16 ? cdiv(n, 256) : 65535 * 16;
+    hipLaunchKernelGGL(clip01_kernel, dim3(grid), dim3(256), 0, stream, x, n);
     HIP_CHECK(hipGetLastError());
 }
 void launch_pixelnorm_silu(const float* x, const float* scale, const float* shift, bf16_t* out, long P, int C,

@@ -29,8 +29,8 @@ F32 = np.float32
 # ---------------------------------------------------------------------------------------------------------------
 def f32_to_bf16_bits(x):
     x = np.ascontiguousarray(x, dtype=np.float32)
-    u = x.view(np.uint32).astype(np.uint64)
-    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16).reshape(x.shape)
+    u = x.view(np.uint32)
+    return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16).reshape(x.shape)
 
 
 def bf16_bits_to_f32(b):
@@ -555,22 +555,47 @@ def vae_param_shapes(channels=VAE_CHANNELS, latent_channels=128, timestep_condit
             u = f"up_blocks_{2 * gi + 1}."
             s[u + "conv.conv.weight"] = (4 * c, c, 3, 3, 3)
             s[u + "conv.conv.bias"] = (4 * c,)
+        if timestep_conditioning:
+            t = g + "time_embedder.timestep_embedder."
+            s[t + "linear_1.weight"], s[t + "linear_1.bias"] = (256, 256), (256,)
+            s[t + "linear_2.weight"], s[t + "linear_2.bias"] = (4 * c, 256), (4 * c,)
+    if timestep_conditioning:
+        t = "last_time_embedder.timestep_embedder."
+        s[t + "linear_1.weight"], s[t + "linear_1.bias"] = (256, 256), (256,)
+        s[t + "linear_2.weight"], s[t + "linear_2.bias"] = (2 * channels[3], 256), (2 * channels[3],)
+        s["timestep_scale_multiplier"] = ()
     return s
 
 
-def vae_decode_raw(w, latent, channels=VAE_CHANNELS):
-    """VideoDecoder.callAsFunction without timestep conditioning (VideoDecoder.swift:358-449) -> [B,3,F,H,W]."""
-    x = (latent.astype(F32) * w["std_of_means"].astype(F32).reshape(1, -1, 1, 1, 1)
+def vae_time_embed(w, prefix, t_scaled):
+    """VAETimestepEmbedder on getTimestepEmbedding (VideoDecoder.swift:13-52)."""
+    e = timestep_embedding(np.asarray(t_scaled, F32).reshape(-1), 256)
+    h = silu(linear(e, w[prefix + "timestep_embedder.linear_1.weight"], w[prefix + "timestep_embedder.linear_1.bias"]))
+    return linear(h, w[prefix + "timestep_embedder.linear_2.weight"], w[prefix + "timestep_embedder.linear_2.bias"])
+
+
+def vae_decode_raw(w, latent, channels=VAE_CHANNELS, timestep=None, noise=None):
+    """VideoDecoder.callAsFunction (VideoDecoder.swift:358-449) -> [B,3,F,H,W]. With `timestep` the explicit `noise`
+    replaces the reference's MLXRandom.normal draw (:369)."""
+    x = latent.astype(F32)
+    scaled = None
+    if timestep is not None:
+        x = (noise.astype(F32) * F32(0.025) + (F32(1.0) - F32(0.025)) * x).astype(F32)
+        scaled = np.full((x.shape[0],), timestep, F32) * F32(w["timestep_scale_multiplier"])
+    x = (x * w["std_of_means"].astype(F32).reshape(1, -1, 1, 1, 1)
          + w["mean_of_means"].astype(F32).reshape(1, -1, 1, 1, 1)).astype(F32)
     x = conv3d_full(x, w["conv_in.conv.weight"], w["conv_in.conv.bias"])
     for gi in range(4):
+        te = vae_time_embed(w, f"up_blocks_{2 * gi}.time_embedder.", scaled) if scaled is not None else None
         for r in range(5):
-            x = vae_res_block(w, f"up_blocks_{2 * gi}.res_blocks.{r}.", x)
+            x = vae_res_block(w, f"up_blocks_{2 * gi}.res_blocks.{r}.", x, te)
         if gi < 3:
             x = vae_upsample(w, f"up_blocks_{2 * gi + 1}.", x)
     x = pixel_norm(x)
-    lsst = w["last_scale_shift_table"].astype(F32)
-    x = silu(x * (lsst[1] + 1).reshape(1, -1, 1, 1, 1) + lsst[0].reshape(1, -1, 1, 1, 1))
+    lsst = w["last_scale_shift_table"].astype(F32)[None]
+    if scaled is not None:
+        lsst = lsst + vae_time_embed(w, "last_time_embedder.", scaled).reshape(x.shape[0], 2, -1)
+    x = silu(x * (lsst[:, 1] + 1).reshape(lsst.shape[0], -1, 1, 1, 1) + lsst[:, 0].reshape(lsst.shape[0], -1, 1, 1, 1))
     x = conv3d_full(x, w["conv_out.conv.weight"], w["conv_out.conv.bias"])
     return vae_unpatchify(x, 4)
 
@@ -595,10 +620,11 @@ def vae_tile_plan(latent_frames, tile, overlap):
     return tiles, total
 
 
-def decode_video(w, latent, tile=0, overlap=1, channels=VAE_CHANNELS):
+def decode_video(w, latent, tile=0, overlap=1, channels=VAE_CHANNELS, timestep=None, noise=None, return_raw=False):
     """decodeVideo (VideoDecoder.swift:466-602) -> (F,H,W,3) f32 in [0,1]."""
     tiles, _ = vae_tile_plan(latent.shape[2], tile, overlap)
-    chunks = [vae_decode_raw(w, latent[:, :, s:e], channels) for s, e in tiles]
+    chunks = [vae_decode_raw(w, latent[:, :, s:e], channels, timestep, None if noise is None else noise[:, :, s:e])
+              for s, e in tiles]
     result = chunks[0]
     po = 8 * overlap
     for nxt in chunks[1:]:
@@ -609,6 +635,8 @@ def decode_video(w, latent, tile=0, overlap=1, channels=VAE_CHANNELS):
             result = np.concatenate([result[:, :, :rf - po], blended, nxt[:, :, po:]], axis=2)
         else:
             result = np.concatenate([result, nxt], axis=2)
+    if return_raw:
+        return result[0].transpose(1, 2, 3, 0).astype(F32)
     frames = np.clip((result + 1.0) / 2.0, 0.0, 1.0)[0]
     return frames.transpose(1, 2, 3, 0).astype(F32)
 
@@ -704,10 +732,16 @@ def synth_dit_weights(cfg, seed=1234):
     return w
 
 
-def synth_vae_weights(channels=VAE_CHANNELS, latent_channels=128, seed=77):
+def synth_vae_weights(channels=VAE_CHANNELS, latent_channels=128, seed=77, timestep_conditioning=False):
     rng = np.random.default_rng(seed)
     w = {}
-    for k, shp in vae_param_shapes(channels, latent_channels).items():
+    for k, shp in vae_param_shapes(channels, latent_channels, timestep_conditioning).items():
+        if k == "timestep_scale_multiplier":
+            w[k] = np.array(1000.0, F32)
+            continue
+        if "timestep_embedder" in k and k.endswith(".weight"):
+            w[k] = bf16_round((rng.standard_normal(shp, dtype=F32) / F32(16.0)))
+            continue
         if k == "mean_of_means":
             v = 0.1 * rng.standard_normal(shp)
         elif k == "std_of_means":
@@ -718,8 +752,8 @@ def synth_vae_weights(channels=VAE_CHANNELS, latent_channels=128, seed=77):
             v = 0.05 * rng.standard_normal(shp)
         else:
             fan_in = shp[1] * 27
-            v = rng.standard_normal(shp) / math.sqrt(fan_in)
-        w[k] = bf16_round(v.astype(F32))
+            v = rng.standard_normal(shp, dtype=F32) / F32(math.sqrt(fan_in))
+        w[k] = bf16_round(np.asarray(v, dtype=F32))
     return w
 
 
