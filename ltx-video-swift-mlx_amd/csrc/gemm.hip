@@ -33,6 +33,114 @@ LTX_DEVFN int reflect_idx(int i, int n) {
 }
 LTX_DEVFN int clamp_idx(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 
+// ---- epilogue: per-wave LDS transpose (16 rows at a time), then 16-B row-contiguous global accesses ----
+template <int BM, int BN>
+LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / 32][BN / 32], const GemmArgs& g, int m0, int n0, int wr, int wc, int lane,
+                             int wave, char* smem) {
+    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+    float* scr = (float*)(smem + wave * (16 * WN * 4));
+    constexpr int LPR = WN / 4;    // lanes per output row
+    constexpr int RPI = 64 / LPR;  // rows per wave-instruction
+    const GemmEpilogue& ep = g.ep;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = acc[mi][ni][r];
+#pragma unroll
+        for (int it = 0; it < 16 / RPI; ++it) {
+            const int row = it * RPI + lane / LPR;
+            const int c4 = (lane % LPR) * 4;
+            f32x4 v = *(const f32x4*)(scr + row * WN + c4);
+            const int gm = m0 + wr * WM + mi * 16 + row;
+            const int gn = n0 + wc * WN + c4;
+            if (gm >= g.M || gn >= g.N) continue;
+            const int nv = (g.N - gn) < 4 ? (g.N - gn) : 4;
+            if (ep.bias_n) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nv) v[e] += ep.bias_n[gn + e];
+            }
+            if (ep.bias_m) {
+                const float bm = ep.bias_m[gm];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bm;
+            }
+            if (ep.act == LTX_ACT_GELU_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+            } else if (ep.act == LTX_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+            }
+            if (ep.round_bf16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
+            }
+            long orow = gm;  // output row (remapped for depth-to-space)
+            int ocol = gn;
+            if (ep.d2s) {
+                // VAE upsampler (VideoDecoder.swift:201-251). Conv output channels were permuted at load time to
+                // n' = sub*Cout + c (sub = dt*4+dh*2+dw), so this 4-wide chunk has one `sub` and consecutive c.
+                const int cout = g.N >> 3;
+                const int sub = gn / cout;
+                const int c = gn - sub * cout;
+                const int dt = sub >> 2, dh = (sub >> 1) & 1, dw = sub & 1;
+                const int hw = g.geom.H * g.geom.W;
+                const int f = gm / hw;
+                const int rem = gm - f * hw;
+                const int y = rem / g.geom.W;
+                const int x = rem - y * g.geom.W;
+                const int fo = 2 * f + dt - 1;  // first frame after D2S is dropped
+                if (fo < 0) continue;
+                orow = ((long)fo * (2 * g.geom.H) + (2 * y + dh)) * (2 * g.geom.W) + (2 * x + dw);
+                ocol = c;
+                if (ep.resid_src) {
+                    // residual = D2S(x)[c mod C/8], tiled along channels (VideoDecoder.swift:219-234)
+                    const int cd2s = g.geom.C >> 3;
+                    const float* rs = ep.resid_src + (long)gm * ep.ld_resid;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e < nv) v[e] += rs[((c + e) % cd2s) * 8 + sub];
+                }
+            } else if (ep.resid) {
+                const float* rs = (ep.resid_src ? ep.resid_src + (long)gm * ep.ld_resid : ep.out_f32 + (long)gm * ep.ld_f32) + gn;
+                f32x4 gt;
+                if (ep.gate) {
+                    const float* gp = ep.gate + (long)(gm / ep.rows_per_batch) * ep.gate_bstride + gn;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gt[e] = (e < nv) ? gp[e] : 0.f;
+                } else {
+                    gt = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nv) v[e] = rs[e] + gt[e] * v[e];
+            }
+            if (ep.out_f32) {
+                float* o = ep.out_f32 + orow * ep.ld_f32 + ocol;
+                if (nv == 4) {
+                    *(f32x4*)o = v;
+                } else {
+                    for (int e = 0; e < nv; ++e) o[e] = v[e];
+                }
+            }
+            if (ep.out_bf16) {
+                bf16_t* o = ep.out_bf16 + orow * ep.ld_bf16 + ocol;
+                if (nv == 4) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)o = pk;
+                } else {
+                    for (int e = 0; e < nv; ++e) o[e] = f32_to_bf16(v[e]);
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -165,108 +273,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
         __syncthreads();  // LDS-DMA of the next stage has landed (vmcnt(0)) and every wave is done reading `cur`
     }
 
-    // ---- epilogue: per-wave LDS transpose (16 rows at a time), then 16-B row-contiguous global accesses ----
-    float* scr = (float*)(smem + wave * (16 * WN * 4));
-    constexpr int LPR = WN / 4;    // lanes per output row
-    constexpr int RPI = 64 / LPR;  // rows per wave-instruction
-    const GemmEpilogue& ep = g.ep;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = acc[mi][ni][r];
-#pragma unroll
-        for (int it = 0; it < 16 / RPI; ++it) {
-            const int row = it * RPI + lane / LPR;
-            const int c4 = (lane % LPR) * 4;
-            f32x4 v = *(const f32x4*)(scr + row * WN + c4);
-            const int gm = m0 + wr * WM + mi * 16 + row;
-            const int gn = n0 + wc * WN + c4;
-            if (gm >= g.M || gn >= g.N) continue;
-            const int nv = (g.N - gn) < 4 ? (g.N - gn) : 4;
-            if (ep.bias_n) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (e < nv) v[e] += ep.bias_n[gn + e];
-            }
-            if (ep.bias_m) {
-                const float bm = ep.bias_m[gm];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bm;
-            }
-            if (ep.act == LTX_ACT_GELU_TANH) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-            } else if (ep.act == LTX_ACT_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-            }
-            if (ep.round_bf16) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
-            }
-            long orow = gm;  // output row (remapped for depth-to-space)
-            int ocol = gn;
-            if (ep.d2s) {
-                // VAE upsampler (VideoDecoder.swift:201-251). Conv output channels were permuted at load time to
-                // n' = sub*Cout + c (sub = dt*4+dh*2+dw), so this 4-wide chunk has one `sub` and consecutive c.
-                const int cout = g.N >> 3;
-                const int sub = gn / cout;
-                const int c = gn - sub * cout;
-                const int dt = sub >> 2, dh = (sub >> 1) & 1, dw = sub & 1;
-                const int hw = g.geom.H * g.geom.W;
-                const int f = gm / hw;
-                const int rem = gm - f * hw;
-                const int y = rem / g.geom.W;
-                const int x = rem - y * g.geom.W;
-                const int fo = 2 * f + dt - 1;  // first frame after D2S is dropped
-                if (fo < 0) continue;
-                orow = ((long)fo * (2 * g.geom.H) + (2 * y + dh)) * (2 * g.geom.W) + (2 * x + dw);
-                ocol = c;
-                if (ep.resid_src) {
-                    // residual = D2S(x)[c mod C/8], tiled along channels (VideoDecoder.swift:219-234)
-                    const int cd2s = g.geom.C >> 3;
-                    const float* rs = ep.resid_src + (long)gm * ep.ld_resid;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (e < nv) v[e] += rs[((c + e) % cd2s) * 8 + sub];
-                }
-            } else if (ep.resid) {
-                const float* rs = (ep.resid_src ? ep.resid_src + (long)gm * ep.ld_resid : ep.out_f32 + (long)gm * ep.ld_f32) + gn;
-                f32x4 gt;
-                if (ep.gate) {
-                    const float* gp = ep.gate + (long)(gm / ep.rows_per_batch) * ep.gate_bstride + gn;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) gt[e] = (e < nv) ? gp[e] : 0.f;
-                } else {
-                    gt = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (e < nv) v[e] = rs[e] + gt[e] * v[e];
-            }
-            if (ep.out_f32) {
-                float* o = ep.out_f32 + orow * ep.ld_f32 + ocol;
-                if (nv == 4) {
-                    *(f32x4*)o = v;
-                } else {
-                    for (int e = 0; e < nv; ++e) o[e] = v[e];
-                }
-            }
-            if (ep.out_bf16) {
-                bf16_t* o = ep.out_bf16 + orow * ep.ld_bf16 + ocol;
-                if (nv == 4) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]);
-                    pk.y = pack_bf16x2(v[2], v[3]);
-                    *(uint2*)o = pk;
-                } else {
-                    for (int e = 0; e < nv; ++e) o[e] = f32_to_bf16(v[e]);
-                }
-            }
-        }
-    }
+    gemm_epilogue<BM, BN>(acc, g, m0, n0, wr, wc, lane, wave, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures. The reference cannot run here (no Swift/MLX), so the expected outputs
+come from the oracle, and the independent cross-check is torch CPU (conv3d via F.conv3d on the padded input; the DiT
+fixture is additionally recomputed with a torch re-implementation of the attention/FFN blocks below and must agree).
+
+    python tests/golden/make_golden.py
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+import ltx_oracle as o  # noqa: E402
+
+
+def torch_dit_forward(w, cfg, latent, context, ts, mask, F, H, W):
+    """Independent f32 torch implementation (different library, different op decomposition) of the same forward."""
+    t = {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in w.items()}
+    bf = lambda x: x.to(torch.bfloat16).float()
+    lin = lambda x, p: Fn.linear(x, t[p + ".weight"], t[p + ".bias"])
+    D, Hh = cfg.dim, cfg.num_heads
+    x = bf(lin(torch.from_numpy(latent), "patchify_proj"))
+    B = x.shape[0]
+    tt = torch.from_numpy(np.asarray(ts, np.float32)) * cfg.timestep_mult
+    half = 128
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    args = tt[:, None] * freqs[None]
+    e = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    emb = lin(Fn.silu(lin(e, "adaln_single.emb.linear_1")), "adaln_single.emb.linear_2")
+    ada = lin(Fn.silu(emb), "adaln_single.linear").reshape(B, 1, 6, D)
+    c = bf(lin(torch.from_numpy(context), "caption_projection.linear_1"))
+    c = bf(lin(bf(Fn.gelu(c, approximate="tanh")), "caption_projection.linear_2"))
+    bias = None if mask is None else ((1 - torch.from_numpy(mask).float()) * -10000.0)[:, None, None, :]
+    cos, sin = (torch.from_numpy(a) for a in o.rope_tables(F, H, W, D, Hh, cfg.rope_theta, cfg.max_pos))
+
+    def rope(z):
+        zh = z.reshape(B, -1, Hh, 2, 64)
+        cc, ss = cos.reshape(1, -1, Hh, 64), sin.reshape(1, -1, Hh, 64)
+        a, b = zh[:, :, :, 0], zh[:, :, :, 1]
+        return torch.stack([a * cc - b * ss, b * cc + a * ss], 3).reshape(B, -1, D)
+
+    def attn(p, xq, ctx=None, bias=None, use_rope=False, kvbf=False):
+        src = xq if ctx is None else ctx
+        q, k, v = lin(xq, p + "to_q"), lin(src, p + "to_k"), lin(src, p + "to_v")
+        if kvbf:
+            k, v = bf(k), bf(v)
+        q = Fn.rms_norm(q, (D,), t[p + "q_norm.weight"], 1e-6)
+        k = Fn.rms_norm(k, (D,), t[p + "k_norm.weight"], 1e-6)
+        if kvbf:
+            k = bf(k)
+        if use_rope:
+            q, k = rope(q), rope(k)
+        sh = lambda z: z.reshape(B, -1, Hh, 128).transpose(1, 2)
+        y = Fn.scaled_dot_product_attention(sh(q), sh(k), sh(v), attn_mask=bias, scale=1 / math.sqrt(128))
+        return lin(y.transpose(1, 2).reshape(B, -1, D), p + "to_out")
+
+    for i in range(cfg.num_layers):
+        p = f"transformer_blocks.{i}."
+        a6 = t[p + "scale_shift_table"][None, None] + ada
+        n = Fn.rms_norm(x, (D,), None, 1e-6)
+        if i == 0:
+            n = bf(n)
+        x = x + attn(p + "attn1.", n * (1 + a6[:, :, 1]) + a6[:, :, 0], use_rope=True) * a6[:, :, 2]
+        x = x + attn(p + "attn2.", x, ctx=c, bias=bias, kvbf=True)
+        n = Fn.rms_norm(x, (D,), None, 1e-6) * (1 + a6[:, :, 4]) + a6[:, :, 3]
+        hdn = Fn.gelu(lin(n, p + "ff.project_in.proj"), approximate="tanh")
+        x = x + lin(hdn, p + "ff.project_out") * a6[:, :, 5]
+    ss = t["scale_shift_table"][None, None] + emb.reshape(B, 1, 1, D)
+    out = Fn.layer_norm(x, (D,), eps=1e-6) * (1 + ss[:, :, 1]) + ss[:, :, 0]
+    return lin(out, "proj_out").numpy()
+
+
+def main():
+    seed, layers, heads, caption = 11, 2, 2, 128
+    cfg = o.DiTConfig(num_layers=layers, num_heads=heads, caption_channels=caption)
+    w = o.synth_dit_weights(cfg, seed=seed)
+    rng = np.random.default_rng(100)
+    F, H, W, S = 2, 3, 5, 21
+    latent = o.bf16_round(rng.standard_normal((1, F * H * W, 128)).astype(np.float32))
+    context = o.bf16_round(rng.standard_normal((1, S, caption)).astype(np.float32))
+    mask = (rng.random((1, S)) > 0.3).astype(np.int32)
+    mask[:, 0] = 1
+    ts = np.array([0.725], np.float32)
+    vel = o.dit_forward(w, cfg, latent, context, ts, mask, F, H, W)
+    vel_t = torch_dit_forward(w, cfg, latent, context, ts, mask, F, H, W)
+    err = np.abs(vel - vel_t).max() / np.abs(vel).max()
+    print("DiT oracle vs torch: max rel err", err)
+    assert err < 2e-4
+    np.savez_compressed(os.path.join(HERE, "dit_tiny.npz"), seed=seed, layers=layers, heads=heads, caption=caption,
+                        fhw=np.array([F, H, W]), latent=latent, context=context, mask=mask, ts=ts,
+                        velocity=vel.astype(np.float32))
+    x = o.bf16_round(rng.standard_normal((1, 64, 2, 3, 4)).astype(np.float32))
+    cw = o.bf16_round((rng.standard_normal((64, 64, 3, 3, 3)) / math.sqrt(64 * 27)).astype(np.float32))
+    cb = o.bf16_round((0.1 * rng.standard_normal(64)).astype(np.float32))
+    y = o.conv3d_full(x, cw, cb)
+    xt = torch.from_numpy(x)
+    xp = Fn.pad(xt.reshape(1, 64 * 2, 3, 4), (1, 1, 1, 1), mode="reflect").reshape(1, 64, 2, 5, 6)
+    xp = torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], 2)
+    yt = Fn.conv3d(xp, torch.from_numpy(cw), torch.from_numpy(cb)).numpy()
+    print("conv3d oracle vs torch:", np.abs(y - yt).max())
+    assert np.abs(y - yt).max() < 1e-4
+    np.savez_compressed(os.path.join(HERE, "conv3d_small.npz"), x=x, w=cw, b=cb, y=y.astype(np.float32))
+    print("fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

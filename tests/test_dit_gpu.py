@@ -102,3 +102,22 @@ def test_dit_errors(ltx, gpu_ctx, tmp_path):
         c2.dit_load(bad)
     assert e.value.case == "weightLoadingFailed"
     c2.close()
+
+
+def test_dit_forward_vs_golden_fixture(ltx, oracle, gpu_ctx, tmp_path):
+    """HIP path vs the committed golden vector (tests/golden/dit_tiny.npz: oracle output cross-checked against an
+    independent torch implementation by make_golden.py)."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_tiny.npz"))
+    heads, layers, caption = int(g["heads"]), int(g["layers"]), int(g["caption"])
+    cfg, ocfg = small_cfg(ltx, oracle, heads=heads, layers=layers, caption=caption)
+    w = oracle.synth_dit_weights(ocfg, seed=int(g["seed"]))
+    path = tmp_path / "dit_golden.safetensors"
+    write_dit_file(oracle, w, path)
+    c = ltx.Context(0)
+    c.dit_load(path, cfg)
+    F, H, W = (int(v) for v in g["fhw"])
+    got = c.dit_forward(ltx.f32_to_bf16_bits(g["latent"]), ltx.f32_to_bf16_bits(g["context"]), g["ts"], g["mask"], F, H, W)
+    c.close()
+    assert rel_l2(got, g["velocity"]) <= 2e-2

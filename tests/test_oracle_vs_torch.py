@@ -1,0 +1,114 @@
+"""CPU tests: the oracle's ops cross-checked against an independent implementation (torch CPU), since the reference
+itself cannot run here. Also pins the oracle to the committed golden fixtures."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_bf16_round_matches_torch(oracle):
+    x = np.random.default_rng(0).standard_normal(100000).astype(np.float32) * 37.0
+    assert np.array_equal(oracle.bf16_round(x), torch.from_numpy(x).to(torch.bfloat16).float().numpy())
+
+
+def test_rms_layer_norm(oracle):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((7, 512)).astype(np.float32) * 3
+    w = rng.standard_normal(512).astype(np.float32)
+    ref = Fn.rms_norm(torch.from_numpy(x), (512,), torch.from_numpy(w), eps=1e-6).numpy()
+    assert np.allclose(oracle.rms_norm(x, w, 1e-6), ref, rtol=1e-5, atol=1e-6)
+    ref = Fn.layer_norm(torch.from_numpy(x), (512,), eps=1e-6).numpy()
+    assert np.allclose(oracle.layer_norm(x, 1e-6), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_activations(oracle):
+    x = torch.linspace(-6, 6, 1001)
+    assert np.allclose(oracle.gelu_tanh(x.numpy()), Fn.gelu(x, approximate="tanh").numpy(), atol=1e-6)
+    assert np.allclose(oracle.silu(x.numpy()), Fn.silu(x).numpy(), atol=1e-6)
+
+
+def test_sdpa(oracle):
+    rng = np.random.default_rng(2)
+    B, H, Tq, Tk = 2, 3, 37, 53
+    q, k, v = (rng.standard_normal((B, t, H * 128)).astype(np.float32) for t in (Tq, Tk, Tk))
+    bias = ((rng.random((B, Tk)) > 0.7) * -10000.0).astype(np.float32)
+    got = oracle.sdpa(q, k, v, H, 1 / math.sqrt(128), bias)
+    tq, tk, tv = (torch.from_numpy(a).reshape(B, -1, H, 128).transpose(1, 2) for a in (q, k, v))
+    ref = Fn.scaled_dot_product_attention(tq, tk, tv, attn_mask=torch.from_numpy(bias)[:, None, None, :], scale=1 / math.sqrt(128))
+    assert np.allclose(got, ref.transpose(1, 2).reshape(B, Tq, H * 128).numpy(), atol=2e-5)
+
+
+def test_split_rope_is_rotation(oracle):
+    F, H, W, heads = 2, 3, 4, 2
+    cos, sin = oracle.rope_tables(F, H, W, dim=heads * 128, num_heads=heads)
+    x = np.random.default_rng(3).standard_normal((1, F * H * W, heads * 128)).astype(np.float32)
+    y = oracle.apply_split_rope(x, cos, sin, heads)
+    # norms of (a_i, b_i) pairs are preserved; identity slots (first 2 of head 0) untouched
+    xr, yr = x.reshape(1, -1, heads, 2, 64), y.reshape(1, -1, heads, 2, 64)
+    assert np.allclose((xr ** 2).sum(3), (yr ** 2).sum(3), rtol=1e-5)
+    assert np.array_equal(xr[:, :, 0, :, :2], yr[:, :, 0, :, :2])
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_conv3d_full(oracle, causal):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((1, 8, 3, 5, 6)).astype(np.float32)
+    w = rng.standard_normal((12, 8, 3, 3, 3)).astype(np.float32)
+    b = rng.standard_normal(12).astype(np.float32)
+    xt = torch.from_numpy(x)
+    xp = Fn.pad(xt.reshape(1, 8 * 3, 5, 6), (1, 1, 1, 1), mode="reflect").reshape(1, 8, 3, 7, 8)
+    xp = torch.cat([xp[:, :, :1]] * 2 + [xp], 2) if causal else torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], 2)
+    ref = Fn.conv3d(xp, torch.from_numpy(w), torch.from_numpy(b)).numpy()
+    assert np.allclose(oracle.conv3d_full(x, w, b, causal), ref, atol=1e-4)
+
+
+def test_depth_to_space_and_unpatchify_index_maps(oracle):
+    # D2S: out[c, 2t+dt, 2h+dh, 2w+dw] = in[((c*2+dt)*2+dh)*2+dw, t, h, w]  (VideoDecoder.swift:201-213)
+    x = np.arange(16 * 2 * 3 * 4, dtype=np.float32).reshape(1, 16, 2, 3, 4)
+    y = oracle.depth_to_space(x, 2)
+    for c, t, h, w, dt, dh, dw in [(0, 0, 0, 0, 0, 0, 0), (1, 1, 2, 3, 1, 0, 1), (0, 1, 1, 2, 0, 1, 1)]:
+        assert y[0, c, 2 * t + dt, 2 * h + dh, 2 * w + dw] == x[0, ((c * 2 + dt) * 2 + dh) * 2 + dw, t, h, w]
+    # unpatchify: channel (c*4+a)*4+b -> (H index 4h+b, W index 4w+a)  (VideoDecoder.swift:257-275)
+    z = np.arange(48 * 2 * 2 * 3, dtype=np.float32).reshape(1, 48, 2, 2, 3)
+    u = oracle.vae_unpatchify(z, 4)
+    for c, a, b, t, h, w in [(0, 0, 0, 0, 0, 0), (2, 3, 1, 1, 1, 2), (1, 0, 2, 0, 1, 1)]:
+        assert u[0, c, t, 4 * h + b, 4 * w + a] == z[0, (c * 4 + a) * 4 + b, t, h, w]
+    assert u.shape == (1, 3, 2, 8, 12)
+
+
+def test_guidance_and_adain(oracle):
+    rng = np.random.default_rng(5)
+    u, c = (rng.standard_normal((1, 8, 2, 3, 4)).astype(np.float32) for _ in range(2))
+    v = oracle.apply_cfg(u, c, 4.0)
+    assert np.allclose(v, u + 4.0 * (c - u), atol=1e-5)
+    r = oracle.guidance_rescale(v, c, 1.0)
+    assert abs(r.std() - c.std()) < 1e-3 * c.std()
+    ref = rng.standard_normal((1, 8, 1, 2, 2)).astype(np.float32) * 3 + 1
+    a = oracle.adain_filter_latent(v, ref)
+    assert np.allclose(a.mean((2, 3, 4)), ref.mean((2, 3, 4)), atol=1e-4)
+    assert np.allclose(a.std((2, 3, 4)), ref.std((2, 3, 4)), rtol=1e-4)
+
+
+def test_euler_step(oracle):
+    x = np.array([1.0, -2.0], np.float32)
+    v = np.array([0.5, 0.25], np.float32)
+    assert np.allclose(oracle.euler_step(x, v, 0.8, 0.0), x - 0.8 * v)
+    # x + (sigma_next - sigma) * v
+    assert np.allclose(oracle.euler_step(x, v, 0.8, 0.3), x + (0.3 - 0.8) * v, atol=1e-6)
+
+
+def test_oracle_matches_golden_fixtures(oracle):
+    """Fixtures are produced by tests/golden/make_golden.py (committed with them): regression pin for the oracle."""
+    g = np.load(os.path.join(GOLD, "dit_tiny.npz"))
+    ocfg = oracle.DiTConfig(num_layers=int(g["layers"]), num_heads=int(g["heads"]), caption_channels=int(g["caption"]))
+    w = oracle.synth_dit_weights(ocfg, seed=int(g["seed"]))
+    F, H, W = (int(v) for v in g["fhw"])
+    vel = oracle.dit_forward(w, ocfg, g["latent"], g["context"], g["ts"], g["mask"], F, H, W)
+    assert np.allclose(vel, g["velocity"], rtol=1e-4, atol=1e-4)
+    c = np.load(os.path.join(GOLD, "conv3d_small.npz"))
+    assert np.allclose(oracle.conv3d_full(c["x"], c["w"], c["b"]), c["y"], atol=1e-4)

@@ -100,3 +100,17 @@ def test_vae_decode_timestep_conditioned(ltx, oracle, gpu_ctx, vae_model):
     assert err <= 2e-2 and rel <= 3e-2, (err, rel)
     with pytest.raises(ltx.LTXError):  # noise is an explicit input
         gpu_ctx.vae_decode(lat, timestep=0.05, noise=None)
+
+
+def test_conv3d_vs_golden_fixture(gpu_ctx):
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "conv3d_small.npz"))
+    x, w, b, y = g["x"], g["w"], g["b"], g["y"]
+    xd = torch.from_numpy(np.ascontiguousarray(x[0].transpose(1, 2, 3, 0))).to(torch.bfloat16).cuda()
+    wd = torch.from_numpy(relayout(w)).to(torch.bfloat16).cuda()
+    out = torch.empty(xd.shape[:3] + (w.shape[0],), device="cuda")
+    gpu_ctx.op_conv3d(xd, wd, torch.from_numpy(b).cuda(), out)
+    torch.cuda.synchronize()
+    ref = y[0].transpose(1, 2, 3, 0)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-4  # inputs are bf16-exact: accumulation order only
