@@ -71,7 +71,8 @@ void ltx_transformer_config_default(ltx_transformer_config* cfg);
 int ltx_ctx_create(int device, ltx_ctx** out);
 void ltx_ctx_destroy(ltx_ctx* ctx);
 const char* ltx_last_error(const ltx_ctx* ctx);
-/* Run all work of this context on an existing HIP stream (hipStream_t passed as void*); NULL = context's own. */
+/* Run all work of this context on an existing HIP stream (hipStream_t passed as void*). The handle is used as given:
+ * NULL selects the default (null) stream. A new context starts on a private non-blocking stream. */
 int ltx_ctx_set_stream(ltx_ctx* ctx, void* hip_stream);
 int ltx_ctx_synchronize(ltx_ctx* ctx);
 /* Counts of the last load call: tensors applied / model parameters absent from the file (left at the reference's
@@ -218,7 +219,8 @@ int ltx_prof_collect(ltx_ctx* ctx, int kind, double* total_ms, long* launches, d
  * Kernel-level entry points (DEVICE pointers). These expose the individual gfx950 kernels so that parity tests can
  * pin each one against the oracle; they are not needed by a pipeline caller.
  * ---------------------------------------------------------------------------------------------------------- */
-/* C[M,N] = A[M,K] . B[N,K]^T (+bias[N]) ; act: 0 none, 1 gelu-tanh, 2 silu; tile_cfg: -1 auto, 0/1/2 forced.
+/* C[M,N] = A[M,K] . B[N,K]^T (+bias[N]) ; act: 0 none, 1 gelu-tanh, 2 silu; tile_cfg: -1 auto, else a forced tile configuration
+ * (0,1,3,4: two-stage 4-wave tiles; 21,23,25: 8-wave LDS-ring tiles).
  * Exactly one of out_f32/out_bf16 may be NULL. */
 int ltx_op_gemm_bf16(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb, const float* bias, int M,
                      int N, int K, int act, int tile_cfg, float* out_f32, long ld_f32, uint16_t* out_bf16,

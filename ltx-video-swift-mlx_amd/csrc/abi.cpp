@@ -137,17 +137,11 @@ const char* ltx_last_error(const ltx_ctx* ctx) { return ctx ? ctx->last_error.c_
 int ltx_ctx_set_stream(ltx_ctx* ctx, void* hip_stream) {
     if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
     return guarded(ctx, [&] {
-        if (ctx->own_stream && ctx->stream) {
-            HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            HIP_CHECK(hipStreamDestroy(ctx->stream));
-        }
-        if (hip_stream) {
-            ctx->stream = (hipStream_t)hip_stream;
-            ctx->own_stream = false;
-        } else {
-            HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-            ctx->own_stream = true;
-        }
+        if (ctx->stream) HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->own_stream && ctx->stream) HIP_CHECK(hipStreamDestroy(ctx->stream));
+        // the handle is used as given: NULL is the (legacy) default stream, which is what torch's default stream is
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
     });
 }
 

@@ -55,7 +55,8 @@ struct GemmArgs {
 
 // Launches on `stream`. Picks the tile shape from (M,N). Throws LtxError on invalid shapes.
 void launch_gemm_bf16(const GemmArgs& args, hipStream_t stream);
-// Force a tile config (0: 128x128, 1: 192x128, 2: 256x128) - used by tests/bench sweeps.
+// Force a tile config (v1: 0 128x128, 1 192x128, 3 96x128, 4 128x96; v2 ring: 21 192x128, 23 256x128, 25 128x192) -
+// used by tests/bench sweeps.
 void launch_gemm_bf16_cfg(const GemmArgs& args, int cfg, hipStream_t stream);
 
 // Small-M path (M <= 8): out[m][n] = act_out( sum_k in_act(a[m][k]) * W[n][k] + bias[n] ), f32 activations x bf16

@@ -34,13 +34,12 @@ LTX_DEVFN int reflect_idx(int i, int n) {
 LTX_DEVFN int clamp_idx(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 
 // ---- epilogue: per-wave LDS transpose (16 rows at a time), then 16-B row-contiguous global accesses ----
-template <int BM, int BN>
-LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / 32][BN / 32], const GemmArgs& g, int m0, int n0, int wr, int wc, int lane,
-                             int wave, char* smem) {
-    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+template <int BM, int BN, int WGM = 2, int WGN = 2>
+LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const GemmArgs& g, int m0, int n0, int wr, int wc,
+                             int lane, int wave, char* smem) {
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
     float* scr = (float*)(smem + wave * (16 * WN * 4));
     constexpr int LPR = WN / 4;    // lanes per output row
-    constexpr int RPI = 64 / LPR;  // rows per wave-instruction
     const GemmEpilogue& ep = g.ep;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -49,9 +48,10 @@ LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / 32][BN / 32], const GemmArgs& g, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = acc[mi][ni][r];
 #pragma unroll
-        for (int it = 0; it < 16 / RPI; ++it) {
-            const int row = it * RPI + lane / LPR;
-            const int c4 = (lane % LPR) * 4;
+        for (int it = 0; it < (16 * LPR) / 64; ++it) {
+            const int chunk = it * 64 + lane;  // 16 rows x LPR float4 chunks, row-major
+            const int row = chunk / LPR;
+            const int c4 = (chunk % LPR) * 4;
             f32x4 v = *(const f32x4*)(scr + row * WN + c4);
             const int gm = m0 + wr * WM + mi * 16 + row;
             const int gn = n0 + wc * WN + c4;
@@ -276,6 +276,196 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
     gemm_epilogue<BM, BN>(acc, g, m0, n0, wr, wc, lane, wave, smem);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2 main loop: NSTAGE-deep LDS ring filled NSTAGE-1 tiles ahead by LDS-DMA, counted `s_waitcnt vmcnt(N)` + raw
+// `s_barrier` (never vmcnt(0) in the steady state), and a skewed software pipeline on the register fragments:
+//
+//   iteration t:   ds_read frags(t, kk=1) -> set B      | MFMA(set A = frags(t, kk=0))      <- LDS latency hidden
+//                  wait tile t+1 landed ; s_barrier
+//                  LDS-DMA tile t+NSTAGE-1 -> ring slot of tile t-1 (every wave is past its reads of t-1)
+//                  ds_read frags(t+1, kk=0) -> set A    | MFMA(set B)                       <- barrier + LDS latency hidden
+//
+// One barrier per K-tile, loads in flight across it (guide "Pipelining across barriers": counted vmcnt + raw barrier).
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+LTX_DEVFN void wait_vmcnt_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WGM * WGN;  // waves per workgroup
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
+    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_PER_WAVE = BM / 8 / NW, B_PER_WAVE = BN / 8 / NW;
+    static_assert(A_PER_WAVE * 8 * NW == BM && B_PER_WAVE * 8 * NW == BN, "tile rows must split evenly over the waves");
+    constexpr int LPT = A_PER_WAVE + B_PER_WAVE;  // LDS-DMA instructions per wave per K-tile
+    constexpr int PD = NSTAGE - 1;                // prefetch distance in tiles
+    static_assert(NSTAGE >= 3, "ring needs >= 3 slots");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WGN, wc = wave % WGN;
+
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int srow = lane >> 3;
+    const int pch = lane & 7;
+    const bf16_t* a_src[A_PER_WAVE];
+    const bf16_t* b_src[B_PER_WAVE];
+    RowPos a_pos[A_PER_WAVE];
+    int a_lch[A_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int row = (wave + NW * i) * 8 + srow;
+        const int lch = pch ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < g.M ? gm : g.M - 1;
+        a_lch[i] = lch;
+        if constexpr (CONV) {
+            const int hw = g.geom.H * g.geom.W;
+            a_pos[i].f = gm / hw;
+            const int rem = gm - a_pos[i].f * hw;
+            a_pos[i].y = rem / g.geom.W;
+            a_pos[i].x = rem - a_pos[i].y * g.geom.W;
+            a_src[i] = g.A;
+        } else {
+            a_src[i] = g.A + (long)gm * g.lda + lch * 8;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i) {
+        const int row = (wave + NW * i) * 8 + srow;
+        const int lch = pch ^ ((row >> 1) & 7);
+        int gn = n0 + row;
+        gn = gn < g.N ? gn : g.N - 1;
+        b_src[i] = g.B + (long)gn * g.ldb + lch * 8;
+    }
+    const int nk = g.K / BK;
+    const int cpt = CONV ? (g.geom.C / BK) : 1;
+
+    auto stage = [&](int slot, int kt) {
+        char* base = smem + slot * STAGE;
+        if constexpr (CONV) {
+            const int tap = kt / cpt;
+            const int cc = kt - tap * cpt;
+            const int dt = tap / 9, dy = (tap - dt * 9) / 3, dx = tap - dt * 9 - dy * 3;
+#pragma unroll
+            for (int i = 0; i < A_PER_WAVE; ++i) {
+                int fi = g.geom.causal ? (a_pos[i].f + dt - 2) : (a_pos[i].f + dt - 1);
+                fi = clamp_idx(fi, g.geom.F);
+                int yi, xi;
+                if (g.geom.pad_mode == 0) {
+                    yi = reflect_idx(a_pos[i].y + dy - 1, g.geom.H);
+                    xi = reflect_idx(a_pos[i].x + dx - 1, g.geom.W);
+                } else {
+                    yi = clamp_idx(a_pos[i].y + dy - 1, g.geom.H);
+                    xi = clamp_idx(a_pos[i].x + dx - 1, g.geom.W);
+                }
+                const long pos = ((long)fi * g.geom.H + yi) * g.geom.W + xi;
+                const bf16_t* src = g.A + pos * g.geom.C + cc * BK + a_lch[i] * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024),
+                                                 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PER_WAVE; ++i) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(a_src[i] + (long)kt * BK),
+                    (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_WAVE; ++i) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(b_src[i] + (long)kt * BK),
+                (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
+        }
+    };
+
+    const int frow = lane & 15;
+    const int fsw = (lane >> 1) & 7;
+    const int foff0 = frow * ROW_BYTES + ((((lane >> 4) + 0) ^ fsw) << 4);
+    const int foff1 = frow * ROW_BYTES + ((((lane >> 4) + 4) ^ fsw) << 4);
+    const int a_wave_off = (wr * WM) * ROW_BYTES;
+    const int b_wave_off = A_BYTES + (wc * WN) * ROW_BYTES;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    s16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+    auto load_frags = [&](int slot, int fo, s16x8(&fa)[MI], s16x8(&fb)[NI]) {
+        const char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = *(const s16x8*)(base + a_wave_off + i * 16 * ROW_BYTES + fo);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[j] = *(const s16x8*)(base + b_wave_off + j * 16 * ROW_BYTES + fo);
+    };
+    // MFMAs idx in [FROM, TO) of the MIxNI grid (row-major) - split so that the compiler-inserted lgkmcnt wait sits
+    // in front of the FIRST product only, while nothing younger is outstanding (see the loop below)
+    auto mfma_first = [&](const s16x8(&fa)[MI], const s16x8(&fb)[NI]) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[0]),
+                                                            __builtin_bit_cast(bf16x8_t, fb[0]), acc[0][0], 0, 0, 0);
+    };
+    auto mfma_rest = [&](const s16x8(&fa)[MI], const s16x8(&fb)[NI]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (i + j > 0)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
+                                                                        __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: fill PD ring slots, wait for tile 0, fetch its first fragments
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+        if (s < nk) stage(s, s);
+    if (nk >= PD) wait_vmcnt_barrier<(PD - 1) * LPT>(); else wait_vmcnt_barrier<0>();
+    load_frags(0, foff0, fa0, fb0);
+
+    int slot = 0;  // ring slot of tile t
+    for (int kt = 0; kt < nk; ++kt) {
+        int nslot = slot + 1;
+        nslot = nslot == NSTAGE ? 0 : nslot;
+        int pslot = slot - 1;  // slot of tile t-1 == slot of tile t+PD
+        pslot = pslot < 0 ? NSTAGE - 1 : pslot;
+
+        // first half: the only LDS reads outstanding at the first MFMA are set A's (issued half an iteration ago)
+        mfma_first(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(slot, foff1, fa1, fb1);
+        mfma_rest(fa0, fb0);
+        // tile t+1 must have landed for every wave; tiles t+2 .. t+PD-1 may stay in flight
+        if (kt + PD < nk + 0 && PD >= 2) {
+            // steady state: tiles up to t+PD-1 were issued -> PD-2 newer tiles outstanding after tile t+1
+            wait_vmcnt_barrier<(PD >= 2 ? (PD - 2) * LPT : 0)>();
+        } else {
+            wait_vmcnt_barrier<0>();
+        }
+        if (kt + PD < nk) stage(pslot, kt + PD);
+        mfma_first(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) load_frags(nslot, foff0, fa0, fb0);
+        mfma_rest(fa1, fb1);
+        slot = nslot;
+    }
+    __syncthreads();
+    gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // small-M path: one wave per output column, f32 activations x bf16 weights
 // ---------------------------------------------------------------------------------------------------------------
@@ -332,6 +522,20 @@ void launch_one(const GemmArgs& a, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
 }
 
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2>
+void launch_v2(const GemmArgs& a, hipStream_t stream) {
+    constexpr int smem = NSTAGE * (BM + BN) * ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN>), dim3(tiles), dim3(WGM * WGN * 64), smem, stream, a);
+    HIP_CHECK(hipGetLastError());
+}
+
 void validate(const GemmArgs& a) {
     LTX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     LTX_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
@@ -358,37 +562,54 @@ void validate(const GemmArgs& a) {
 void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     validate(a);
     ProfScope prof(a.conv ? PROF_CONV : PROF_GEMM, 2.0 * a.M * a.N * a.K, stream);
+    // cfg 0..2: v1 (2-stage, one barrier + full drain per K-tile); cfg 10..: v2 (ring + counted vmcnt)
     if (a.conv) {
         switch (cfg) {
             case 0: launch_one<128, 128, true>(a, stream); break;
             case 1: launch_one<192, 128, true>(a, stream); break;
-            default: launch_one<256, 128, true>(a, stream); break;
+            case 3: launch_one<96, 128, true>(a, stream); break;
+            case 4: launch_one<128, 96, true>(a, stream); break;
+            case 21: launch_v2<192, 128, 4, true, 4, 2>(a, stream); break;   // 8 waves (4x2), per-wave 48x64, 4-slot ring
+            case 23: launch_v2<256, 128, 3, true, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
+            case 25: launch_v2<128, 192, 4, true, 2, 4>(a, stream); break;
+            default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
         }
     } else {
         switch (cfg) {
             case 0: launch_one<128, 128, false>(a, stream); break;
             case 1: launch_one<192, 128, false>(a, stream); break;
-            default: launch_one<256, 128, false>(a, stream); break;
+            case 3: launch_one<96, 128, false>(a, stream); break;
+            case 4: launch_one<128, 96, false>(a, stream); break;
+            case 21: launch_v2<192, 128, 4, false, 4, 2>(a, stream); break;  // 8 waves (4x2), per-wave 48x64, 4-slot ring
+            case 23: launch_v2<256, 128, 3, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
+            case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
+            default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
         }
     }
 }
 
 void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
-    // Tile choice: minimise (waves of workgroups over 256 CUs x 2 resident blocks) x tile cost. With M=1536 and
-    // N=4096 (the DiT's most common shape) 192x128 gives exactly 256 workgroups = one per CU.
-    const long n_tiles = (a.N + 127) / 128;
-    auto cost = [&](int bm) {
-        const long tiles = ((a.M + bm - 1) / bm) * n_tiles;
-        const long slots = 512;  // two resident workgroups per CU
-        const long rounds = (tiles + slots - 1) / slots;
-        // a round with <=256 tiles runs one block per CU (faster per block than two co-resident ones)
-        const double per_round = (tiles <= 256) ? 0.62 : 1.0;
-        return (double)rounds * per_round * bm;
-    };
+    // Tile choice = workgroup-count quantisation x structure efficiency. Two structures:
+    //   v1 (cfg 0,1,3,4): 4 waves, 2 LDS stages, TWO workgroups resident per CU (512 slots) - two waves per SIMD from
+    //       co-residency; best when a launch has >= 512 tiles. Its single-tile prefetch exposes HBM latency on
+    //       weights that are streamed once (the DiT case), hence the lower factor for the small tiles.
+    //   v2 (cfg 21,23,25): 8 waves (two per SIMD inside ONE workgroup per CU, 256 slots), 3/4-slot LDS ring filled
+    //       2-3 K-tiles ahead with counted vmcnt - HBM-cold weights cost nothing; best at exactly k*256 tiles.
+    // Measured on MI355X, HBM-cold B operand, random data (tools/bench_gemm.py --cold), TFLOP/s:
+    //   M=1536 N=4096 K=4096 : cfg21 944 | cfg0 754 | cfg1 608      N=8192: cfg1 1026 | cfg21 949
+    //   N=16384: cfg1 1049 | cfg21 991         K=16384: cfg21 1094 | cfg0 864       M=4096 N=1536: cfg25 876 | cfg0 629
+    struct Cand { int cfg, bm, bn, slots; double f; };
+    static const Cand cands[] = {{1, 192, 128, 512, 1.00}, {21, 192, 128, 256, 0.95}, {25, 128, 192, 256, 0.90},
+                                 {0, 128, 128, 512, 0.80}, {3, 96, 128, 512, 0.72},   {4, 128, 96, 512, 0.72}};
     int best = 0;
-    double bc = cost(128);
-    if (cost(192) < bc) { best = 1; bc = cost(192); }
-    if (cost(256) < bc) { best = 2; bc = cost(256); }
+    double be = -1;
+    for (const Cand& c : cands) {
+        const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
+        const long rounds = (tiles + c.slots - 1) / c.slots;
+        const double fill = ((double)a.M * a.N) / ((double)tiles * c.bm * c.bn);  // ragged edges waste MFMA work
+        const double e = (double)tiles / (double)(rounds * c.slots) * c.f * fill;
+        if (e > be + 1e-9) { be = e; best = c.cfg; }
+    }
     launch_gemm_bf16_cfg(a, best, stream);
 }
 

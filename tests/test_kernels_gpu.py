@@ -26,8 +26,8 @@ def as_f32(t):
     return t.float().cpu().numpy()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (105, 200, 128), (1, 128, 64), (577, 130, 320)])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 21, 23, 25])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (105, 200, 128), (1, 128, 64), (577, 130, 320), (200, 136, 64), (384, 256, 1024)])
 def test_gemm_integer_exact(gpu_ctx, cfg, M, N, K):
     """Small-integer operands: every product and partial sum is exact in f32 -> result must be bit-exact."""
     rng = np.random.default_rng(M * 7 + N * 3 + K + cfg)
