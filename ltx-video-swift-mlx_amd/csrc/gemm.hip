@@ -14,6 +14,8 @@
 //   * two LDS stages, one barrier per K-tile (prefetch tile t+1 while the MFMAs of tile t run).
 //   * epilogue through a per-wave LDS transpose so global stores are 16 B/lane, row-contiguous.
 //   * workgroup ids are remapped so that each XCD's L2 sees a contiguous chunk of the tile grid.
+#include <type_traits>
+
 #include "gemm.h"
 #include "runtime.h"
 
@@ -418,7 +420,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
                                                             __builtin_bit_cast(bf16x8_t, fb[0]), acc[0][0], 0, 0, 0);
     };
     auto mfma_rest = [&](const s16x8(&fa)[MI], const s16x8(&fb)[NI]) {
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -426,7 +427,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
                 if (i + j > 0)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
                                                                         __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
     };
 
     // prologue: fill PD ring slots, wait for tile 0, fetch its first fragments
@@ -436,32 +436,57 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     if (nk >= PD) wait_vmcnt_barrier<(PD - 1) * LPT>(); else wait_vmcnt_barrier<0>();
     load_frags(0, foff0, fa0, fb0);
 
-    int slot = 0;  // ring slot of tile t
-    for (int kt = 0; kt < nk; ++kt) {
+    // One K-tile. STEADY iterations are branch-free so that each half is ONE scheduling region in which the LDS
+    // fragment reads and the LDS-DMA issues are interleaved one-for-one with MFMAs (sched_group_barrier): their issue
+    // cost then hides under the previous MFMA's execution instead of serialising in front of the MFMA cluster
+    // (ablation on MI355X: MFMA 98 us, LDS reads+barriers 74 us, DMA issue 57 us were ADDING UP to 207 us).
+    int slot = 0;  // ring slot of tile kt
+    auto ktile = [&](int kt, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
         int nslot = slot + 1;
         nslot = nslot == NSTAGE ? 0 : nslot;
-        int pslot = slot - 1;  // slot of tile t-1 == slot of tile t+PD
+        int pslot = slot - 1;  // slot of tile kt-1 == slot of tile kt+PD
         pslot = pslot < 0 ? NSTAGE - 1 : pslot;
-
-        // first half: the only LDS reads outstanding at the first MFMA are set A's (issued half an iteration ago)
+        // ---- first half: the only LDS reads outstanding at the first MFMA are set A's (issued half a tile ago)
         mfma_first(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         load_frags(slot, foff1, fa1, fb1);
         mfma_rest(fa0, fb0);
-        // tile t+1 must have landed for every wave; tiles t+2 .. t+PD-1 may stay in flight
-        if (kt + PD < nk + 0 && PD >= 2) {
-            // steady state: tiles up to t+PD-1 were issued -> PD-2 newer tiles outstanding after tile t+1
-            wait_vmcnt_barrier<(PD >= 2 ? (PD - 2) * LPT : 0)>();
-        } else {
-            wait_vmcnt_barrier<0>();
+#pragma unroll
+        for (int q = 0; q < MI + NI; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one ds_read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
         }
-        if (kt + PD < nk) stage(pslot, kt + PD);
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - 1 - (MI + NI), 0);
+        // ---- tile kt+1 must have landed for every wave; tiles kt+2 .. kt+PD-1 may stay in flight
+        if constexpr (STEADY) wait_vmcnt_barrier<(PD - 2) * LPT>(); else wait_vmcnt_barrier<0>();
+        // ---- second half
         mfma_first(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) load_frags(nslot, foff0, fa0, fb0);
-        mfma_rest(fa1, fb1);
+        if constexpr (STEADY) {
+            stage(pslot, kt + PD);
+            load_frags(nslot, foff0, fa0, fb0);
+            mfma_rest(fa1, fb1);
+#pragma unroll
+            for (int q = 0; q < LPT; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);  // one LDS-DMA (VMEM read)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            }
+#pragma unroll
+            for (int q = 0; q < MI + NI; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - 1 - (MI + NI) - LPT, 1);
+        } else {
+            if (kt + 1 < nk) load_frags(nslot, foff0, fa0, fb0);
+            mfma_rest(fa1, fb1);
+        }
         slot = nslot;
-    }
+    };
+    int kt = 0;
+    for (; kt < nk - PD; ++kt) ktile(kt, std::true_type{});
+    for (; kt < nk; ++kt) ktile(kt, std::false_type{});
     __syncthreads();
     gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem);
 }
