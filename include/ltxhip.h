@@ -113,11 +113,19 @@ int ltx_map_lora_key(const char* lora_key, char* out, int cap);
  * ---------------------------------------------------------------------------------------------------------- */
 /* Replaces LTXTransformer(config:) + LTXWeightLoader.loadTransformerWeights/applyTransformerWeights
  * (LTXPipeline.swift:293-314, ModelDownloader.swift:605-639,972-1019). cfg NULL = reference defaults.
- * quant_bits: 16 (bf16). */
+ * quant_bits: 16 (bf16), 8 (qint8) or 4 (int4) = LTXQuantizationConfig.transformer (LTXQuantizationConfig.swift:19-62):
+ * after loading, every Linear weight is affine-quantised per 64-wide group along `in` (LTXPipeline.swift:323-333) and
+ * kept as its de-quantised bf16 value (HBM capacity is not the constraint here; the MFMA path stays bf16). */
 int ltx_dit_load(ltx_ctx* ctx, const char* safetensors_path, const ltx_transformer_config* cfg, int quant_bits,
                  int group_size);
 /* Random-init weights of the given architecture, generated on device (bench / property tests). */
 int ltx_dit_init_synthetic(ltx_ctx* ctx, const ltx_transformer_config* cfg, uint64_t seed);
+/* quantize(model:groupSize:bits:) applied to an already loaded / synthetic model (LTXPipeline.swift:329). */
+int ltx_dit_quantize(ltx_ctx* ctx, int bits, int group_size);
+/* Replaces LTXPipeline.fuseLoRA(from:scale:) -> Module.fuseLoRA (LTXPipeline.swift:3134-3153, LoRAAdapter.swift:64-166):
+ * W' = W + cast(scale * (alpha/rank | 1) * (up @ down)) for every LoRA layer whose mapped key (ltx_map_lora_key) names a
+ * Linear weight; on a quantised model dequant -> merge -> requant. *n_fused = number of fused layers. */
+int ltx_dit_fuse_lora(ltx_ctx* ctx, const char* lora_path, float scale, int* n_fused);
 /* `transformer = nil` (LTXPipeline.swift:989-999) */
 int ltx_dit_unload(ltx_ctx* ctx);
 /* Replaces transformer(latent:context:timesteps:contextMask:latentShape:) (LTXTransformer.swift:235).

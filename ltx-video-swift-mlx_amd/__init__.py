@@ -168,6 +168,15 @@ class Context:
     def dit_init_synthetic(self, cfg=None, seed=1234):
         self._ck(lib.ltx_dit_init_synthetic(self._h, C.byref(cfg) if cfg is not None else None, seed))
 
+    def dit_quantize(self, bits, group_size=64):
+        self._ck(lib.ltx_dit_quantize(self._h, bits, group_size))
+
+    def fuse_lora(self, path, scale=1.0):
+        """``LTXPipeline.fuseLoRA(from:scale:)`` -> number of fused layers."""
+        n = C.c_int()
+        self._ck(lib.ltx_dit_fuse_lora(self._h, str(path).encode(), scale, C.byref(n)))
+        return n.value
+
     def dit_unload(self):
         self._ck(lib.ltx_dit_unload(self._h))
 

@@ -82,6 +82,8 @@ SIGNATURES = {
     "ltx_dit_load": (_i, [_vp, C.c_char_p, C.POINTER(TransformerConfig), _i, _i]),
     "ltx_dit_init_synthetic": (_i, [_vp, C.POINTER(TransformerConfig), _u64]),
     "ltx_dit_unload": (_i, [_vp]),
+    "ltx_dit_quantize": (_i, [_vp, _i, _i]),
+    "ltx_dit_fuse_lora": (_i, [_vp, C.c_char_p, _f, _ip]),
     "ltx_dit_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ltx_dit_forward_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _vp]),
     "ltx_dit_set_cross_attn_scale": (_i, [_vp, _f, _i, _i]),

@@ -231,7 +231,9 @@ int ltx_dit_load(ltx_ctx* ctx, const char* path, const ltx_transformer_config* c
     if (!ctx || !path) return LTX_ERR_INVALID_CONFIGURATION;
     (void)group_size;
     return guarded(ctx, [&] {
-        LTX_REQUIRE(quant_bits == 16 || quant_bits == 0, "transformer quantization %d bits is not available in this build (bf16 only)", quant_bits);
+        LTX_REQUIRE(quant_bits == 16 || quant_bits == 0 || quant_bits == 8 || quant_bits == 4,
+                    "transformer quantization must be bf16 (16), qint8 (8) or int4 (4); got %d bits", quant_bits);
+        LTX_REQUIRE(quant_bits == 16 || quant_bits == 0 || group_size == 64, "quantization group size must be 64, got %d", group_size);
         if (ctx->dit) {
             dit_destroy(ctx->dit);
             ctx->dit = nullptr;
@@ -239,6 +241,7 @@ int ltx_dit_load(ltx_ctx* ctx, const char* path, const ltx_transformer_config* c
         DiTModel* m = dit_create(to_cfg(cfg));
         try {
             dit_load_safetensors(ctx, m, path);
+            if (quant_bits == 8 || quant_bits == 4) dit_quantize(ctx, m, quant_bits, 64);
         } catch (...) {
             dit_destroy(m);
             throw;
@@ -262,6 +265,20 @@ int ltx_dit_init_synthetic(ltx_ctx* ctx, const ltx_transformer_config* cfg, uint
             throw;
         }
         ctx->dit = m;
+    });
+}
+
+int ltx_dit_quantize(ltx_ctx* ctx, int bits, int group_size) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { dit_quantize(ctx, need_dit(ctx), bits, group_size); });
+}
+
+int ltx_dit_fuse_lora(ltx_ctx* ctx, const char* path, float scale, int* n_fused) {
+    if (!ctx || !path) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        if (!ctx->dit) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model component not loaded: Transformer not loaded");
+        const int n = dit_fuse_lora(ctx, ctx->dit, path, scale);
+        if (n_fused) *n_fused = n;
     });
 }
 

@@ -50,6 +50,7 @@ struct DiTModel {
     std::vector<DiTBlock> blocks;
     std::map<std::string, ParamSlot> slots;  // module key -> destination
     size_t weight_bytes = 0;
+    int quant_bits = 16;  // 16 (bf16), 8 or 4 after dit_quantize
 
     // ---- caches ----
     DevBuf rope_cos, rope_sin;  // [T][D/2] f32
@@ -94,3 +95,11 @@ struct DiTForwardArgs {
     float* velocity = nullptr;        // device [B][T][out_channels] f32
 };
 void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a);
+
+// R22: fuse a LoRA file into the resident weights: W' = W + cast(scale * (alpha/rank | 1) * (up @ down))
+// (LoRALoader.swift:63-111,162-178; LoRAAdapter.swift:64-166). Returns the number of fused layers.
+int dit_fuse_lora(ltx_ctx* ctx, DiTModel* m, const std::string& path, float scale);
+// R21: on-the-fly affine quantisation of every Linear weight, group size 64 along `in`, 8 or 4 bits
+// (LTXQuantizationConfig.swift:19-62, LTXPipeline.swift:323-333). Weights are replaced by their de-quantised
+// values (HBM capacity is not the constraint on MI355X; the MFMA path stays bf16).
+void dit_quantize(ltx_ctx* ctx, DiTModel* m, int bits, int group);

@@ -795,3 +795,67 @@ def vae_file_keys(w):
                     break
         out["decoder." + fk] = v
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R22: LoRA fusion (LoRALoader.swift:63-111,162-178; LoRAAdapter.swift:64-166)
+# ---------------------------------------------------------------------------------------------------------------
+def lora_fuse(w, lora, scale=1.0):
+    """`lora` maps file keys (e.g. 'diffusion_model.transformer_blocks.0.attn1.to_q.lora_down.weight') to arrays.
+    Returns (new weight dict, number of fused layers). Arithmetic in bf16 as MLX does for bf16 LoRA files."""
+    out = dict(w)
+    fused = 0
+    for key, down in lora.items():
+        if "lora_down" in key:
+            up_key = key.replace("lora_down", "lora_up")
+            base = key.replace(".lora_down.weight", "").replace(".lora_down", "")
+        elif "lora_A" in key:
+            up_key = key.replace("lora_A", "lora_B")
+            base = key.replace(".lora_A.weight", "").replace(".lora_A", "")
+        else:
+            continue
+        if up_key not in lora:
+            continue
+        up = lora[up_key]
+        rank = down.shape[0]
+        eff = F32(scale)
+        if base + ".alpha" in lora:
+            eff = F32(scale) * (F32(lora[base + ".alpha"]) / F32(rank))
+        mk = map_lora_key(base)
+        if mk not in out:
+            continue
+        delta = bf16_round(bf16_round(up).astype(F32) @ bf16_round(down).astype(F32))  # bf16 matmul, f32 accumulate
+        delta = bf16_round(delta * eff)
+        out[mk] = bf16_round(out[mk].astype(F32) + delta)
+        fused += 1
+    return out, fused
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R21: affine group quantisation of every Linear (LTXQuantizationConfig.swift:19-62; MLXNN.quantize, group 64).
+# The rounding rule is MLX's (third party, unverifiable here); this is the documented affine min/max rule.
+# ---------------------------------------------------------------------------------------------------------------
+def fake_quant(wm, bits, group=64):
+    wm = wm.astype(F32)
+    o, i = wm.shape
+    g = wm.reshape(-1, group)
+    n_bins = F32((1 << bits) - 1)
+    w_max, w_min = g.max(1, keepdims=True), g.min(1, keepdims=True)
+    mask = np.abs(w_min) > np.abs(w_max)
+    scale = np.maximum((w_max - w_min) / n_bins, F32(1e-7)).astype(F32)
+    scale = np.where(mask, scale, -scale)
+    edge = np.where(mask, w_min, w_max)
+    q0 = np.rint(edge / scale)
+    scale = np.where(q0 != 0, edge / np.where(q0 != 0, q0, 1), scale).astype(F32)
+    bias = np.where(q0 == 0, F32(0), edge).astype(F32)
+    scale, bias = bf16_round(scale), bf16_round(bias)
+    q = np.clip(np.rint((g - bias) / scale), 0, n_bins)
+    return (q * scale + bias).astype(F32).reshape(o, i)
+
+
+def quantize_dit_weights(w, bits, group=64):
+    out = dict(w)
+    for k, v in w.items():
+        if k.endswith(".weight") and v.ndim == 2:  # every Linear (norm weights are vectors, tables are not '.weight')
+            out[k] = fake_quant(v, bits, group)
+    return out

@@ -1,0 +1,124 @@
+"""R21 (qint8/int4 on-the-fly quantisation) and R22 (LoRA fusion) through the C ABI vs the oracle."""
+import numpy as np
+import pytest
+
+from test_dit_gpu import rel_l2, small_cfg, write_dit_file
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ltx, oracle, tmp_path, seed=31):
+    cfg, ocfg = small_cfg(ltx, oracle, heads=2, layers=2, caption=128)
+    w = oracle.synth_dit_weights(ocfg, seed=seed)
+    path = tmp_path / "dit.safetensors"
+    write_dit_file(oracle, w, path)
+    rng = np.random.default_rng(seed)
+    F, H, W, S = 2, 3, 4, 19
+    latent = oracle.bf16_round(rng.standard_normal((1, F * H * W, 128)).astype(np.float32))
+    context = oracle.bf16_round(rng.standard_normal((1, S, 128)).astype(np.float32))
+    ts = np.array([0.8], np.float32)
+    return cfg, ocfg, w, path, (latent, context, ts, F, H, W)
+
+
+def _fwd(ltx, ctx, inp):
+    latent, context, ts, F, H, W = inp
+    return ctx.dit_forward(ltx.f32_to_bf16_bits(latent), ltx.f32_to_bf16_bits(context), ts, None, F, H, W)
+
+
+def make_lora(oracle, ocfg, rank=16, seed=9):
+    """ComfyUI-style file keys; mixes lora_down/up with lora_A/B naming and alpha / no-alpha layers."""
+    rng = np.random.default_rng(seed)
+    D = ocfg.dim
+    lora = {}
+    layers = []
+    for i in range(ocfg.num_layers):
+        p = f"diffusion_model.transformer_blocks.{i}."
+        layers += [(p + "attn1.to_q", D, D), (p + "attn1.to_k", D, D), (p + "attn1.to_v", D, D), (p + "attn1.to_out.0", D, D),
+                   (p + "attn2.to_q", D, D), (p + "attn2.to_out.0", D, D),
+                   (p + "ff.net.0.proj", 4 * D, D), (p + "ff.net.2", D, 4 * D)]
+    for n, (base, out, inn) in enumerate(layers):
+        down = oracle.bf16_round((rng.standard_normal((rank, inn)) / np.sqrt(inn)).astype(np.float32))
+        up = oracle.bf16_round((rng.standard_normal((out, rank)) * 0.05).astype(np.float32))
+        if n % 3 == 0:
+            lora[base + ".lora_A.weight"], lora[base + ".lora_B.weight"] = down, up
+        else:
+            lora[base + ".lora_down.weight"], lora[base + ".lora_up.weight"] = down, up
+        if n % 2 == 0:
+            lora[base + ".alpha"] = np.array(8.0, np.float32)
+    lora["diffusion_model.not_a_layer.lora_down.weight"] = np.zeros((rank, 64), np.float32)
+    lora["diffusion_model.not_a_layer.lora_up.weight"] = np.zeros((64, rank), np.float32)
+    return lora, len(layers)
+
+
+def test_lora_fuse_parity(ltx, oracle, tmp_path):
+    from safetensors.numpy import save_file
+
+    cfg, ocfg, w, path, inp = _setup(ltx, oracle, tmp_path)
+    lora, n_layers = make_lora(oracle, ocfg)
+    lpath = tmp_path / "lora.safetensors"
+    save_file({k: np.ascontiguousarray(v, dtype=np.float32) for k, v in lora.items()}, str(lpath))
+    ctx = ltx.Context(0)
+    ctx.dit_load(path, cfg)
+    base = _fwd(ltx, ctx, inp)
+    n = ctx.fuse_lora(lpath, scale=0.8)
+    assert n == n_layers  # the unmapped layer is skipped, not an error (LoRAAdapter.swift:136-139)
+    got = _fwd(ltx, ctx, inp)
+    wf, nf = oracle.lora_fuse(w, lora, scale=0.8)
+    assert nf == n_layers
+    ref = oracle.dit_forward(wf, ocfg, *inp[:3], None, *inp[3:])
+    ref0 = oracle.dit_forward(w, ocfg, *inp[:3], None, *inp[3:])
+    assert rel_l2(got, ref) <= 2e-2
+    assert rel_l2(base, ref0) <= 2e-2
+    assert rel_l2(ref, ref0) > 5e-2, "LoRA too weak to prove anything"
+    with pytest.raises(ltx.LTXError) as e:
+        ctx.fuse_lora(tmp_path / "missing.safetensors")
+    assert e.value.case == "fileNotFound"
+    bad = {"diffusion_model.transformer_blocks.0.attn1.to_q.lora_down.weight": np.zeros((16, 100), np.float32),
+           "diffusion_model.transformer_blocks.0.attn1.to_q.lora_up.weight": np.zeros((ocfg.dim, 16), np.float32)}
+    save_file(bad, str(tmp_path / "bad.safetensors"))
+    with pytest.raises(ltx.LTXError) as e:
+        ctx.fuse_lora(tmp_path / "bad.safetensors")
+    assert e.value.case == "invalidLoRA"
+    ctx.close()
+
+
+@pytest.mark.parametrize("bits,tol", [(8, 3e-2), (4, 8e-2)])
+def test_quantized_forward_parity(ltx, oracle, tmp_path, bits, tol):
+    cfg, ocfg, w, path, inp = _setup(ltx, oracle, tmp_path, seed=40 + bits)
+    ctx = ltx.Context(0)
+    ctx.dit_load(path, cfg, quant_bits=bits, group_size=64)
+    got = _fwd(ltx, ctx, inp)
+    wq = oracle.quantize_dit_weights(w, bits)
+    ref = oracle.dit_forward(wq, ocfg, *inp[:3], None, *inp[3:])
+    ref16 = oracle.dit_forward(w, ocfg, *inp[:3], None, *inp[3:])
+    assert rel_l2(got, ref) <= tol, rel_l2(got, ref)
+    # the quantised model is closer to the quantised oracle than to the bf16 one (int4: clearly so)
+    if bits == 4:
+        assert rel_l2(got, ref) < rel_l2(got, ref16)
+    with pytest.raises(ltx.LTXError) as e:
+        ctx.dit_load(path, cfg, quant_bits=3)
+    assert e.value.case == "invalidConfiguration"
+    ctx.close()
+
+
+def test_lora_on_quantized_model(ltx, oracle, tmp_path):
+    """dequant -> merge -> requant (LoRAAdapter.swift:104-131)."""
+    from safetensors.numpy import save_file
+
+    cfg, ocfg, w, path, inp = _setup(ltx, oracle, tmp_path, seed=77)
+    lora, n_layers = make_lora(oracle, ocfg, seed=5)
+    lpath = tmp_path / "lora.safetensors"
+    save_file({k: np.ascontiguousarray(v, dtype=np.float32) for k, v in lora.items()}, str(lpath))
+    ctx = ltx.Context(0)
+    ctx.dit_load(path, cfg, quant_bits=8)
+    assert ctx.fuse_lora(lpath, 1.0) == n_layers
+    got = _fwd(ltx, ctx, inp)
+    wq = oracle.quantize_dit_weights(w, 8)
+    wf, _ = oracle.lora_fuse(wq, lora, 1.0)
+    fused_keys = {oracle.map_lora_key(k.split(".lora_")[0]) for k in lora if ".lora_" in k}
+    for k in fused_keys:
+        if k in wf:
+            wf[k] = oracle.fake_quant(wf[k], 8)
+    ref = oracle.dit_forward(wf, ocfg, *inp[:3], None, *inp[3:])
+    assert rel_l2(got, ref) <= 3e-2
+    ctx.close()
