@@ -184,6 +184,26 @@ int ltx_op_conv3d(ltx_ctx* ctx, const uint16_t* x, int F, int H, int W, int Cin,
                   int Cout, int causal, float* out);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Two-stage generation glue (generateVideoTwoStage, LTXPipeline.swift:2420-2741)
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Replaces loadSpatialUpscaler(from:) (SpatialUpscaler.swift:271-349); mid_channels is detected from the file. */
+int ltx_upscaler_load(ltx_ctx* ctx, const char* safetensors_path);
+int ltx_upscaler_unload(ltx_ctx* ctx);
+/* Replaces upsampleLatents(_:upscaler:latentMean:latentStd:) (SpatialUpscaler.swift:352-379; call site
+ * LTXPipeline.swift:2595-2618): denormalise with the VAE's mean_of_means/std_of_means (the VAE must be loaded),
+ * SpatialUpscaler forward, renormalise. latent [1][128][F][H][W] f32 -> out [1][128][F][2H][2W] f32. HOST pointers. */
+int ltx_upscale_latent(ltx_ctx* ctx, const float* latent, int F, int H, int W, float* out);
+int ltx_upscale_latent_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, float* out);
+/* adainFilterLatent (LatentUtils.swift:201-227): per-channel mean/std of `latent` [1][C][n] matched to those of
+ * `reference` [1][C][n_ref] (population variance, +1e-8 on the std), blended by factor. In place. HOST pointers. */
+int ltx_adain_filter_latent(ltx_ctx* ctx, float* latent, long n_per_channel, const float* reference,
+                            long n_ref_per_channel, int channels, float factor);
+int ltx_adain_filter_latent_dev(ltx_ctx* ctx, float* latent, long n_per_channel, const float* reference,
+                                long n_ref_per_channel, int channels, float factor);
+/* Stage-2 re-noise (LTXPipeline.swift:2644-2647): latent = sigma*noise + (1-sigma)*latent. DEVICE pointers. */
+int ltx_renoise_dev(ltx_ctx* ctx, float* latent, const float* noise, float sigma, long n);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Denoising loop
  * ---------------------------------------------------------------------------------------------------------- */
 /* GenerationProgressCallback (LTXPipeline.swift:50-72): invoked synchronously on the calling thread once per step,

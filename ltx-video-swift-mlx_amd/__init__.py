@@ -249,6 +249,50 @@ class Context:
         Cout = w.shape[0]
         self._ck(lib.ltx_op_conv3d(self._h, _ptr(x), F, H, W, Cin, _ptr(w), _ptr(bias), Cout, int(causal), _ptr(out)))
 
+    # ---- two-stage glue ----
+    def upscaler_load(self, path):
+        self._ck(lib.ltx_upscaler_load(self._h, str(path).encode()))
+
+    def upscaler_unload(self):
+        self._ck(lib.ltx_upscaler_unload(self._h))
+
+    def upscale_latent(self, latent):
+        """``upsampleLatents``: [1,128,F,H,W] f32 -> [1,128,F,2H,2W] f32 (needs the VAE's statistics loaded)."""
+        lat = np.ascontiguousarray(latent, dtype=np.float32)
+        _, Cc, F, H, W = lat.shape
+        out = np.empty((1, Cc, F, 2 * H, 2 * W), dtype=np.float32)
+        self._ck(lib.ltx_upscale_latent(self._h, _ptr(lat), F, H, W, _ptr(out)))
+        return out
+
+    def adain_filter_latent(self, latent, reference, factor=1.0):
+        lat = np.ascontiguousarray(latent, dtype=np.float32).copy()
+        ref = np.ascontiguousarray(reference, dtype=np.float32)
+        Cc = lat.shape[1]
+        self._ck(lib.ltx_adain_filter_latent(self._h, _ptr(lat), lat[0, 0].size, _ptr(ref), ref[0, 0].size, Cc, factor))
+        return lat
+
+    def generate_two_stage(self, noise1, noise2, context_bf16, mask, width, height, num_frames, num_steps=8, vae_tile=0,
+                           decode=True, on_progress=None):
+        """Host-level mirror of ``generateVideoTwoStage`` (LTXPipeline.swift:2420-2741) for the distilled T2V case:
+        stage 1 at W/2 x H/2, latent upscale x2, AdaIN against the stage-1 latent, re-noise with the explicit
+        ``noise2`` at sigma 0.909375, 3-step stage-2 refinement (never CFG), decode. Noise tensors are explicit
+        inputs (the reference draws them from MLX's global RNG)."""
+        validate_generation_config(width, height, num_frames, num_steps, 1.0, two_stage=True)
+        F1, H1, W1 = latent_shape(width // 2, height // 2, num_frames)
+        F2, H2, W2 = latent_shape(width, height, num_frames)
+        sig1 = sigmas(True, num_steps, F1 * H1 * W1)
+        lat = np.ascontiguousarray(noise1, dtype=np.float32) * sig1[0]
+        lat = self.denoise(lat, sig1, context_bf16, mask, F1, H1, W1, on_progress=on_progress)
+        stage1 = lat
+        lat = self.upscale_latent(lat)
+        lat = self.adain_filter_latent(lat, stage1)
+        s2 = stage2_sigmas()
+        lat = (np.float32(s2[0]) * np.asarray(noise2, np.float32) + np.float32(1.0 - s2[0]) * lat).astype(np.float32)
+        lat = self.denoise(lat, s2, context_bf16, mask, F2, H2, W2, on_progress=on_progress)
+        if not decode:
+            return lat
+        return self.vae_decode(lat, tile=vae_tile)
+
     # ---- denoise loop ----
     @staticmethod
     def _options(cfg_scale=1.0, guidance_rescale=0.0, stg_scale=0.0, stg_blocks=(29,), ge_gamma=0.0):

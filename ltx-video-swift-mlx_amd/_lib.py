@@ -96,6 +96,13 @@ SIGNATURES = {
     "ltx_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _l, _ip]),
     "ltx_vae_decode_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _l, _ip]),
     "ltx_op_conv3d": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "ltx_upscaler_load": (_i, [_vp, C.c_char_p]),
+    "ltx_upscaler_unload": (_i, [_vp]),
+    "ltx_upscale_latent": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ltx_upscale_latent_dev": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ltx_adain_filter_latent": (_i, [_vp, _vp, _l, _vp, _l, _i, _f]),
+    "ltx_adain_filter_latent_dev": (_i, [_vp, _vp, _l, _vp, _l, _i, _f]),
+    "ltx_renoise_dev": (_i, [_vp, _vp, _vp, _f, _l]),
     "ltx_denoise": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _vp, _vp, _i, C.POINTER(DenoiseOptions), PROGRESS_CB, _vp]),
     "ltx_denoise_dev": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), _i, _vp, _vp, _i, _i, _u64, C.POINTER(DenoiseOptions), PROGRESS_CB, _vp]),
     "ltx_prof_enable": (_i, [_vp, _i]),

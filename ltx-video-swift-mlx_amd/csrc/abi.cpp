@@ -9,6 +9,7 @@
 #include "gemm.h"
 #include "hostmath.h"
 #include "pipeline.h"
+#include "upscaler.h"
 #include "vae.h"
 #include "runtime.h"
 
@@ -128,6 +129,7 @@ void ltx_ctx_destroy(ltx_ctx* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->dit) dit_destroy(ctx->dit);
     if (ctx->vae) vae_destroy(ctx->vae);
+    if (ctx->upscaler) upscaler_destroy(ctx->upscaler);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -503,6 +505,96 @@ int ltx_op_conv3d(ltx_ctx* ctx, const uint16_t* x, int F, int H, int W, int Cin,
         g.ep.out_f32 = out; g.ep.ld_f32 = Cout;
         launch_gemm_bf16(g, ctx->stream);
     });
+}
+
+// ---- two-stage glue ----
+int ltx_upscaler_load(ltx_ctx* ctx, const char* path) {
+    if (!ctx || !path) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        if (ctx->upscaler) {
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            upscaler_destroy(ctx->upscaler);
+            ctx->upscaler = nullptr;
+        }
+        ctx->upscaler = upscaler_load(ctx, path);
+    });
+}
+
+int ltx_upscaler_unload(ltx_ctx* ctx) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->upscaler) upscaler_destroy(ctx->upscaler);
+        ctx->upscaler = nullptr;
+    });
+}
+
+int ltx_upscale_latent_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, float* out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        if (!ctx->upscaler) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model component not loaded: spatial upscaler");
+        VaeModel* v = need_vae(ctx);  // per-channel statistics come from the VAE (LTXPipeline.swift:2598-2599)
+        upscaler_forward(ctx, ctx->upscaler, latent, F, H, W, v->mean, v->std_, out);
+    });
+}
+
+int ltx_upscale_latent(ltx_ctx* ctx, const float* latent, int F, int H, int W, float* out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        if (!ctx->upscaler) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model component not loaded: spatial upscaler");
+        VaeModel* v = need_vae(ctx);
+        LTX_REQUIRE(latent && out && F >= 1 && H >= 1 && W >= 1, "ltx_upscale_latent: bad arguments");
+        const size_t n_in = (size_t)128 * F * H * W * 4;
+        DevBuf di, dout;
+        di.ensure(n_in);
+        dout.ensure(n_in * 4);
+        HIP_CHECK(hipMemcpyAsync(di.p, latent, n_in, hipMemcpyHostToDevice, ctx->stream));
+        upscaler_forward(ctx, ctx->upscaler, di.as<float>(), F, H, W, v->mean, v->std_, dout.as<float>());
+        HIP_CHECK(hipMemcpyAsync(out, dout.p, n_in * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int ltx_adain_filter_latent_dev(ltx_ctx* ctx, float* latent, long n, const float* reference, long n_ref, int channels,
+                                float factor) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        LTX_REQUIRE(latent && reference && n > 0 && n_ref > 0 && channels > 0, "adain: bad arguments");
+        if (factor <= 0.f) return;
+        ctx->dn_stats.ensure((size_t)channels * 4 * 4 + 64);
+        float* sx = ctx->dn_stats.as<float>();
+        float* sr = sx + 2 * channels;
+        launch_mean_var(latent, n, channels, sx, ctx->stream);
+        launch_mean_var(reference, n_ref, channels, sr, ctx->stream);
+        launch_adain(latent, sx, sr, factor, n, channels, ctx->stream);
+    });
+}
+
+int ltx_adain_filter_latent(ltx_ctx* ctx, float* latent, long n, const float* reference, long n_ref, int channels,
+                            float factor) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        LTX_REQUIRE(latent && reference && n > 0 && n_ref > 0 && channels > 0, "adain: bad arguments");
+        if (factor <= 0.f) return;
+        DevBuf dl, dr;
+        dl.ensure((size_t)n * channels * 4);
+        dr.ensure((size_t)n_ref * channels * 4);
+        HIP_CHECK(hipMemcpyAsync(dl.p, latent, dl.bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(dr.p, reference, dr.bytes, hipMemcpyHostToDevice, ctx->stream));
+        ctx->dn_stats.ensure((size_t)channels * 4 * 4 + 64);
+        float* sx = ctx->dn_stats.as<float>();
+        float* sr = sx + 2 * channels;
+        launch_mean_var(dl.as<float>(), n, channels, sx, ctx->stream);
+        launch_mean_var(dr.as<float>(), n_ref, channels, sr, ctx->stream);
+        launch_adain(dl.as<float>(), sx, sr, factor, n, channels, ctx->stream);
+        HIP_CHECK(hipMemcpyAsync(latent, dl.p, dl.bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int ltx_renoise_dev(ltx_ctx* ctx, float* latent, const float* noise, float sigma, long n) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { launch_lincomb(noise, latent, sigma, 1.0f - sigma, latent, n, ctx->stream); });
 }
 
 // ---- denoise loop ----

@@ -79,3 +79,13 @@ void launch_pixelnorm_silu(const float* x, const float* scale, const float* shif
 // temporal-tile blending is done by launch_blend_frames on the (F,H,W,3) tensors.
 void launch_vae_unpatchify_frames(const float* x, long ldx, float* frames, int F, int H, int W, int apply_clip,
                                   hipStream_t stream);
+
+// ---- latent upscaler helpers (SpatialUpscaler.swift) ----
+// GroupNorm statistics over (all positions, C/G channels) per group, population variance: stats[g] = {mean, rstd}
+// with rstd = 1/sqrt(var + eps) (UpscalerGroupNorm3D, SpatialUpscaler.swift:14-58). x: f32 [P][C].
+void launch_groupnorm_stats(const float* x, long P, int C, int G, float eps, float* stats, hipStream_t stream);
+// y = (x - mean_g) * rstd_g * w[c] + b[c]; if resid: y += resid; y = SiLU(y) when act; writes f32 and/or bf16
+void launch_groupnorm_apply(const float* x, const float* stats, const float* w, const float* b, const float* resid,
+                            int act_silu, float* out_f32, bf16_t* out_bf16, long P, int C, int G, hipStream_t stream);
+// x [P][C] f32 -> out [C][P] f32 with (x - mean[c]) / std[c]  (upsampleLatents renormalisation, SpatialUpscaler.swift:352-379)
+void launch_upscaler_finish(const float* x, const float* mean, const float* std_, float* out, long P, int C, hipStream_t stream);

@@ -440,6 +440,65 @@ __global__ void clip01_kernel(float* __restrict__ x, long n) {
     for (; i < n; i += stride) x[i] = fminf(fmaxf((x[i] + 1.0f) * 0.5f, 0.f), 1.f);
 }
 
+// one workgroup per group: two passes (mean, then variance) over P positions x (C/G) channels
+__global__ __launch_bounds__(1024) void groupnorm_stats_kernel(const float* __restrict__ x, long P, int C, int G, float eps,
+                                                               float* __restrict__ stats) {
+    __shared__ float red[16];
+    const int g = blockIdx.x;
+    const int cpg = C / G;
+    const long n = P * cpg;
+    const float* base = x + (long)g * cpg;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) s += base[(i / cpg) * C + (i % cpg)];
+    const float mean = block_reduce_sum(s, red) / (float)n;
+    float v = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        const float d = base[(i / cpg) * C + (i % cpg)] - mean;
+        v += d * d;
+    }
+    const float var = block_reduce_sum(v, red) / (float)n;
+    if (threadIdx.x == 0) {
+        stats[g * 2 + 0] = mean;
+        stats[g * 2 + 1] = 1.0f / sqrtf(var + eps);
+    }
+}
+__global__ void groupnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                       const float* __restrict__ w, const float* __restrict__ b,
+                                       const float* __restrict__ resid, int act_silu, float* __restrict__ out_f32,
+                                       bf16_t* __restrict__ out_bf16, long n, int C, int G) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int cpg = C / G;
+    for (; i < n; i += stride) {
+        const int c = i % C;
+        const int g = c / cpg;
+        float y = (x[i] - stats[g * 2]) * stats[g * 2 + 1] * w[c] + b[c];
+        if (resid) y += resid[i];
+        if (act_silu) y = silu_f(y);
+        if (out_f32) out_f32[i] = y;
+        if (out_bf16) out_bf16[i] = f32_to_bf16(y);
+    }
+}
+__global__ __launch_bounds__(256) void upscaler_finish_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ std_, float* __restrict__ out,
+                                                              long P, int C) {
+    __shared__ float tile[32][33];
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const long p = p0 + k;
+        const int c = c0 + tx;
+        tile[k][tx] = (p < P && c < C) ? (x[p * C + c] - mean[c]) / std_[c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k;
+        const long p = p0 + tx;
+        if (c < C && p < P) out[(long)c * P + p] = tile[tx][k];
+    }
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
@@ -572,5 +631,22 @@ void launch_vae_unpatchify_frames(const float* x, long ldx, float* frames, int F
                                   hipStream_t stream) {
     const long n = (long)F * H * W * 48;
     hipLaunchKernelGGL(vae_unpatchify_frames_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, ldx, frames, F, H, W, apply_clip);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_groupnorm_stats(const float* x, long P, int C, int G, float eps, float* stats, hipStream_t stream) {
+    LTX_REQUIRE(C % G == 0, "groupnorm: C=%d not divisible by G=%d", C, G);
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(G), dim3(1024), 0, stream, x, P, C, G, eps, stats);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_groupnorm_apply(const float* x, const float* stats, const float* w, const float* b, const float* resid,
+                            int act_silu, float* out_f32, bf16_t* out_bf16, long P, int C, int G, hipStream_t stream) {
+    const long n = P * C;
+    const int grid = cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096;
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(grid), dim3(256), 0, stream, x, stats, w, b, resid, act_silu, out_f32, out_bf16, n, C, G);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_upscaler_finish(const float* x, const float* mean, const float* std_, float* out, long P, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(upscaler_finish_kernel, dim3(cdiv(P, 32), cdiv(C, 32)), dim3(256), 0, stream, x, mean, std_, out, P, C);
     HIP_CHECK(hipGetLastError());
 }

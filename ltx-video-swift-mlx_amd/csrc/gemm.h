@@ -29,8 +29,9 @@ struct GemmEpilogue {
     float gate_scalar = 1.0f;
     const float* resid_src = nullptr;  // defaults to out_f32 (in-place) when null
     long ld_resid = 0;
-    // depth-to-space store (VAE upsampler, VideoDecoder.swift:201-251). When d2s != 0 the output row index is
-    // remapped: see conv3d section in gemm.hip.
+    // depth-to-space store. 1: VAE upsampler (2,2,2) with first-frame drop and tiled D2S residual
+    // (VideoDecoder.swift:201-251); 2: per-frame pixel shuffle (1,2,2) of the latent upscaler
+    // (SpatialUpscaler.swift:116-131). Conv output channels are stored sub-position-major (permuted at load).
     int d2s = 0;
 };
 
@@ -39,7 +40,10 @@ struct GemmEpilogue {
 struct Conv3dGeom {
     int F = 0, H = 0, W = 0, C = 0;
     int causal = 0;
-    int pad_mode = 0;  // 0 reflect, 1 zeros(not supported by gather: clamps to a zero row), 2 replicate
+    int pad_mode = 0;  // 0: reflect H/W + replicate T (VAE Conv3dFull); 1: zeros in every dim (MLXNN.Conv3d/Conv2d
+                       // padding=1, SpatialUpscaler.swift:78-92,139-145): out-of-range taps read the all-zero row that
+                       // the caller keeps at position index F*H*W of the input tensor; 2: replicate H/W/T
+    int kt = 3;        // temporal taps: 3 (3x3x3) or 1 (per-frame 3x3 conv2d)
 };
 
 struct GemmArgs {

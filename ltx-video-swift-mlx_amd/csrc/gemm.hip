@@ -82,7 +82,19 @@ LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const G
             }
             long orow = gm;  // output row (remapped for depth-to-space)
             int ocol = gn;
-            if (ep.d2s) {
+            if (ep.d2s == 2) {
+                // latent upscaler: per-frame pixel shuffle (1,2,2); channels stored (i,j)-major: n' = sub*Cout + c
+                const int cout = g.N >> 2;
+                const int sub = gn / cout;
+                const int c = gn - sub * cout;
+                const int hw = g.geom.H * g.geom.W;
+                const int f = gm / hw;
+                const int rem = gm - f * hw;
+                const int y = rem / g.geom.W;
+                const int x = rem - y * g.geom.W;
+                orow = ((long)f * (2 * g.geom.H) + (2 * y + (sub >> 1))) * (2 * g.geom.W) + (2 * x + (sub & 1));
+                ocol = c;
+            } else if (ep.d2s) {
                 // VAE upsampler (VideoDecoder.swift:201-251). Conv output channels were permuted at load time to
                 // n' = sub*Cout + c (sub = dt*4+dh*2+dw), so this 4-wide chunk has one `sub` and consecutive c.
                 const int cout = g.N >> 3;
@@ -201,20 +213,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
         if constexpr (CONV) {
             const int tap = kt / cpt;
             const int cc = kt - tap * cpt;
-            const int dt = tap / 9, dy = (tap - dt * 9) / 3, dx = tap - dt * 9 - dy * 3;
+            const int dt = (g.geom.kt == 3) ? tap / 9 : 1;
+            const int t9 = (g.geom.kt == 3) ? tap - dt * 9 : tap;
+            const int dy = t9 / 3, dx = t9 - dy * 3;
 #pragma unroll
             for (int i = 0; i < A_PER_WAVE; ++i) {
                 int fi = g.geom.causal ? (a_pos[i].f + dt - 2) : (a_pos[i].f + dt - 1);
-                fi = clamp_idx(fi, g.geom.F);
-                int yi, xi;
-                if (g.geom.pad_mode == 0) {
-                    yi = reflect_idx(a_pos[i].y + dy - 1, g.geom.H);
-                    xi = reflect_idx(a_pos[i].x + dx - 1, g.geom.W);
+                int yi = a_pos[i].y + dy - 1, xi = a_pos[i].x + dx - 1;
+                long pos;
+                if (g.geom.pad_mode == 1) {
+                    const bool ok = fi >= 0 && fi < g.geom.F && yi >= 0 && yi < g.geom.H && xi >= 0 && xi < g.geom.W;
+                    pos = ok ? ((long)fi * g.geom.H + yi) * g.geom.W + xi : (long)g.geom.F * g.geom.H * g.geom.W;
                 } else {
-                    yi = clamp_idx(a_pos[i].y + dy - 1, g.geom.H);
-                    xi = clamp_idx(a_pos[i].x + dx - 1, g.geom.W);
+                    fi = clamp_idx(fi, g.geom.F);
+                    if (g.geom.pad_mode == 0) {
+                        yi = reflect_idx(yi, g.geom.H);
+                        xi = reflect_idx(xi, g.geom.W);
+                    } else {
+                        yi = clamp_idx(yi, g.geom.H);
+                        xi = clamp_idx(xi, g.geom.W);
+                    }
+                    pos = ((long)fi * g.geom.H + yi) * g.geom.W + xi;
                 }
-                const long pos = ((long)fi * g.geom.H + yi) * g.geom.W + xi;
                 const bf16_t* src = g.A + pos * g.geom.C + cc * BK + a_lch[i] * 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024),
@@ -357,20 +377,28 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         if constexpr (CONV) {
             const int tap = kt / cpt;
             const int cc = kt - tap * cpt;
-            const int dt = tap / 9, dy = (tap - dt * 9) / 3, dx = tap - dt * 9 - dy * 3;
+            const int dt = (g.geom.kt == 3) ? tap / 9 : 1;
+            const int t9 = (g.geom.kt == 3) ? tap - dt * 9 : tap;
+            const int dy = t9 / 3, dx = t9 - dy * 3;
 #pragma unroll
             for (int i = 0; i < A_PER_WAVE; ++i) {
                 int fi = g.geom.causal ? (a_pos[i].f + dt - 2) : (a_pos[i].f + dt - 1);
-                fi = clamp_idx(fi, g.geom.F);
-                int yi, xi;
-                if (g.geom.pad_mode == 0) {
-                    yi = reflect_idx(a_pos[i].y + dy - 1, g.geom.H);
-                    xi = reflect_idx(a_pos[i].x + dx - 1, g.geom.W);
+                int yi = a_pos[i].y + dy - 1, xi = a_pos[i].x + dx - 1;
+                long pos;
+                if (g.geom.pad_mode == 1) {
+                    const bool ok = fi >= 0 && fi < g.geom.F && yi >= 0 && yi < g.geom.H && xi >= 0 && xi < g.geom.W;
+                    pos = ok ? ((long)fi * g.geom.H + yi) * g.geom.W + xi : (long)g.geom.F * g.geom.H * g.geom.W;
                 } else {
-                    yi = clamp_idx(a_pos[i].y + dy - 1, g.geom.H);
-                    xi = clamp_idx(a_pos[i].x + dx - 1, g.geom.W);
+                    fi = clamp_idx(fi, g.geom.F);
+                    if (g.geom.pad_mode == 0) {
+                        yi = reflect_idx(yi, g.geom.H);
+                        xi = reflect_idx(xi, g.geom.W);
+                    } else {
+                        yi = clamp_idx(yi, g.geom.H);
+                        xi = clamp_idx(xi, g.geom.W);
+                    }
+                    pos = ((long)fi * g.geom.H + yi) * g.geom.W + xi;
                 }
-                const long pos = ((long)fi * g.geom.H + yi) * g.geom.W + xi;
                 const bf16_t* src = g.A + pos * g.geom.C + cc * BK + a_lch[i] * 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024),
@@ -568,9 +596,10 @@ void validate(const GemmArgs& a) {
     LTX_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0, "gemm: operands must be 16-B aligned");
     LTX_REQUIRE(a.ldb % 8 == 0, "gemm: ldb=%ld must be a multiple of 8", a.ldb);
     if (a.conv) {
-        LTX_REQUIRE(a.geom.C % BK == 0 && a.K == 27 * a.geom.C, "gemm/conv3d: C=%d K=%d", a.geom.C, a.K);
+        LTX_REQUIRE(a.geom.kt == 1 || a.geom.kt == 3, "gemm/conv3d: kt=%d", a.geom.kt);
+        LTX_REQUIRE(a.geom.C % BK == 0 && a.K == 9 * a.geom.kt * a.geom.C, "gemm/conv3d: C=%d K=%d kt=%d", a.geom.C, a.K, a.geom.kt);
         LTX_REQUIRE(a.M == a.geom.F * a.geom.H * a.geom.W, "gemm/conv3d: M=%d != F*H*W", a.M);
-        LTX_REQUIRE(a.geom.H >= 2 && a.geom.W >= 2, "gemm/conv3d: reflect padding needs H,W >= 2");
+        LTX_REQUIRE(a.geom.pad_mode != 0 || (a.geom.H >= 2 && a.geom.W >= 2), "gemm/conv3d: reflect padding needs H,W >= 2");
     } else {
         LTX_REQUIRE(a.lda % 8 == 0, "gemm: lda=%ld must be a multiple of 8", a.lda);
     }

@@ -859,3 +859,108 @@ def quantize_dit_weights(w, bits, group=64):
         if k.endswith(".weight") and v.ndim == 2:  # every Linear (norm weights are vectors, tables are not '.weight')
             out[k] = fake_quant(v, bits, group)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R23: latent spatial upscaler + two-stage glue (SpatialUpscaler.swift:14-258,352-379; LTXPipeline.swift:2588-2647)
+# ---------------------------------------------------------------------------------------------------------------
+def conv_nd_zero(x, weight, bias):
+    """MLXNN.Conv3d/Conv2d with padding=1 (zeros), stride 1. x [B,C,F,H,W]; weight (O,I,3,3,3) or (O,I,3,3) (per frame)."""
+    b, c, t, h, w = x.shape
+    o = weight.shape[0]
+    if weight.ndim == 4:
+        weight = weight[:, :, None]  # kT = 1
+        pt = 0
+    else:
+        pt = 1
+    xp = np.pad(x.astype(F32), ((0, 0), (0, 0), (pt, pt), (1, 1), (1, 1)))
+    out = np.zeros((b, o, t, h, w), F32)
+    wf = weight.astype(F32)
+    for kt in range(weight.shape[2]):
+        for kh in range(3):
+            for kw in range(3):
+                patch = xp[:, :, kt:kt + t, kh:kh + h, kw:kw + w].reshape(b, c, -1)
+                out += np.einsum("oc,bcn->bon", wf[:, :, kt, kh, kw], patch, optimize=True).reshape(b, o, t, h, w)
+    return out + bias.astype(F32).reshape(1, -1, 1, 1, 1)
+
+
+def group_norm3d(x, weight, bias, groups=32, eps=1e-5):
+    """UpscalerGroupNorm3D (SpatialUpscaler.swift:14-58): stats over (F,H,W, C/G), population variance. x [B,C,F,H,W]."""
+    b, c = x.shape[:2]
+    g = x.astype(np.float64).reshape(b, groups, -1)
+    mu = g.mean(-1, keepdims=True)
+    var = ((g - mu) ** 2).mean(-1, keepdims=True)
+    y = ((g - mu) / np.sqrt(var + eps)).reshape(x.shape)
+    return (y * weight.astype(np.float64).reshape(1, -1, 1, 1, 1) + bias.astype(np.float64).reshape(1, -1, 1, 1, 1)).astype(F32)
+
+
+def upscaler_param_shapes(mid=1024, in_ch=128):
+    s = {"initial_conv.weight": (mid, in_ch, 3, 3, 3), "initial_conv.bias": (mid,),
+         "initial_norm.weight": (mid,), "initial_norm.bias": (mid,),
+         "upsampler.conv.weight": (4 * mid, mid, 3, 3), "upsampler.conv.bias": (4 * mid,),
+         "final_conv.weight": (in_ch, mid, 3, 3, 3), "final_conv.bias": (in_ch,)}
+    for stage in ("res_blocks", "post_upsample_res_blocks"):
+        for i in range(4):
+            for cv, nm in (("conv1", "norm1"), ("conv2", "norm2")):
+                s[f"{stage}.{i}.{cv}.weight"] = (mid, mid, 3, 3, 3)
+                s[f"{stage}.{i}.{cv}.bias"] = (mid,)
+                s[f"{stage}.{i}.{nm}.weight"] = (mid,)
+                s[f"{stage}.{i}.{nm}.bias"] = (mid,)
+    return s
+
+
+def synth_upscaler_weights(mid=128, seed=55):
+    rng = np.random.default_rng(seed)
+    w = {}
+    for k, shp in upscaler_param_shapes(mid).items():
+        if "norm" in k and k.endswith(".weight"):
+            v = 1.0 + 0.1 * rng.standard_normal(shp)
+        elif k.endswith(".bias"):
+            v = 0.05 * rng.standard_normal(shp)
+        else:
+            v = rng.standard_normal(shp) / math.sqrt(np.prod(shp[1:]))
+        w[k] = bf16_round(np.asarray(v, F32))
+    return w
+
+
+def upscaler_forward(w, x):
+    """SpatialUpscaler.callAsFunction (SpatialUpscaler.swift:226-258). x [B,128,F,H,W] -> [B,128,F,2H,2W]."""
+    def res_block(p, h):
+        r = h
+        h = silu(group_norm3d(conv_nd_zero(h, w[p + "conv1.weight"], w[p + "conv1.bias"]), w[p + "norm1.weight"], w[p + "norm1.bias"]))
+        h = group_norm3d(conv_nd_zero(h, w[p + "conv2.weight"], w[p + "conv2.bias"]), w[p + "norm2.weight"], w[p + "norm2.bias"])
+        return silu(h + r)
+
+    h = conv_nd_zero(x, w["initial_conv.weight"], w["initial_conv.bias"])
+    h = silu(group_norm3d(h, w["initial_norm.weight"], w["initial_norm.bias"]))
+    for i in range(4):
+        h = res_block(f"res_blocks.{i}.", h)
+    h = conv_nd_zero(h, w["upsampler.conv.weight"], w["upsampler.conv.bias"])  # [B,4C,F,H,W]
+    b, c4, f, hh, ww = h.shape
+    c = c4 // 4
+    # pixelShuffle2DNHWC: channel = c*4 + i*2 + j -> (2h+i, 2w+j) (SpatialUpscaler.swift:116-131)
+    h = h.reshape(b, c, 2, 2, f, hh, ww).transpose(0, 1, 4, 5, 2, 6, 3).reshape(b, c, f, hh * 2, ww * 2)
+    for i in range(4):
+        h = res_block(f"post_upsample_res_blocks.{i}.", h)
+    return conv_nd_zero(h, w["final_conv.weight"], w["final_conv.bias"])
+
+
+def upsample_latents(wu, latent, mean, std):
+    """upsampleLatents (SpatialUpscaler.swift:352-379)."""
+    m5, s5 = mean.astype(F32).reshape(1, -1, 1, 1, 1), std.astype(F32).reshape(1, -1, 1, 1, 1)
+    x = upscaler_forward(wu, latent.astype(F32) * s5 + m5)
+    return ((x - m5) / s5).astype(F32)
+
+
+def two_stage_latent(w, cfg, wu, mean, std, noise1, noise2, context, mask, width, height, num_frames, num_layers=None):
+    """generateVideoTwoStage, distilled T2V (LTXPipeline.swift:2420-2741) up to the final latent."""
+    F1, H1, W1 = latent_shape(width // 2, height // 2, num_frames)
+    F2, H2, W2 = latent_shape(width, height, num_frames)
+    sig1 = sigmas(True, 8, F1 * H1 * W1)
+    lat = denoise(w, cfg, noise1.astype(F32) * sig1[0], sig1, context, mask, F1, H1, W1, num_layers=num_layers)
+    stage1 = lat
+    lat = upsample_latents(wu, lat, mean, std)
+    lat = adain_filter_latent(lat, stage1)
+    s2 = np.array(STAGE_2_DISTILLED_SIGMA_VALUES, F32)
+    lat = (s2[0] * noise2.astype(F32) + (F32(1.0) - s2[0]) * lat).astype(F32)
+    return denoise(w, cfg, lat, s2, context, mask, F2, H2, W2, num_layers=num_layers)
