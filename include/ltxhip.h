@@ -108,6 +108,12 @@ int ltx_map_vae_key(const char* file_key, char* out, int cap);
 /* LoRAKeyMapper.loraKeyToModelKey (LoRALoader.swift:209-243). */
 int ltx_map_lora_key(const char* lora_key, char* out, int cap);
 
+/* safetensors file access for host tools (the CLI reads PrecomputedEmbeddings / noise tensors through these).
+ * ltx_st_info: shape of `key` (up to 8 dims), returns ndim or <0. ltx_st_read: converts to `dtype` (0 f32, 1 bf16 bits,
+ * 2 int32) into out (capacity in elements), returns the element count or <0. */
+int ltx_st_info(const char* path, const char* key, long* shape8);
+long ltx_st_read(const char* path, const char* key, int dtype, void* out, long cap);
+
 /* ------------------------------------------------------------------------------------------------------------
  * DiT (LTXTransformer)
  * ---------------------------------------------------------------------------------------------------------- */

@@ -79,6 +79,8 @@ SIGNATURES = {
     "ltx_map_transformer_key": (_i, [C.c_char_p, C.c_char_p, _i]),
     "ltx_map_vae_key": (_i, [C.c_char_p, C.c_char_p, _i]),
     "ltx_map_lora_key": (_i, [C.c_char_p, C.c_char_p, _i]),
+    "ltx_st_info": (_i, [C.c_char_p, C.c_char_p, C.POINTER(C.c_long)]),
+    "ltx_st_read": (_l, [C.c_char_p, C.c_char_p, _i, _vp, _l]),
     "ltx_dit_load": (_i, [_vp, C.c_char_p, C.POINTER(TransformerConfig), _i, _i]),
     "ltx_dit_init_synthetic": (_i, [_vp, C.POINTER(TransformerConfig), _u64]),
     "ltx_dit_unload": (_i, [_vp]),

@@ -228,6 +228,52 @@ int ltx_map_lora_key(const char* lora_key, char* out, int cap) {
     return copy_str(mk, out, cap);
 }
 
+int ltx_st_info(const char* path, const char* key, long* shape8) {
+    if (!path || !key) return -LTX_ERR_INVALID_CONFIGURATION;
+    int nd = -1;
+    const int rc = guarded(nullptr, [&] {
+        SafeTensors st;
+        st.open(path);
+        auto it = st.tensors.find(key);
+        if (it == st.tensors.end()) LTX_THROW(LTXS_WEIGHT_LOADING_FAILED, "Failed to load weights: no tensor '%s' in %s", key, path);
+        nd = (int)it->second.shape.size();
+        for (int i = 0; i < nd && i < 8; ++i)
+            if (shape8) shape8[i] = it->second.shape[i];
+    });
+    return rc == 0 ? nd : -rc;
+}
+
+long ltx_st_read(const char* path, const char* key, int dtype, void* out, long cap) {
+    if (!path || !key || !out) return -LTX_ERR_INVALID_CONFIGURATION;
+    long n = -1;
+    const int rc = guarded(nullptr, [&] {
+        SafeTensors st;
+        st.open(path);
+        auto it = st.tensors.find(key);
+        if (it == st.tensors.end()) LTX_THROW(LTXS_WEIGHT_LOADING_FAILED, "Failed to load weights: no tensor '%s' in %s", key, path);
+        const StTensor& t = it->second;
+        n = t.numel();
+        LTX_REQUIRE(n <= cap, "ltx_st_read: buffer too small (%ld < %ld)", cap, n);
+        if (dtype == 1) {
+            st_to_bf16(st, t, (bf16_t*)out);
+        } else if (dtype == 0) {
+            st_to_f32(st, t, (float*)out);
+        } else {
+            if (t.dtype == "I32") {
+                memcpy(out, st.ptr(t), (size_t)n * 4);
+            } else if (t.dtype == "I64") {
+                const int64_t* s64 = (const int64_t*)st.ptr(t);
+                for (long i = 0; i < n; ++i) ((int32_t*)out)[i] = (int32_t)s64[i];
+            } else {
+                std::vector<float> f(n);
+                st_to_f32(st, t, f.data());
+                for (long i = 0; i < n; ++i) ((int32_t*)out)[i] = (int32_t)f[i];
+            }
+        }
+    });
+    return rc == 0 ? n : -rc;
+}
+
 // ---- DiT ----
 int ltx_dit_load(ltx_ctx* ctx, const char* path, const ltx_transformer_config* cfg, int quant_bits, int group_size) {
     if (!ctx || !path) return LTX_ERR_INVALID_CONFIGURATION;

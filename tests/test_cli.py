@@ -1,0 +1,73 @@
+"""`ltx-video` CLI (C++ host mirror over the C ABI): flag surface, defaults, dry-run and validation messages of the
+reference CLI (LTXVideoCLI.swift:21-209) on CPU; one end-to-end generate on the GPU."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "ltx-video-swift-mlx_amd", "csrc", "build", "ltx-video")
+
+
+def run(*args):
+    p = subprocess.run([CLI, *args], capture_output=True, text=True, timeout=600)
+    return p.returncode, p.stdout, p.stderr
+
+
+def test_cli_info_and_version(ltx):
+    rc, out, _ = run()
+    assert rc == 0 and "0.1.0" in out  # default subcommand = info
+    rc, out, _ = run("--version")
+    assert rc == 0 and out.strip() == "0.1.0"
+
+
+def test_cli_dry_run_defaults(ltx):
+    rc, out, _ = run("generate", "a beaver building a dam", "--dry-run")
+    assert rc == 0
+    # defaults of the reference CLI: 512x512, 25 frames, distilled, output.mp4 (LTXVideoCLI.swift:29-50)
+    assert "Resolution: 512x512" in out and "Frames: 25" in out and "Model: distilled" in out and "Output: output.mp4" in out
+    assert out.strip().endswith("Validation passed (dry run mode)")
+    rc, out, _ = run("generate", "x", "-w", "768", "-h", "512", "-f", "25", "--two-stage", "--distilled-lora", "--dry-run",
+                     "--transformer-quant", "qint8", "--seed", "42")
+    assert rc == 0 and "Model: dev" in out and "Two-stage pipeline: 384x256 -> upscale 2x -> 768x512" in out
+    assert "Distilled LoRA: will fuse into dev model (8 steps, no CFG)" in out and "Seed: 42" in out
+
+
+@pytest.mark.parametrize("args,msg", [
+    (["-f", "24"], "Frame count must be 8n+1 (e.g., 9, 17, 25, 33, ...). Got 24"),
+    (["-w", "500"], "Width and height must be divisible by 32. Got 500x512"),
+    (["--transformer-quant", "fp8"], "Invalid transformer quantization: fp8. Use: bf16, qint8, or int4"),
+    (["-m", "turbo"], "Invalid model: turbo. Use: distilled or dev"),
+    (["-w", "800", "--two-stage"], "Two-stage requires width and height divisible by 64. Got 800x512"),
+])
+def test_cli_validation_messages(ltx, args, msg):
+    rc, _, err = run("generate", "x", "--dry-run", *args)
+    assert rc != 0 and msg in err
+
+
+@pytest.mark.gpu
+def test_cli_generate_end_to_end(ltx, oracle, tmp_path):
+    """generate with a reduced-depth DiT, statistics-only VAE file and explicit embeddings: plumbing + file contract."""
+    from safetensors.numpy import save_file
+
+    from test_dit_gpu import write_dit_file
+
+    ocfg = oracle.DiTConfig(num_layers=2, num_heads=2, caption_channels=128)
+    write_dit_file(oracle, oracle.synth_dit_weights(ocfg, seed=1), tmp_path / "dit.safetensors")
+    save_file({"latents_mean": np.zeros(128, np.float32), "latents_std": np.ones(128, np.float32)}, str(tmp_path / "vae.safetensors"))
+    rng = np.random.default_rng(0)
+    save_file({"prompt_embeddings": rng.standard_normal((1, 24, 128)).astype(np.float32),
+               "prompt_mask": np.ones((1, 24), np.int32)}, str(tmp_path / "emb.safetensors"))
+    out = tmp_path / "out.raw"
+    rc, so, se = run("generate", "test", "-w", "64", "-h", "64", "-f", "9", "--seed", "7", "-o", str(out),
+                     "--ltx-weights", str(tmp_path / "dit.safetensors"), "--vae-weights", str(tmp_path / "vae.safetensors"),
+                     "--embeddings", str(tmp_path / "emb.safetensors"), "--num-layers", "2", "--num-heads", "2",
+                     "--caption-channels", "128", "--profile")
+    assert rc == 0, se
+    assert "Step 8/8" in so and "Generated 9 frames (64x64)" in so
+    meta = json.loads(open(str(out) + ".json").read())
+    assert meta == {"frames": 9, "height": 64, "width": 64, "channels": 3, "dtype": "float32", "range": [0, 1], "seed": 7}
+    frames = np.fromfile(out, np.float32).reshape(9, 64, 64, 3)
+    assert np.isfinite(frames).all() and frames.min() >= 0 and frames.max() <= 1
