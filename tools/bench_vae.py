@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""VAE decode micro-benchmark at 768x512x25 (latent 4x16x24): python tools/bench_vae.py [--iters 3]"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ltx = importlib.import_module("ltx-video-swift-mlx_amd")
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--F", type=int, default=4)
+ap.add_argument("--H", type=int, default=16)
+ap.add_argument("--W", type=int, default=24)
+a = ap.parse_args()
+ctx = ltx.Context(0)
+ctx.vae_init_synthetic(seed=77)
+lat = torch.empty((1, 128, a.F, a.H, a.W), dtype=torch.float32, device="cuda")
+ctx.op_fill_normal_f32(lat, seed=45)
+nf = 8 * (a.F - 1) + 1
+frames = torch.empty((nf, a.H * 32, a.W * 32, 3), dtype=torch.float32, device="cuda")
+ctx.vae_decode_dev(lat, a.F, a.H, a.W, frames)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.iters):
+    ctx.vae_decode_dev(lat, a.F, a.H, a.W, frames)
+torch.cuda.synchronize()
+print(f"vae decode {1e3 * (time.perf_counter() - t0) / a.iters:.3f} ms")
+ctx.close()
