@@ -53,6 +53,89 @@ LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const G
     float* scr = (float*)(smem + wave * (16 * WN * 4));
     constexpr int LPR = WN / 4;    // lanes per output row
     const GemmEpilogue& ep = g.ep;
+    if (!ep.d2s && n0 + BN <= g.N) {
+        // Interior columns (every DiT GEMM): branch-free 16-B accesses, and the residual-stream / gate reads of slab
+        // mi+1 are issued BEFORE slab mi's LDS transpose so that their HBM/MALL latency overlaps it. One workgroup
+        // per CU runs this tail with nothing else resident, so a dependent load -> fma -> store chain per 16-row slab
+        // (the general path below) was costing 12-20 us per gated-residual GEMM (76.8 vs 57.1 us in the DiT block trace).
+        constexpr int NIT = (16 * LPR) / 64;
+        const bool has_res = ep.resid != 0;
+        const int gn_w = n0 + wc * WN;
+        f32x4 bias[NIT], rs[2][NIT], gt[2][NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c4 = ((it * 64 + lane) % LPR) * 4;
+            bias[it] = ep.bias_n ? *(const f32x4*)(ep.bias_n + gn_w + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float* rbase = ep.resid_src ? ep.resid_src : ep.out_f32;
+        const long rld = ep.resid_src ? ep.ld_resid : ep.ld_f32;
+        auto prefetch = [&](auto mi_c, auto buf_c) {
+            constexpr int mi = decltype(mi_c)::value, buf = decltype(buf_c)::value;
+            if (!has_res) return;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int chunk = it * 64 + lane;
+                const int c4 = (chunk % LPR) * 4;
+                int gm = m0 + wr * WM + mi * 16 + chunk / LPR;
+                gm = gm < g.M ? gm : g.M - 1;
+                rs[buf][it] = *(const f32x4*)(rbase + (long)gm * rld + gn_w + c4);
+                if (ep.gate)
+                    gt[buf][it] = *(const f32x4*)(ep.gate + (long)(gm / ep.rows_per_batch) * ep.gate_bstride + gn_w + c4);
+                else
+                    gt[buf][it] = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
+            }
+        };
+        prefetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        static_for<0, MI>([&](auto mi_c) {
+            constexpr int mi = decltype(mi_c)::value;
+            constexpr int buf = mi & 1;
+            if constexpr (mi + 1 < MI) prefetch(std::integral_constant<int, mi + 1>{}, std::integral_constant<int, (mi + 1) & 1>{});
+            static_for<0, NI>([&](auto ni_c) {
+                constexpr int ni = decltype(ni_c)::value;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = acc[mi][ni][r];
+            });
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int chunk = it * 64 + lane;
+                const int row = chunk / LPR;
+                const int c4 = (chunk % LPR) * 4;
+                f32x4 v = *(const f32x4*)(scr + row * WN + c4);
+                const int gm = m0 + wr * WM + mi * 16 + row;
+                const int gmc = gm < g.M ? gm : g.M - 1;
+                v += bias[it];
+                if (ep.bias_m) {
+                    const float bm = ep.bias_m[gmc];
+                    v += f32x4{bm, bm, bm, bm};
+                }
+                if (ep.act == LTX_ACT_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                } else if (ep.act == LTX_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                }
+                if (ep.round_bf16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = rs[buf][it][e] + gt[buf][it][e] * v[e];
+                }
+                if (gm < g.M) {
+                    if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn_w + c4) = v;
+                    if (ep.out_bf16) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(v[0], v[1]);
+                        pk.y = pack_bf16x2(v[2], v[3]);
+                        *(uint2*)(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn_w + c4) = pk;
+                    }
+                }
+            }
+        });
+        return;
+    }
     static_for<0, MI>([&](auto mi_c) {
         constexpr int mi = decltype(mi_c)::value;
         static_for<0, NI>([&](auto ni_c) {
@@ -793,6 +876,201 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v4: phased "ping-pong" kernel for the wide DiT GEMMs (fused q/k, FFN up): BMx256 output tile (BM = 192 or 256),
+// BK = 64, 8 waves as 2(M) x 4(N). The two waves that share a SIMD (wave w and w+4: wave rows 0 and 1) run half a
+// phase apart: while one is inside its MFMA cluster (priority 1) the other issues the LDS fragment reads and LDS-DMA
+// pieces for its next cluster; two workgroup barriers per phase hand the roles over. Per K-tile a wave walks its
+// WMx64 output in four quadrants (a0,b0) (a0,b1) (a1,b1) (a1,b0), so every quadrant re-uses one operand half held
+// in registers and needs 0/4/6-8/10-12 ds_read_b128 for 12-16 MFMAs.
+// LDS: 2 slots (K-tile parity) x [A image BM rows | B image 256 rows] x 128 B, rows ordered [half][wave row/col][..]
+// so that an operand half is a contiguous row range; 16-B chunk c of LDS row r sits at chunk c ^ ((r >> 1) & 7).
+// Staging: one wave-instruction = 8 rows; unit u of an operand = LDS rows [64u, 64u+64) over the 8 waves.
+//   tile t+2 replaces tile t (same slot) one phase after the last read of the rows it overwrites:
+//     BM=256:  P2(t): A u0,u1   P3(t): B u0,u1   P4(t): B u2,u3   P1(t+1): A u2,u3
+//     BM=192:  P2(t): A u0,B u0 P3(t): B u1,u2   P4(t): B u3,A u1 P1(t+1): A u2
+//   (reads: A half 0 + B half 0 in P1, B half 1 in P2, A half 1 in P3; every phase retires its reads with
+//   lgkmcnt(0) BEFORE its first barrier, so the other wave group - which is one barrier behind - stages only rows
+//   whose reads have completed).  One counted wait per K-tile: vmcnt(6) in P4(t+1) leaves the six pieces of tile
+//   t+3 in flight and retires all of tile t+2, which is first read one phase later (P1(t+2)).
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+LTX_DEVFN void wait_lgkm_vmcnt_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+LTX_DEVFN void wait_lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+LTX_DEVFN void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int BM, int BN>
+__global__ __launch_bounds__(512) void gemm_bf16_kernel_v4(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(BN == 256 && (BM == 192 || BM == 256), "v4 tile shapes");
+    constexpr int WGM = 2, WGN = 4;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16, MIH = MI / 2, NIH = NI / 2;
+    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, SLOT = A_BYTES + B_BYTES;
+    constexpr int AU = BM / 64, BU = BN / 64;  // staging units (= LDS-DMA instructions per wave) per K-tile
+    constexpr int HM = BM / 2, HN = BN / 2, QM = WM / 2, QN = WN / 2;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WGN, wc = wave % WGN;
+
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging sources: LDS row -> tile row through the [half][wave row][quarter rows] ordering
+    const int srow = lane >> 3, pch = lane & 7;
+    const bf16_t* a_src[AU];
+    const bf16_t* b_src[BU];
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+        const int lr = 64 * u + 8 * wave + srow;
+        const int h = lr / HM, rem = lr - h * HM, w_ = rem / QM, i = rem - w_ * QM;
+        int gm = m0 + w_ * WM + h * QM + i;
+        gm = gm < g.M ? gm : g.M - 1;
+        a_src[u] = g.A + (long)gm * g.lda + ((pch ^ ((lr >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+        const int lr = 64 * u + 8 * wave + srow;
+        const int h = lr / HN, rem = lr - h * HN, w_ = rem / QN, j = rem - w_ * QN;
+        int gn = n0 + w_ * WN + h * QN + j;
+        gn = gn < g.N ? gn : g.N - 1;
+        b_src[u] = g.B + (long)gn * g.ldb + ((pch ^ ((lr >> 1) & 7)) << 3);
+    }
+    auto stage_a = [&](int slot, int u, int kt) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[u] + (long)kt * BK),
+                                         (__attribute__((address_space(3))) void*)(smem + slot * SLOT + (8 * u + wave) * 1024),
+                                         16, 0, 0);
+    };
+    auto stage_b = [&](int slot, int u, int kt) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[u] + (long)kt * BK),
+                                         (__attribute__((address_space(3))) void*)(smem + slot * SLOT + A_BYTES + (8 * u + wave) * 1024),
+                                         16, 0, 0);
+    };
+    // the four per-phase staging groups of one K-tile, in issue order (see the header)
+    auto stage_g2 = [&](int slot, int kt) {  // issued in P2(t) for tile t+2
+        if constexpr (BM == 256) { stage_a(slot, 0, kt); stage_a(slot, 1, kt); } else { stage_a(slot, 0, kt); stage_b(slot, 0, kt); }
+    };
+    auto stage_g3 = [&](int slot, int kt) {
+        if constexpr (BM == 256) { stage_b(slot, 0, kt); stage_b(slot, 1, kt); } else { stage_b(slot, 1, kt); stage_b(slot, 2, kt); }
+    };
+    auto stage_g4 = [&](int slot, int kt) {
+        if constexpr (BM == 256) { stage_b(slot, 2, kt); stage_b(slot, 3, kt); } else { stage_b(slot, 3, kt); stage_a(slot, 1, kt); }
+    };
+    auto stage_g1 = [&](int slot, int kt) {  // issued in P1(t+1) for tile t+2
+        if constexpr (BM == 256) { stage_a(slot, 2, kt); stage_a(slot, 3, kt); } else { stage_a(slot, 2, kt); }
+    };
+    constexpr int G1 = (BM == 256) ? 2 : 1;  // pieces in group 1; groups 2..4 have two each
+
+    // ---- fragment reads
+    const int frow = lane & 15, fsw = (lane >> 1) & 7;
+    const int fch0 = (((lane >> 4) + 0) ^ fsw) << 4, fch1 = (((lane >> 4) + 4) ^ fsw) << 4;
+    const int a_off = (wr * QM + frow) * ROW_BYTES;            // + h*HM*128 + i*16*128 + chunk
+    const int b_off = A_BYTES + (wc * QN + frow) * ROW_BYTES;  // + h*HN*128 + j*16*128 + chunk
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s16x8 fa[MIH][2], fb0[NIH][2], fb1[NIH][2];
+
+    auto read_a = [&](int slot, int h) {
+        const char* base = smem + slot * SLOT + a_off + h * HM * ROW_BYTES;
+#pragma unroll
+        for (int i = 0; i < MIH; ++i) {
+            fa[i][0] = *(const s16x8*)(base + i * 16 * ROW_BYTES + fch0);
+            fa[i][1] = *(const s16x8*)(base + i * 16 * ROW_BYTES + fch1);
+        }
+    };
+    auto read_b = [&](int slot, int h, s16x8(&fb)[NIH][2]) {
+        const char* base = smem + slot * SLOT + b_off + h * HN * ROW_BYTES;
+#pragma unroll
+        for (int j = 0; j < NIH; ++j) {
+            fb[j][0] = *(const s16x8*)(base + j * 16 * ROW_BYTES + fch0);
+            fb[j][1] = *(const s16x8*)(base + j * 16 * ROW_BYTES + fch1);
+        }
+    };
+    auto cluster = [&](auto hm_tag, auto hn_tag, const s16x8(&fb)[NIH][2]) {
+        constexpr int hm = decltype(hm_tag)::value, hn = decltype(hn_tag)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MIH; ++i)
+#pragma unroll
+                for (int j = 0; j < NIH; ++j)
+                    acc[hm * MIH + i][hn * NIH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, fa[i][ks]), __builtin_bit_cast(bf16x8_t, fb[j][ks]),
+                        acc[hm * MIH + i][hn * NIH + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        raw_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    const int nk = g.K / BK;  // >= 2 (launcher)
+    // prologue: tile 0 complete, tile 1 except its group 1 (issued in P1 of tile 0)
+    stage_g2(0, 0); stage_g3(0, 0); stage_g4(0, 0); stage_g1(0, 0);
+    stage_g2(1, 1); stage_g3(1, 1); stage_g4(1, 1);
+    wait_vmcnt_barrier<6>();
+    if (wr == 1) raw_barrier();  // wave row 1 runs one barrier behind wave row 0 from here on
+
+    // One K-tile = four phases. MODE 0: steady (tile t+2 exists); 1: tile t+1 is the last (stage only its group 1);
+    // 2: last tile (nothing to stage).
+    auto ktile = [&](int t, auto slot_tag, auto mode_tag) {
+        constexpr int S = decltype(slot_tag)::value, MODE = decltype(mode_tag)::value;
+        // P1: (a0, b0)
+        read_b(S, 0, fb0);
+        read_a(S, 0);
+        if constexpr (MODE <= 1) stage_g1(S ^ 1, t + 1);
+        wait_lgkm_barrier();
+        cluster(I0{}, I0{}, fb0);
+        // P2: (a0, b1)
+        read_b(S, 1, fb1);
+        if constexpr (MODE == 0) stage_g2(S, t + 2);
+        wait_lgkm_barrier();
+        cluster(I0{}, I1{}, fb1);
+        // P3: (a1, b1)
+        read_a(S, 1);
+        if constexpr (MODE == 0) stage_g3(S, t + 2);
+        wait_lgkm_barrier();
+        cluster(I1{}, I1{}, fb1);
+        // P4: (a1, b0); retire tile t+1 (read from P1 of the next tile on)
+        if constexpr (MODE == 0) {
+            stage_g4(S, t + 2);
+            wait_lgkm_vmcnt_barrier<6>();
+        } else {
+            wait_lgkm_vmcnt_barrier<0>();
+        }
+        cluster(I1{}, I0{}, fb0);
+    };
+    int t = 0;
+    for (; t + 3 < nk; t += 2) {
+        ktile(t, I0{}, I0{});
+        ktile(t + 1, I1{}, I0{});
+    }
+    // 2 or 3 tiles left, t even
+    if (t + 3 == nk) {
+        ktile(t, I0{}, I0{});
+        ktile(t + 1, I1{}, I1{});
+        ktile(t + 2, I0{}, std::integral_constant<int, 2>{});
+    } else {
+        ktile(t, I0{}, I1{});
+        ktile(t + 1, I1{}, std::integral_constant<int, 2>{});
+    }
+    if (wr == 0) raw_barrier();  // re-align the two wave rows
+    __syncthreads();
+    gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem);
+}
+
 template <int BM, int BN, bool CONV>
 void launch_one(const GemmArgs& a, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
@@ -837,6 +1115,22 @@ void launch_v3(const GemmArgs& a, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
 }
 
+template <int BM, int BN>
+void launch_v4(const GemmArgs& a, hipStream_t stream) {
+    constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
+    static_assert(smem >= 8 * 16 * (BN / 4) * 4, "epilogue scratch must fit in the ring");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_v4<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    LTX_REQUIRE(!a.conv, "gemm v4: dense operands only");
+    LTX_REQUIRE(a.K % BK == 0 && a.K >= 2 * BK, "gemm v4: K=%d must be a multiple of %d and >= %d", a.K, BK, 2 * BK);
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_bf16_kernel_v4<BM, BN>), dim3(tiles), dim3(512), smem, stream, a);
+    HIP_CHECK(hipGetLastError());
+}
+
 void validate(const GemmArgs& a) {
     LTX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     LTX_REQUIRE(a.K % 32 == 0, "gemm: K=%d must be a multiple of 32", a.K);
@@ -856,6 +1150,11 @@ void validate(const GemmArgs& a) {
     if (e.out_f32) LTX_REQUIRE(e.ld_f32 % 4 == 0 && ((uintptr_t)e.out_f32 & 15) == 0, "gemm: f32 output alignment");
     if (e.out_bf16) LTX_REQUIRE(e.ld_bf16 % 4 == 0 && ((uintptr_t)e.out_bf16 & 7) == 0, "gemm: bf16 output alignment");
     if (e.resid && !e.d2s) LTX_REQUIRE(e.out_f32 || e.resid_src, "gemm: residual mode needs an f32 stream");
+    if (!e.d2s) {  // the interior-column epilogue reads these with 16-B accesses
+        LTX_REQUIRE(((uintptr_t)e.bias_n & 15) == 0, "gemm: bias must be 16-B aligned");
+        LTX_REQUIRE(((uintptr_t)e.gate & 15) == 0 && e.gate_bstride % 4 == 0, "gemm: gate must be 16-B aligned (stride %ld)", (long)e.gate_bstride);
+        LTX_REQUIRE(((uintptr_t)e.resid_src & 15) == 0 && (!e.resid_src || e.ld_resid % 4 == 0), "gemm: residual source alignment");
+    }
     if (e.d2s) LTX_REQUIRE(a.conv && a.N % 32 == 0, "gemm: d2s epilogue needs conv mode and N%%32==0");
 }
 
@@ -895,6 +1194,8 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 32: launch_v3<384, 128, 5, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 96x64
             case 33: launch_v3<192, 256, 4, false, 4, 2>(a, stream); break;
             case 34: launch_v3<256, 192, 5, false, 2, 4>(a, stream); break;  // 8 waves, per-wave 128x48
+            case 41: launch_v4<192, 256>(a, stream); break;  // ping-pong, 8 waves (2x4), per-wave 96x64
+            case 42: launch_v4<256, 256>(a, stream); break;  // ping-pong, per-wave 128x64
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
         }
     }

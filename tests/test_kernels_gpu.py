@@ -58,6 +58,25 @@ def test_gemm_v3_odd_ktiles(gpu_ctx, cfg, K):
     assert np.array_equal(as_f32(out), A @ B.T)
 
 
+@pytest.mark.parametrize("cfg", [41, 42])
+@pytest.mark.parametrize("M,N,K,reps", [(192, 256, 128, 1), (256, 256, 192, 1), (100, 60, 320, 1), (500, 700, 256, 2),
+                                        (777, 1000, 448, 2), (1536, 1024, 4096, 6), (1536, 2048, 1024, 6), (3000, 768, 2112, 3)])
+def test_gemm_pingpong_integer_exact(gpu_ctx, cfg, M, N, K, reps):
+    """Phased 8-wave kernel (two wave groups half a phase apart, 2-slot LDS, counted vmcnt): bit-exact on integer
+    data for 2/3/even/odd K-tile counts and ragged edges; the large shapes are repeated with fresh operands to
+    screen the staging schedule for LDS races (a stale or early-read tile shows as a wrong integer)."""
+    for r in range(reps):
+        rng = np.random.default_rng(M + N + K + cfg + 1000 * r)
+        A = rng.integers(-3, 4, (M, K)).astype(np.float32)
+        B = rng.integers(-3, 4, (N, K)).astype(np.float32)
+        out = torch.empty((M, N), device="cuda")
+        gpu_ctx.op_gemm(dev_bf16(A), dev_bf16(B), None, tile_cfg=cfg, out_f32=out)
+        torch.cuda.synchronize()
+        ref = A @ B.T
+        got = as_f32(out)
+        assert np.array_equal(got, ref), f"rep {r}: {np.count_nonzero(got != ref)} wrong, max diff {np.abs(got - ref).max()}"
+
+
 @pytest.mark.parametrize("M,N,K,act", [(1536, 512, 4096, 0), (300, 256, 1024, 1), (128, 4096, 256, 2)])
 def test_gemm_random_vs_f32(gpu_ctx, M, N, K, act):
     rng = np.random.default_rng(11)
