@@ -388,8 +388,8 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             eqk.out_f32 = qk;
             eqk.ld_f32 = 2 * D;
             gemm_linear(xn, D, blk.qk1, (int)rows, eqk, st);
-            launch_qknorm_rope(qk, 2 * D, blk.qn1, m->rope_cos.as<float>(), m->rope_sin.as<float>(), T, q, D, (int)rows, D, eps, st);
-            launch_qknorm_rope(qk + D, 2 * D, blk.kn1, m->rope_cos.as<float>(), m->rope_sin.as<float>(), T, k, D, (int)rows, D, eps, st);
+            launch_qknorm_rope2(qk, blk.qn1, q, qk + D, blk.kn1, k, 2 * D, D, m->rope_cos.as<float>(), m->rope_sin.as<float>(), T,
+                                (int)rows, D, eps, st);
             for (int b = 0; b < B; ++b) gemm_vt(xn + (size_t)b * T * D, D, T, blk.v1, vt + (size_t)b * D * Tpad, Tpad, st);
             AttnArgs at;
             at.Q = q; at.ldq = D; at.q_bstride = (long)T * D;

@@ -18,6 +18,10 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
 // q/k RMSNorm across ALL heads with learnable weight, then split-RoPE per head (LTXAttention.swift:179-189,
 // LTXRoPE.swift:84-149). x: f32 [rows][ldx] (D valid columns), w: f32 [D], cos/sin: f32 [T][D/2] indexed by
 // (row % T) with per-head slices of 64 (nullable -> no RoPE, cross-attention). out: bf16 [rows][ldo].
+// q and k of a fused projection in ONE launch (job 1 optional: x1 == nullptr)
+void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const float* x1, const float* w1, bf16_t* out1,
+                         long ldx, long ldo, const float* cosT, const float* sinT, int T, int rows, int D, float eps,
+                         hipStream_t stream);
 void launch_qknorm_rope(const float* x, long ldx, const float* w, const float* cosT, const float* sinT, int T,
                         bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t stream);
 

@@ -19,7 +19,10 @@ LTX_DEVFN float block_reduce_sum(float v, float* red) {
     return t;
 }
 
-// one workgroup (256 threads) per row
+// one workgroup (256 threads) per row; NV = float4 chunks per thread (D <= NV*1024). The modulation vectors are
+// fetched together with the row, BEFORE the reduction: every workgroup of the launch is resident at once, so the kernel
+// costs one memory latency plus the transfer, and a second dependent load after the barrier doubled it (17 -> ~9 us).
+template <int NV>
 __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__ x, long ldx,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift, long mod_bstride,
@@ -28,28 +31,42 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__
     __shared__ float red[4];
     const int row = blockIdx.x;
     const float* xr = x + (long)row * ldx;
-    f32x4 v[MAXV];
+    const long b = row / rows_per_batch;
+    const float* sc = scale ? scale + b * mod_bstride : nullptr;
+    const float* sh = shift ? shift + b * mod_bstride : nullptr;
+    f32x4 v[NV], s4[NV], h4[NV];
     float s1 = 0.f, s2 = 0.f;
     const int nchunk = D >> 2;
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int c = threadIdx.x + j * 256;
-        if (c < nchunk) {
-            v[j] = *(const f32x4*)(xr + c * 4);
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nchunk) v[j] = *(const f32x4*)(xr + c * 4);
+    }
+    if (sc) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s1 += v[j][e];
-                s2 += v[j][e] * v[j][e];
+        for (int j = 0; j < NV; ++j) {
+            const int c = threadIdx.x + j * 256;
+            if (c < nchunk) {
+                s4[j] = *(const f32x4*)(sc + c * 4);
+                h4[j] = *(const f32x4*)(sh + c * 4);
             }
         }
     }
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s1 += v[j][e];
+            s2 += v[j][e] * v[j][e];
+        }
     float mean = 0.f, rstd;
     if (norm_kind == LTX_NORM_LAYER) {
         mean = block_reduce_sum(s1, red) / (float)D;
         // two-pass variance on the register copy (population variance, as MLXNN.LayerNorm)
         float sv = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int c = threadIdx.x + j * 256;
             if (c < nchunk) {
 #pragma unroll
@@ -65,12 +82,9 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__
         const float ms = block_reduce_sum(s2, red) / (float)D;
         rstd = rsqrtf(ms + eps);
     }
-    const long b = row / rows_per_batch;
-    const float* sc = scale ? scale + b * mod_bstride : nullptr;
-    const float* sh = shift ? shift + b * mod_bstride : nullptr;
     bf16_t* orow = out + (long)row * ldo;
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int c = threadIdx.x + j * 256;
         if (c < nchunk) {
             f32x4 y;
@@ -80,10 +94,8 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__
                 if (round_norm_bf16) y[e] = bf16_to_f32(f32_to_bf16(y[e]));
             }
             if (sc) {
-                const f32x4 s4 = *(const f32x4*)(sc + c * 4);
-                const f32x4 h4 = *(const f32x4*)(sh + c * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = y[e] * (1.0f + s4[e]) + h4[e];
+                for (int e = 0; e < 4; ++e) y[e] = y[e] * (1.0f + s4[j][e]) + h4[j][e];
             }
             uint2 pk;
             pk.x = pack_bf16x2(y[0], y[1]);
@@ -93,59 +105,77 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__
     }
 }
 
-// one workgroup per row; thread handles float4 chunks of the first half `a` of a head and the matching `b` chunk
-__global__ __launch_bounds__(256) void qknorm_rope_kernel(const float* __restrict__ x, long ldx,
-                                                          const float* __restrict__ w,
-                                                          const float* __restrict__ cosT,
-                                                          const float* __restrict__ sinT, int T,
-                                                          bf16_t* __restrict__ out, long ldo, int D, float eps) {
+// one workgroup per row; thread handles float4 chunks of the first half `a` of a head and the matching `b` chunk.
+// blockIdx.y selects the job (q or k of the fused projection): one launch normalises and rotates both. The weight and
+// cos/sin chunks are fetched with the row, before the reduction (same reason as norm_mod_kernel).
+struct QkJob {
+    const float* x;
+    const float* w;
+    bf16_t* out;
+    long ldx, ldo;
+};
+template <int NP>
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(QkJob j0, QkJob j1, const float* __restrict__ cosT,
+                                                          const float* __restrict__ sinT, int T, int D, float eps) {
     __shared__ float red[4];
+    const QkJob job = blockIdx.y ? j1 : j0;
     const int row = blockIdx.x;
-    const float* xr = x + (long)row * ldx;
+    const float* xr = job.x + (long)row * job.ldx;
     // pair chunk p (0 .. D/8-1): head = p / 16, i4 = p % 16 ; a at head*128 + i4*4, b at +64
     const int npair = D >> 3;
-    constexpr int MAXP = MAXV / 2;
-    f32x4 va[MAXP], vb[MAXP];
-    float s2 = 0.f;
+    const int t = row % T;
+    f32x4 va[NP], vb[NP], wa[NP], wb[NP], c4[NP], s4[NP];
 #pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
+    for (int j = 0; j < NP; ++j) {
         const int p = threadIdx.x + j * 256;
+        va[j] = vb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p < npair) {
             const int col = (p >> 4) * 128 + (p & 15) * 4;
             va[j] = *(const f32x4*)(xr + col);
             vb[j] = *(const f32x4*)(xr + col + 64);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s2 += va[j][e] * va[j][e] + vb[j][e] * vb[j][e];
         }
     }
-    const float rstd = rsqrtf(block_reduce_sum(s2, red) / (float)D + eps);
-    const int t = row % T;
-    bf16_t* orow = out + (long)row * ldo;
 #pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
+    for (int j = 0; j < NP; ++j) {
         const int p = threadIdx.x + j * 256;
         if (p < npair) {
             const int col = (p >> 4) * 128 + (p & 15) * 4;
-            const f32x4 wa = *(const f32x4*)(w + col);
-            const f32x4 wb = *(const f32x4*)(w + col + 64);
-            f32x4 a, b;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a[e] = va[j][e] * rstd * wa[e];
-                b[e] = vb[j][e] * rstd * wb[e];
-            }
+            wa[j] = *(const f32x4*)(job.w + col);
+            wb[j] = *(const f32x4*)(job.w + col + 64);
             if (cosT) {
                 // cos/sin rows are [T][D/2]; head h uses columns h*64 .. h*64+63
                 const int fc = (p >> 4) * 64 + (p & 15) * 4;
-                const f32x4 c4 = *(const f32x4*)(cosT + (long)t * (D >> 1) + fc);
-                const f32x4 s4 = *(const f32x4*)(sinT + (long)t * (D >> 1) + fc);
+                c4[j] = *(const f32x4*)(cosT + (long)t * (D >> 1) + fc);
+                s4[j] = *(const f32x4*)(sinT + (long)t * (D >> 1) + fc);
+            }
+        }
+    }
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s2 += va[j][e] * va[j][e] + vb[j][e] * vb[j][e];
+    const float rstd = rsqrtf(block_reduce_sum(s2, red) / (float)D + eps);
+    bf16_t* orow = job.out + (long)row * job.ldo;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int p = threadIdx.x + j * 256;
+        if (p < npair) {
+            const int col = (p >> 4) * 128 + (p & 15) * 4;
+            f32x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = va[j][e] * rstd * wa[j][e];
+                b[e] = vb[j][e] * rstd * wb[j][e];
+            }
+            if (cosT) {
                 // the reference rounds the normed q/k to its storage dtype before the f32 rotation only when that
                 // dtype is bf16 (cross-modal case); in the DiT q,k are f32 here (LTXRoPE.swift:90-92).
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float a0 = a[e], b0 = b[e];
-                    a[e] = a0 * c4[e] - b0 * s4[e];
-                    b[e] = b0 * c4[e] + a0 * s4[e];
+                    a[e] = a0 * c4[j][e] - b0 * s4[j][e];
+                    b[e] = b0 * c4[j][e] + a0 * s4[j][e];
                 }
             }
             uint2 pa, pb;
@@ -508,17 +538,34 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
                      int round_norm_bf16, hipStream_t stream) {
     LTX_REQUIRE(D % 4 == 0 && D <= MAXV * 1024 && ldx % 4 == 0 && ldo % 4 == 0, "norm_mod: D=%d ldx=%ld ldo=%ld", D, ldx, ldo);
     LTX_REQUIRE((scale == nullptr) == (shift == nullptr), "norm_mod: scale/shift must both be set or both null");
-    hipLaunchKernelGGL(norm_mod_kernel, dim3(rows), dim3(256), 0, stream, x, ldx, scale, shift, mod_bstride,
-                       rows_per_batch < 1 ? 1 : rows_per_batch, out, ldo, D, norm_kind, eps, round_norm_bf16);
+    const int rpb = rows_per_batch < 1 ? 1 : rows_per_batch;
+#define LTX_NORM_LAUNCH(NV)                                                                                              \
+    hipLaunchKernelGGL(norm_mod_kernel<NV>, dim3(rows), dim3(256), 0, stream, x, ldx, scale, shift, mod_bstride, rpb, out, \
+                       ldo, D, norm_kind, eps, round_norm_bf16)
+    if (D <= 1024) LTX_NORM_LAUNCH(1);
+    else if (D <= 2048) LTX_NORM_LAUNCH(2);
+    else if (D <= 4096) LTX_NORM_LAUNCH(4);
+    else LTX_NORM_LAUNCH(8);
+#undef LTX_NORM_LAUNCH
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const float* x1, const float* w1, bf16_t* out1,
+                         long ldx, long ldo, const float* cosT, const float* sinT, int T, int rows, int D, float eps,
+                         hipStream_t stream) {
+    LTX_REQUIRE(D % 128 == 0 && D <= MAXV * 1024 && ldx % 4 == 0 && ldo % 4 == 0, "qknorm_rope: D=%d", D);
+    const QkJob j0{x0, w0, out0, ldx, ldo}, j1{x1, w1, out1, ldx, ldo};
+    const dim3 grid(rows, x1 ? 2 : 1);
+    const int t = T < 1 ? 1 : T;
+    if (D <= 2048) hipLaunchKernelGGL(qknorm_rope_kernel<1>, grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
+    else if (D <= 4096) hipLaunchKernelGGL(qknorm_rope_kernel<2>, grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
+    else hipLaunchKernelGGL(qknorm_rope_kernel<4>, grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
     HIP_CHECK(hipGetLastError());
 }
 
 void launch_qknorm_rope(const float* x, long ldx, const float* w, const float* cosT, const float* sinT, int T,
                         bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t stream) {
-    LTX_REQUIRE(D % 128 == 0 && D <= MAXV * 1024 && ldx % 4 == 0 && ldo % 4 == 0, "qknorm_rope: D=%d", D);
-    hipLaunchKernelGGL(qknorm_rope_kernel, dim3(rows), dim3(256), 0, stream, x, ldx, w, cosT, sinT, T < 1 ? 1 : T, out,
-                       ldo, D, eps);
-    HIP_CHECK(hipGetLastError());
+    launch_qknorm_rope2(x, w, out, nullptr, nullptr, nullptr, ldx, ldo, cosT, sinT, T, rows, D, eps, stream);
 }
 
 void launch_cast_f32_bf16(const float* x, bf16_t* out, long n, hipStream_t stream) {

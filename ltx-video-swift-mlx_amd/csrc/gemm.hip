@@ -405,10 +405,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
 // One barrier per K-tile, loads in flight across it (guide "Pipelining across barriers": counted vmcnt + raw barrier).
 // ---------------------------------------------------------------------------------------------------------------
 template <int N>
+LTX_DEVFN void wait_lgkm_vmcnt_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+LTX_DEVFN void wait_lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+LTX_DEVFN void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+template <int N>
 LTX_DEVFN void wait_vmcnt_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// (Tried and removed: a ninth wave per workgroup that touched the B lines eight K-tiles ahead of the ring, one dword per
+// 128-B line, to hide the HBM latency of the once-streamed DiT weights. Same-process A/B on MI355X: 779 vs 963 TFLOP/s
+// cold and 932 vs 1040 warm at 1536x8192x4096 - every touched line crosses the CU's vector L1, +40 % bytes through the
+// texture path that this loop already saturates. The ring depth stays the only latency cover.)
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -626,215 +636,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// v3: the v2 ring with 32-element K-tiles (64-byte LDS rows), which lets tiles with a larger output AREA per CU
-// (192x256, 384x128) keep a 4/5-slot ring inside 160 KiB. This kernel family is bound by the L2 -> LDS fill rate
-// (~60-70 GB/s per CU measured: ablating the MFMAs leaves 80 % of the run time), and fill bytes per FLOP are
-// (1/BM + 1/BN): 0.0130 for 192x128, 0.0091 for 192x256, 0.0104 for 384x128.
-// LDS image: [rows][64 B]; one LDS-DMA wave-instruction = 16 rows; 16-B chunk c of row r is stored at chunk
-// c ^ G[(r>>2)&3], G = {0,2,3,1}, which makes the 16x16x32 fragment reads (16 rows x one chunk per lane group)
-// conflict-free for ds_read_b128.
-// One k-step per K-tile: fragments of tile t+1 are fetched (other register set) while tile t's MFMAs run.
-// ---------------------------------------------------------------------------------------------------------------
-LTX_DEVFN int swz32(int q) { return (0x78 >> (2 * (q & 3))) & 3; }
-
-template <int BM, int BN, int NSTAGE, bool CONV, int WGM, int WGN>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v3(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BK3 = 32, RB = 64;  // K-tile elements, bytes per LDS row
-    constexpr int NW = WGM * WGN;
-    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
-    constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INSTR = BM / 16, B_INSTR = BN / 16, T_INSTR = A_INSTR + B_INSTR;
-    constexpr int IPW = (T_INSTR + NW - 1) / NW;  // max LDS-DMA instructions per wave per K-tile
-    constexpr int PD = NSTAGE - 1;
-    static_assert(NSTAGE >= 3 && PD >= 2, "ring needs >= 3 slots");
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WGN, wc = wave % WGN;
-    // this wave's DMA instructions: j = wave + NW*i. When T_INSTR is not a multiple of the wave count the surplus
-    // slots re-issue the last instruction (same rows, same LDS bytes - benign), so that every wave issues exactly IPW
-    // instructions per K-tile: no divergent control flow in the K loop and one vmcnt count for all waves.
-
-    const int tiles_m = (g.M + BM - 1) / BM;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid % tiles_m, tn = bid / tiles_m;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const int srow = lane >> 2;  // row inside a 16-row wave-instruction
-    const int pch = lane & 3;    // physical 16-B chunk written by the lane
-    const bf16_t* src[IPW];      // per-instruction source (A or B rows), advanced by K-tile
-    RowPos pos[IPW];
-    int lchv[IPW];
-    bool is_a[IPW];
-#pragma unroll
-    for (int i = 0; i < IPW; ++i) {
-        int j = wave + NW * i;
-        j = j < T_INSTR ? j : T_INSTR - 1;
-        is_a[i] = j < A_INSTR;
-        const int row = (is_a[i] ? j : j - A_INSTR) * 16 + srow;
-        const int lch = pch ^ swz32(row >> 2);
-        lchv[i] = lch;
-        src[i] = g.A;
-        if (is_a[i]) {
-            int gm = m0 + row;
-            gm = gm < g.M ? gm : g.M - 1;
-            if constexpr (CONV) {
-                const int hw = g.geom.H * g.geom.W;
-                pos[i].f = gm / hw;
-                const int rem = gm - pos[i].f * hw;
-                pos[i].y = rem / g.geom.W;
-                pos[i].x = rem - pos[i].y * g.geom.W;
-            } else {
-                src[i] = g.A + (long)gm * g.lda + lch * 8;
-            }
-        } else {
-            int gn = n0 + row;
-            gn = gn < g.N ? gn : g.N - 1;
-            src[i] = g.B + (long)gn * g.ldb + lch * 8;
-        }
-    }
-    const int nk = g.K / BK3;
-    const int cpt = CONV ? (g.geom.C / BK3) : 1;
-
-    auto conv_tap_ptrs = [&](int tap) {
-        const int dt = (g.geom.kt == 3) ? tap / 9 : 1;
-        const int t9 = (g.geom.kt == 3) ? tap - dt * 9 : tap;
-        const int dy = t9 / 3, dx = t9 - dy * 3;
-#pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-            if (!is_a[i]) continue;
-            int fi = g.geom.causal ? (pos[i].f + dt - 2) : (pos[i].f + dt - 1);
-            int yi = pos[i].y + dy - 1, xi = pos[i].x + dx - 1;
-            long p;
-            if (g.geom.pad_mode == 1) {
-                const bool ok = fi >= 0 && fi < g.geom.F && yi >= 0 && yi < g.geom.H && xi >= 0 && xi < g.geom.W;
-                p = ok ? ((long)fi * g.geom.H + yi) * g.geom.W + xi : (long)g.geom.F * g.geom.H * g.geom.W;
-            } else {
-                fi = clamp_idx(fi, g.geom.F);
-                if (g.geom.pad_mode == 0) {
-                    yi = reflect_idx(yi, g.geom.H);
-                    xi = reflect_idx(xi, g.geom.W);
-                } else {
-                    yi = clamp_idx(yi, g.geom.H);
-                    xi = clamp_idx(xi, g.geom.W);
-                }
-                p = ((long)fi * g.geom.H + yi) * g.geom.W + xi;
-            }
-            src[i] = g.A + p * g.geom.C + lchv[i] * 8;
-        }
-    };
-    int conv_cc = 0, conv_tap = 0;
-    auto stage = [&](int slot, int kt) {
-        char* base = smem + slot * STAGE;
-        if constexpr (CONV) {
-            if (conv_cc == 0) conv_tap_ptrs(conv_tap);
-        }
-#pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-            int j = wave + NW * i;
-            j = j < T_INSTR ? j : T_INSTR - 1;
-            const long koff = (CONV && is_a[i]) ? (long)conv_cc * BK3 : (long)kt * BK3;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
-        }
-        if constexpr (CONV) {
-            if (++conv_cc == cpt) {
-                conv_cc = 0;
-                ++conv_tap;
-            }
-        }
-    };
-    // the ring slot image is [A rows | B rows] x 64 B, and DMA instruction j fills bytes [j*1024, j*1024+1024)
-    const int foff = (lane & 15) * RB + (((lane >> 4) ^ swz32(lane >> 2)) << 4);
-    const int a_wave_off = (wr * WM) * RB;
-    const int b_wave_off = A_BYTES + (wc * WN) * RB;
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    s16x8 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
-    auto load_frags = [&](int slot, s16x8(&fa)[MI], s16x8(&fb)[NI]) {
-        const char* base = smem + slot * STAGE + foff;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i] = *(const s16x8*)(base + a_wave_off + i * 16 * RB);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) fb[j] = *(const s16x8*)(base + b_wave_off + j * 16 * RB);
-    };
-    auto mfma_first = [&](const s16x8(&fa)[MI], const s16x8(&fb)[NI]) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[0]),
-                                                            __builtin_bit_cast(bf16x8_t, fb[0]), acc[0][0], 0, 0, 0);
-    };
-    auto mfma_rest = [&](const s16x8(&fa)[MI], const s16x8(&fb)[NI]) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                if (i + j > 0)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
-                                                                        __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
-    };
-    auto wait_steady = [&]() { wait_vmcnt_barrier<(PD - 2) * IPW>(); };
-
-#pragma unroll
-    for (int s = 0; s < PD; ++s)
-        if (s < nk) stage(s, s);
-    if (nk >= PD) wait_vmcnt_barrier<(PD - 1) * IPW>(); else wait_vmcnt_barrier<0>();
-    load_frags(0, fa0, fb0);
-
-    int slot = 0;
-    // one K-tile with fragment set `cur`, prefetching tile kt+1 into set `nxt`
-    auto ktile = [&](int kt, s16x8(&fac)[MI], s16x8(&fbc)[NI], s16x8(&fan)[MI], s16x8(&fbn)[NI], auto steady_tag) {
-        constexpr bool STEADY = decltype(steady_tag)::value;
-        int nslot = slot + 1;
-        nslot = nslot == NSTAGE ? 0 : nslot;
-        int pslot = slot - 1;
-        pslot = pslot < 0 ? NSTAGE - 1 : pslot;
-        mfma_first(fac, fbc);
-        if constexpr (STEADY) wait_steady(); else wait_vmcnt_barrier<0>();
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (STEADY) {
-            stage(pslot, kt + PD);
-            load_frags(nslot, fan, fbn);
-            mfma_rest(fac, fbc);
-#pragma unroll
-            for (int q = 0; q < IPW; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < MI + NI; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - 1 - (MI + NI) - IPW, 0);
-        } else {
-            // tail / odd remainder of the pair-unrolled steady loop: everything drained (vmcnt(0)), still staging
-            // whatever tiles remain
-            if (kt + PD < nk) stage(pslot, kt + PD);
-            if (kt + 1 < nk) load_frags(nslot, fan, fbn);
-            mfma_rest(fac, fbc);
-        }
-        slot = nslot;
-    };
-    int kt = 0;
-    for (; kt + 1 < nk - PD; kt += 2) {
-        ktile(kt, fa0, fb0, fa1, fb1, std::true_type{});
-        ktile(kt + 1, fa1, fb1, fa0, fb0, std::true_type{});
-    }
-    for (; kt + 1 < nk; kt += 2) {
-        ktile(kt, fa0, fb0, fa1, fb1, std::false_type{});
-        ktile(kt + 1, fa1, fb1, fa0, fb0, std::false_type{});
-    }
-    if (kt < nk) ktile(kt, fa0, fb0, fa1, fb1, std::false_type{});
-    __syncthreads();
-    gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // small-M path: one wave per output column, f32 activations x bf16 weights
 // ---------------------------------------------------------------------------------------------------------------
 template <int MMAX>
@@ -894,12 +695,6 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__
 //   whose reads have completed).  One counted wait per K-tile: vmcnt(6) in P4(t+1) leaves the six pieces of tile
 //   t+3 in flight and retires all of tile t+2, which is first read one phase later (P1(t+2)).
 // ---------------------------------------------------------------------------------------------------------------
-template <int N>
-LTX_DEVFN void wait_lgkm_vmcnt_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-}
-LTX_DEVFN void wait_lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-LTX_DEVFN void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 template <int BM, int BN>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel_v4(const GemmArgs g) {
@@ -1099,22 +894,6 @@ void launch_v2(const GemmArgs& a, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
 }
 
-template <int BM, int BN, int NSTAGE, bool CONV, int WGM, int WGN>
-void launch_v3(const GemmArgs& a, hipStream_t stream) {
-    constexpr int smem = NSTAGE * (BM + BN) * 64;
-    static_assert(smem >= WGM * WGN * 16 * (BN / WGN) * 4, "epilogue scratch must fit in the ring");
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_v3<BM, BN, NSTAGE, CONV, WGM, WGN>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
-    LTX_REQUIRE(a.K % 32 == 0, "gemm v3: K=%d must be a multiple of 32", a.K);
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel_v3<BM, BN, NSTAGE, CONV, WGM, WGN>), dim3(tiles), dim3(WGM * WGN * 64), smem, stream, a);
-    HIP_CHECK(hipGetLastError());
-}
-
 template <int BM, int BN>
 void launch_v4(const GemmArgs& a, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
@@ -1133,13 +912,13 @@ void launch_v4(const GemmArgs& a, hipStream_t stream) {
 
 void validate(const GemmArgs& a) {
     LTX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
-    LTX_REQUIRE(a.K % 32 == 0, "gemm: K=%d must be a multiple of 32", a.K);
+    LTX_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
     LTX_REQUIRE(a.A && a.B, "gemm: null operand");
     LTX_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0, "gemm: operands must be 16-B aligned");
     LTX_REQUIRE(a.ldb % 8 == 0, "gemm: ldb=%ld must be a multiple of 8", a.ldb);
     if (a.conv) {
         LTX_REQUIRE(a.geom.kt == 1 || a.geom.kt == 3, "gemm/conv3d: kt=%d", a.geom.kt);
-        LTX_REQUIRE(a.geom.C % 32 == 0 && a.K == 9 * a.geom.kt * a.geom.C, "gemm/conv3d: C=%d K=%d kt=%d", a.geom.C, a.K, a.geom.kt);
+        LTX_REQUIRE(a.geom.C % BK == 0 && a.K == 9 * a.geom.kt * a.geom.C, "gemm/conv3d: C=%d K=%d kt=%d", a.geom.C, a.K, a.geom.kt);
         LTX_REQUIRE(a.M == a.geom.F * a.geom.H * a.geom.W, "gemm/conv3d: M=%d != F*H*W", a.M);
         LTX_REQUIRE(a.geom.pad_mode != 0 || (a.geom.H >= 2 && a.geom.W >= 2), "gemm/conv3d: reflect padding needs H,W >= 2");
     } else {
@@ -1162,8 +941,6 @@ void validate(const GemmArgs& a) {
 
 void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     validate(a);
-    LTX_REQUIRE(cfg >= 30 || a.K % BK == 0, "gemm: K=%d must be a multiple of %d for tile cfg %d", a.K, BK, cfg);
-    LTX_REQUIRE(!a.conv || cfg >= 30 || a.geom.C % BK == 0, "gemm/conv3d: C=%d must be a multiple of %d for tile cfg %d", a.geom.C, BK, cfg);
     ProfScope prof(a.conv ? PROF_CONV : PROF_GEMM, 2.0 * a.M * a.N * a.K, stream);
     // cfg 0..2: v1 (2-stage, one barrier + full drain per K-tile); cfg 10..: v2 (ring + counted vmcnt)
     if (a.conv) {
@@ -1175,10 +952,6 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 21: launch_v2<192, 128, 4, true, 4, 2>(a, stream); break;   // 8 waves (4x2), per-wave 48x64, 4-slot ring
             case 23: launch_v2<256, 128, 3, true, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, true, 2, 4>(a, stream); break;
-            case 31: launch_v3<192, 256, 5, true, 4, 2>(a, stream); break;  // 8 waves, per-wave 48x128, BK=32, 5-slot ring
-            case 32: launch_v3<384, 128, 5, true, 4, 2>(a, stream); break;  // 8 waves, per-wave 96x64
-            case 33: launch_v3<192, 256, 4, true, 4, 2>(a, stream); break;
-            case 34: launch_v3<256, 192, 5, true, 2, 4>(a, stream); break;  // 8 waves, per-wave 128x48
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
         }
     } else {
@@ -1190,10 +963,6 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 21: launch_v2<192, 128, 4, false, 4, 2>(a, stream); break;  // 8 waves (4x2), per-wave 48x64, 4-slot ring
             case 23: launch_v2<256, 128, 3, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
-            case 31: launch_v3<192, 256, 5, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 48x128, BK=32, 5-slot ring
-            case 32: launch_v3<384, 128, 5, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 96x64
-            case 33: launch_v3<192, 256, 4, false, 4, 2>(a, stream); break;
-            case 34: launch_v3<256, 192, 5, false, 2, 4>(a, stream); break;  // 8 waves, per-wave 128x48
             case 41: launch_v4<192, 256>(a, stream); break;  // ping-pong, 8 waves (2x4), per-wave 96x64
             case 42: launch_v4<256, 256>(a, stream); break;  // ping-pong, per-wave 128x64
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);

@@ -26,7 +26,7 @@ def as_f32(t):
     return t.float().cpu().numpy()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 21, 23, 25, 31, 32, 33, 34])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 21, 23, 25])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (105, 200, 128), (1, 128, 64), (577, 130, 320), (200, 136, 64), (384, 256, 1024), (130, 260, 448), (64, 128, 576), (300, 192, 256)])
 def test_gemm_integer_exact(gpu_ctx, cfg, M, N, K):
     """Small-integer operands: every product and partial sum is exact in f32 -> result must be bit-exact."""
@@ -42,20 +42,6 @@ def test_gemm_integer_exact(gpu_ctx, cfg, M, N, K):
     assert np.array_equal(got, ref), f"max diff {np.abs(got - ref).max()}"
     if out.shape[1] > N:  # padding columns untouched
         assert np.all(as_f32(out)[:, N:] == -777.0)
-
-
-@pytest.mark.parametrize("cfg", [31, 32, 33, 34])
-@pytest.mark.parametrize("K", [32, 96, 160, 224, 288, 352, 416])
-def test_gemm_v3_odd_ktiles(gpu_ctx, cfg, K):
-    """32-wide K-tiles: every parity / remainder of the pair-unrolled ring loop (K need only be a multiple of 32)."""
-    rng = np.random.default_rng(K + cfg)
-    M, N = 200, 264
-    A = rng.integers(-3, 4, (M, K)).astype(np.float32)
-    B = rng.integers(-3, 4, (N, K)).astype(np.float32)
-    out = torch.empty((M, N), device="cuda")
-    gpu_ctx.op_gemm(dev_bf16(A), dev_bf16(B), None, tile_cfg=cfg, out_f32=out)
-    torch.cuda.synchronize()
-    assert np.array_equal(as_f32(out), A @ B.T)
 
 
 @pytest.mark.parametrize("cfg", [41, 42])
