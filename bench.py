@@ -17,7 +17,9 @@ roofline: dominant kernel family = the bf16 MFMA GEMM (gemm_bf16_kernel / gemm_b
 GEMM launches' algorithmic FLOPs (2*M*N*K) / sum of their durations over K steps, measured with HIP events recorded
 on the launch stream around every GEMM launch (ltx_prof_*) in a second pass of the same K steps right after the timed
 region (the event packets cost ~6 % of a step, so `value` comes from the un-instrumented pass). peak = 2500 TFLOP/s
-dense bf16.
+dense bf16. traffic = fabric-side bytes per GEMM launch from the rocprofv3 PMC passes committed under profiles/
+(tools/pmc_traffic.py); the algorithmic bytes per launch (A + B + C + residual) average 103 MB, the counters see
+~298 MB because every XCD's L2 fetches the whole activation operand once (8 x A).
 cpu_baseline: the oracle (numpy restatement of the reference path, kind "port") timed on the host cores for a few
 transformer blocks of the same workload and extrapolated to one full step.
 """
@@ -33,6 +35,19 @@ sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, FRAMES, S_TEXT = 768, 512, 25, 1024
 PEAK_BF16_TFLOPS = 2500.0
+
+
+def pmc_traffic():
+    """HBM-side bytes per GEMM launch (mean over all GEMM launches of this workload). PMC counters cannot be read from
+    inside the process: they come from two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE) of this same
+    command, corrected as MI355X_MICROARCH.md prescribes (KiB units, FETCH_SIZE x2 on gfx950) by tools/pmc_traffic.py and
+    committed under profiles/. null when that file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return round(json.load(f)["gemm_all"]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def dit_flops_per_step(T, S=1024, D=4096, L=48, B=1):
@@ -178,7 +193,7 @@ def main():
         if g["ms"] > 0:
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel{,_v2}", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
                         "launches": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2),
                         "gemm_ms_per_step": round(g["ms"] / args.steps, 3),
                         "ms_per_step_with_events": round(1e3 * el_prof / args.steps, 3)}

@@ -55,6 +55,7 @@ struct GemmArgs {
     int conv = 0;  // 1: A is an implicit conv3d view described by geom, K = 27*C
     Conv3dGeom geom;
     GemmEpilogue ep;
+    int group_m = 4;  // row-tiles per supertile of the workgroup order (0 = column-major tile order); see tile_coords()
 };
 
 // Launches on `stream`. Picks the tile shape from (M,N). Throws LtxError on invalid shapes.

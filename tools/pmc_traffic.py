@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Combine two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE - they do not fit one pass on gfx950) of the same bench
+command into per-launch HBM-side traffic per kernel family. Corrections per MI355X_MICROARCH.md 'HBM': both counters
+are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled; WRITE_SIZE is exact for 16-B stores.
+Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*\)$", "", name)
+
+
+def load(path, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        acc[family(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    out = {"unit": "bytes per launch (mean over the launches of the run)", "corrections": "FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1", "kernels": {}}
+    tot_f = tot_w = 0.0
+    n_gemm = 0
+    for k in sorted(set(fetch) | set(write)):
+        f = fetch.get(k, [])
+        w = write.get(k, [])
+        fb = 2.0 * 1024.0 * (sum(f) / len(f)) if f else 0.0
+        wb = 1024.0 * (sum(w) / len(w)) if w else 0.0
+        out["kernels"][k] = {"launches": max(len(f), len(w)), "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
+        if k.startswith("gemm_bf16_kernel"):
+            tot_f += 2.0 * 1024.0 * sum(f)
+            tot_w += 1024.0 * sum(w)
+            n_gemm += max(len(f), len(w))
+    if n_gemm:
+        out["gemm_all"] = {"launches": n_gemm, "hbm_bytes_per_launch": (tot_f + tot_w) / n_gemm,
+                           "fetch_bytes_per_launch": tot_f / n_gemm, "write_bytes_per_launch": tot_w / n_gemm}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out.get("gemm_all", {})))
+
+
+if __name__ == "__main__":
+    main()
