@@ -742,6 +742,12 @@ int ltx_op_gemm_bf16(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* 
         g.ep.act = act;
         g.ep.out_f32 = out_f32; g.ep.ld_f32 = ld_f32;
         g.ep.out_bf16 = out_bf16; g.ep.ld_bf16 = ld_bf16;
+        if (tile_cfg >= 100) {  // S*100 + cfg: S-way split-K on a ring tile (workspace owned by the context)
+            g.split_k = tile_cfg / 100;
+            tile_cfg %= 100;
+            if (ctx->op_ws.ensure((size_t)g.split_k * M * N * 4)) HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            g.split_ws = ctx->op_ws.as<float>();
+        }
         if (tile_cfg < 0) launch_gemm_bf16(g, ctx->stream); else launch_gemm_bf16_cfg(g, tile_cfg, ctx->stream);
     });
 }

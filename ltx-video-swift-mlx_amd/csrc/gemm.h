@@ -55,8 +55,17 @@ struct GemmArgs {
     int conv = 0;  // 1: A is an implicit conv3d view described by geom, K = 27*C
     Conv3dGeom geom;
     GemmEpilogue ep;
+    // split-K (ring kernels): grid.y = split_k workgroups share one output tile, each walks 1/split_k of the K-tiles and
+    // stores its raw f32 partial tile to split_ws[z][M][N]; splitk_finish then sums the partials in a fixed order and applies
+    // the epilogue (deterministic - no float atomics). Used when a launch has too few output tiles to fill the chip.
+    int split_k = 1;
+    float* split_ws = nullptr;
     int group_m = 4;  // row-tiles per supertile of the workgroup order (0 = column-major tile order); see tile_coords()
 };
+
+// Number of K splits that fills the chip for a launch with few output tiles (1 = do not split). The caller provides
+// split_ws with room for split_k * M * N floats.
+int gemm_suggest_split_k(int M, int N, int K);
 
 // Launches on `stream`. Picks the tile shape from (M,N). Throws LtxError on invalid shapes.
 void launch_gemm_bf16(const GemmArgs& args, hipStream_t stream);

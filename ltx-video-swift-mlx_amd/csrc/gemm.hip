@@ -494,7 +494,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         gn = gn < g.N ? gn : g.N - 1;
         b_src[i] = g.B + (long)gn * g.ldb + lch * 8;
     }
-    const int nk = g.K / BK;
+    int nk = g.K / BK, kt0 = 0;  // this workgroup's K-tiles: [kt0, kt0 + nk)
+    if (g.split_k > 1) {
+        const int z = blockIdx.y;
+        kt0 = (int)((long)nk * z / g.split_k);
+        nk = (int)((long)nk * (z + 1) / g.split_k) - kt0;
+    }
     const int cpt = CONV ? (g.geom.C / BK) : 1;
 
     // conv mode: the gathered source pointers only change when the 3x3x3 tap changes (every C/64 K-tiles); inside a
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
             a_src[i] = g.A + pos * g.geom.C + a_lch[i] * 8;
         }
     };
-    int conv_cc = 0, conv_tap = 0;  // position of the NEXT K-tile to stage
+    int conv_tap = kt0 / cpt, conv_cc = kt0 - conv_tap * cpt;  // position of the NEXT K-tile to stage
     auto stage = [&](int slot, int kt) {
         char* base = smem + slot * STAGE;
         if constexpr (CONV) {
@@ -594,9 +599,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     };
 
     // prologue: fill PD ring slots, wait for tile 0, fetch its first fragments
+    if constexpr (CONV) {
+        if (conv_cc != 0) conv_tap_ptrs(conv_tap);  // a K split may begin in the middle of a tap
+    }
 #pragma unroll
     for (int s = 0; s < PD; ++s)
-        if (s < nk) stage(s, s);
+        if (s < nk) stage(s, kt0 + s);
     if (nk >= PD) wait_vmcnt_barrier<(PD - 1) * LPT>(); else wait_vmcnt_barrier<0>();
     load_frags(0, foff0, fa0, fb0);
 
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         mfma_first(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (STEADY) {
-            stage(pslot, kt + PD);
+            stage(pslot, kt0 + kt + PD);
             load_frags(nslot, foff0, fa0, fb0);
             mfma_rest(fa1, fb1);
 #pragma unroll
@@ -652,6 +660,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     for (; kt < nk - PD; ++kt) ktile(kt, std::true_type{});
     for (; kt < nk; ++kt) ktile(kt, std::false_type{});
     __syncthreads();
+    if (g.split_k > 1) {
+        GemmArgs gs = g;  // raw partial tile -> workspace slice of this split
+        gs.ep = GemmEpilogue{};
+        gs.ep.out_f32 = g.split_ws + (long)blockIdx.y * g.M * g.N;
+        gs.ep.ld_f32 = g.N;
+        gemm_epilogue<BM, BN, WGM, WGN>(acc, gs, m0, n0, wr, wc, lane, wave, smem);
+        return;
+    }
     gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem);
 }
 
@@ -888,6 +904,40 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_v4(const GemmArgs g) {
     gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem);
 }
 
+// split-K finish: out = epilogue(sum_z ws[z]) for the epilogue subset the VAE convs use (bias, scalar-gated residual,
+// f32 and/or bf16 outputs); partials are summed in ascending z, so the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int S, int M, int N, GemmEpilogue ep) {
+    const long n4 = N >> 2;
+    const long total = (long)M * n4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / n4;
+        const int c = (int)(i - m * n4) * 4;
+        f32x4 v = *(const f32x4*)(ws + m * N + c);
+        for (int z = 1; z < S; ++z) v += *(const f32x4*)(ws + ((long)z * M + m) * N + c);
+        if (ep.bias_n) v += *(const f32x4*)(ep.bias_n + c);
+        if (ep.act == LTX_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        } else if (ep.act == LTX_ACT_GELU_TANH) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+        }
+        if (ep.resid) {
+            const float* rs = (ep.resid_src ? ep.resid_src + m * ep.ld_resid : ep.out_f32 + m * ep.ld_f32) + c;
+            const f32x4 r4 = *(const f32x4*)rs;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r4[e] + ep.gate_scalar * v[e];
+        }
+        if (ep.out_f32) *(f32x4*)(ep.out_f32 + m * ep.ld_f32 + c) = v;
+        if (ep.out_bf16) {
+            uint2 pk;
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
+            *(uint2*)(ep.out_bf16 + m * ep.ld_bf16 + c) = pk;
+        }
+    }
+}
+
 template <int BM, int BN, bool CONV>
 void launch_one(const GemmArgs& a, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
@@ -912,8 +962,20 @@ void launch_v2(const GemmArgs& a, hipStream_t stream) {
         attr_set = true;
     }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN>), dim3(tiles), dim3(WGM * WGN * 64), smem, stream, a);
+    if (a.split_k > 1) {
+        const GemmEpilogue& e = a.ep;
+        LTX_REQUIRE(a.split_ws && a.N % 4 == 0 && !e.d2s && !e.gate && !e.bias_m && !e.round_bf16, "gemm split-K: unsupported epilogue");
+        LTX_REQUIRE(a.split_k <= a.K / BK, "gemm split-K: %d splits for %d K-tiles", a.split_k, a.K / BK);
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN>), dim3(tiles, a.split_k > 1 ? a.split_k : 1),
+                       dim3(WGM * WGN * 64), smem, stream, a);
     HIP_CHECK(hipGetLastError());
+    if (a.split_k > 1) {
+        const long total = (long)a.M * (a.N / 4);
+        const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+        HIP_CHECK(hipGetLastError());
+    }
 }
 
 template <int BM, int BN>
@@ -963,6 +1025,7 @@ void validate(const GemmArgs& a) {
 
 void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     validate(a);
+    LTX_REQUIRE(a.split_k <= 1 || (cfg >= 20 && cfg < 30), "gemm: split-K needs a ring kernel (tile cfg %d)", cfg);
     ProfScope prof(a.conv ? PROF_CONV : PROF_GEMM, 2.0 * a.M * a.N * a.K, stream);
     // cfg 0..2: v1 (2-stage, one barrier + full drain per K-tile); cfg 10..: v2 (ring + counted vmcnt)
     if (a.conv) {
@@ -991,6 +1054,16 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
         }
     }
+}
+
+int gemm_suggest_split_k(int M, int N, int K) {
+    const long tiles = (long)((M + 191) / 192) * ((N + 127) / 128);  // the 192x128 ring kernel's tiles
+    const int nk = K / BK;
+    if (tiles >= 160 || nk < 32) return 1;
+    long s = 256 / tiles;
+    if (s > 8) s = 8;
+    if (s > nk / 8) s = nk / 8;
+    return s < 1 ? 1 : (int)s;
 }
 
 void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {

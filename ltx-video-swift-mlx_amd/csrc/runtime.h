@@ -136,6 +136,7 @@ struct ltx_ctx {
     Profiler prof;
     // denoise-loop scratch (device)
     DevBuf dn_tokens, dn_vel_tok, dn_vel, dn_vel2, dn_vel3, dn_prev, dn_ts, dn_stats, dn_lat2;
+    DevBuf op_ws;  // split-K workspace of the kernel-level test hook
 };
 
 // synthetic weights (bench / property tests): counter-based normal fill on device

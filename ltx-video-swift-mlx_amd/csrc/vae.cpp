@@ -203,7 +203,10 @@ struct Dims {
     long P() const { return (long)F * H * W; }
 };
 
-void conv3d(const bf16_t* x, const Dims& d, const ConvW& cw, GemmEpilogue ep, hipStream_t st) {
+// `skws`/`skws_elems`: split-K workspace (floats) - convs with too few output tiles to fill the chip (the 1024-channel
+// stage: 1536 positions -> 64 tiles of 192x128) split their 27*Cin reduction over several workgroups per tile
+void conv3d(const bf16_t* x, const Dims& d, const ConvW& cw, GemmEpilogue ep, hipStream_t st, float* skws = nullptr,
+            long skws_elems = 0) {
     GemmArgs g;
     g.A = x;
     g.B = cw.w;
@@ -220,6 +223,14 @@ void conv3d(const bf16_t* x, const Dims& d, const ConvW& cw, GemmEpilogue ep, hi
     g.geom.pad_mode = 0;  // reflect
     ep.bias_n = cw.b;
     g.ep = ep;
+    if (skws && !ep.d2s && cw.cout % 4 == 0) {
+        int sk = gemm_suggest_split_k(g.M, g.N, g.K);
+        while (sk > 1 && (long)sk * g.M * g.N > skws_elems) --sk;
+        if (sk > 1) {
+            g.split_k = sk;
+            g.split_ws = skws;
+        }
+    }
     launch_gemm_bf16(g, st);
 }
 
@@ -232,6 +243,8 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
     float* t1 = m->t1.as<float>();
     bf16_t* hb = m->hb.as<bf16_t>();
     float* mods = m->mods.as<float>();
+    float* skws = m->skws.as<float>();
+    const long skn = (long)(m->skws.bytes / 4);
 
     // per-block modulation vectors: rows shift1, scale1+1, shift2, scale2+1 (VideoDecoder.swift:93-113)
     float* emb = m->temb.as<float>();        // [256] sinusoid, [256] hidden, then per-group outputs
@@ -280,7 +293,7 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
         GemmEpilogue e;
         e.out_f32 = xa;
         e.ld_f32 = m->channels[0];
-        conv3d(hb, d, m->conv_in, e, st);
+        conv3d(hb, d, m->conv_in, e, st, skws, skn);
     }
     float* x = xa;
     float* xo = xb;
@@ -293,14 +306,14 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
             GemmEpilogue e1;
             e1.out_f32 = t1;
             e1.ld_f32 = C;
-            conv3d(hb, d, rb.conv1, e1, st);
+            conv3d(hb, d, rb.conv1, e1, st, skws, skn);
             launch_pixelnorm_silu(t1, md + 3 * C, md + 2 * C, hb, d.P(), C, st);
             GemmEpilogue e2;  // x = conv2(h) + x, in place
             e2.out_f32 = x;
             e2.ld_f32 = C;
             e2.resid = 1;
             e2.gate_scalar = 1.0f;
-            conv3d(hb, d, rb.conv2, e2, st);
+            conv3d(hb, d, rb.conv2, e2, st, skws, skn);
         }
         if (g < 3) {
             // depth-to-space upsampler (VideoDecoder.swift:215-251): conv on the raw stream, D2S, drop frame 0, + D2S(x)
@@ -354,6 +367,7 @@ void vae_decode(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a) {
         m->xb.ensure((size_t)elems * 4);
         m->t1.ensure((size_t)elems * 4);
         m->hb.ensure((size_t)elems * 2);
+        m->skws.ensure((size_t)elems * 4);
         m->ws_elems = elems;
     }
     m->mods.ensure((size_t)(20 * 4 * 1024 + 256) * 4);

@@ -61,7 +61,7 @@ struct VaeModel {
     std::map<std::string, Slot> slots;
 
     // workspace
-    DevBuf xa, xb, t1, hb, mods, tile_frames, temb;
+    DevBuf xa, xb, t1, hb, mods, tile_frames, temb, skws;
     long ws_elems = 0;
 };
 

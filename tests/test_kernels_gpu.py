@@ -44,6 +44,23 @@ def test_gemm_integer_exact(gpu_ctx, cfg, M, N, K):
         assert np.all(as_f32(out)[:, N:] == -777.0)
 
 
+@pytest.mark.parametrize("M,N,K,S,cfg", [(200, 136, 2048, 4, 21), (64, 512, 4096, 8, 21), (300, 192, 1728, 3, 25), (1536, 1024, 3456, 4, 21)])
+def test_gemm_split_k_integer_exact(gpu_ctx, M, N, K, S, cfg):
+    """Deterministic split-K (grid.y workgroups per tile, f32 partials, fixed-order finish pass with the epilogue): bit-exact
+    on integer data, uneven K-tile shares (27 tiles over 3 splits, 54 over 4), bias + bf16 mirror through the finish pass."""
+    rng = np.random.default_rng(M + N + K + S)
+    A = rng.integers(-3, 4, (M, K)).astype(np.float32)
+    B = rng.integers(-3, 4, (N, K)).astype(np.float32)
+    bias = rng.integers(-5, 6, (N,)).astype(np.float32)
+    out = torch.empty((M, N), device="cuda")
+    outb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_gemm(dev_bf16(A), dev_bf16(B), dev_f32(bias), tile_cfg=S * 100 + cfg, out_f32=out, out_bf16=outb)
+    torch.cuda.synchronize()
+    ref = A @ B.T + bias
+    assert np.array_equal(as_f32(out), ref)
+    assert np.array_equal(as_f32(outb), torch.from_numpy(ref).to(torch.bfloat16).float().numpy())
+
+
 @pytest.mark.parametrize("cfg", [41, 42])
 @pytest.mark.parametrize("M,N,K,reps", [(192, 256, 128, 1), (256, 256, 192, 1), (100, 60, 320, 1), (500, 700, 256, 2),
                                         (777, 1000, 448, 2), (1536, 1024, 4096, 6), (1536, 2048, 1024, 6), (3000, 768, 2112, 3)])
