@@ -210,6 +210,46 @@ int ltx_adain_filter_latent_dev(ltx_ctx* ctx, float* latent, long n_per_channel,
 int ltx_renoise_dev(ltx_ctx* ctx, float* latent, const float* noise, float sigma, long n);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Text-embedding connector (VideoGemmaTextEncoderModel.encodeFromHiddenStates,
+ * LTXTextEncoder.swift:574-643 - call site LTXPipeline.swift:640-700): from the 49 Gemma-3 hidden states to the
+ * [B,T,3840] bf16 context + all-ones mask that ltx_denoise / ltx_dit_forward take. The language model itself is not
+ * part of this library: its hidden states are the input.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct ltx_connector_config {
+    int dim;        /* 3840 = heads x 128 */
+    int heads;      /* 30 */
+    int layers;     /* 2 */
+    int registers;  /* 128 learnable registers */
+    int states;     /* 49 hidden states (embedding + 48 layers) */
+    float theta;    /* 10000 */
+    int max_pos;    /* 4096 */
+} ltx_connector_config;
+void ltx_connector_config_default(ltx_connector_config* cfg);
+/* Replaces the connector part of loadModels (LTXPipeline.swift:420-540, key rules ModelDownloader.swift:911-968): reads
+ * `text_embedding_projection.*` / `video_embeddings_connector.*` from a unified checkpoint, or `text_proj_in.*` /
+ * `video_connector.*` from a standalone connector file. cfg NULL = reference architecture. */
+int ltx_connector_load(ltx_ctx* ctx, const char* safetensors_path, const ltx_connector_config* cfg);
+int ltx_connector_init_synthetic(ltx_ctx* ctx, const ltx_connector_config* cfg, unsigned long seed);
+int ltx_connector_unload(ltx_ctx* ctx);
+/* hidden [states][B][T][dim] bf16, attention_mask [B][T] int32 0/1 (padding_right: 0 = left padding, the reference's
+ * default) -> context [B][T][dim] bf16 and out_mask [B][T] int32 (all ones; may be NULL). T must be a multiple of
+ * `registers` (the reference aborts otherwise). DEVICE pointers. */
+int ltx_connector_encode_dev(ltx_ctx* ctx, const uint16_t* hidden, const int32_t* attention_mask, int B, int T,
+                             int padding_right, uint16_t* context, int32_t* out_mask);
+/* HOST-pointer variant of the same call. */
+int ltx_connector_encode(ltx_ctx* ctx, const uint16_t* hidden, const int32_t* attention_mask, int B, int T,
+                         int padding_right, uint16_t* context, int32_t* out_mask);
+/* Parity taps (DEVICE pointers, any may be NULL): the normalised concat [B][T][dim*states] bf16, the feature-extractor
+ * output [B][T][dim] bf16 and the stream after register replacement [B][T][dim] f32. */
+int ltx_connector_encode_taps_dev(ltx_ctx* ctx, const uint16_t* hidden, const int32_t* attention_mask, int B, int T,
+                                  int padding_right, uint16_t* context, uint16_t* norm_concat, uint16_t* fe_out,
+                                  float* after_registers);
+/* mapTextEncoderWeights (ModelDownloader.swift:911-968): returns the length of the module key, 0 if the key is dropped. */
+int ltx_map_text_encoder_key(const char* file_key, char* out, int cap);
+/* Connector RoPE tables (positions 0..T-1, one axis, f64 math): cos/sin [T][dim/2] f32, before the cast to bf16. */
+int ltx_rope_tables_1d(int T, int dim, float theta, int max_pos, float* cos_out, float* sin_out);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Denoising loop
  * ---------------------------------------------------------------------------------------------------------- */
 /* GenerationProgressCallback (LTXPipeline.swift:50-72): invoked synchronously on the calling thread once per step,

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import PROGRESS_CB, DenoiseOptions, LTXError, TransformerConfig, lib
+from ._lib import ConnectorConfig, PROGRESS_CB, DenoiseOptions, LTXError, TransformerConfig, lib
 
 __version__ = lib.ltx_version().decode()
 
@@ -104,6 +104,26 @@ def map_vae_key(key):
 
 def map_lora_key(key):
     return _map_key(lib.ltx_map_lora_key, key)
+
+
+def map_text_encoder_key(key):
+    """``mapTextEncoderWeights`` (ModelDownloader.swift:911-968); None = dropped."""
+    return _map_key(lib.ltx_map_text_encoder_key, key)
+
+
+def connector_config(**kw):
+    cfg = ConnectorConfig()
+    lib.ltx_connector_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def rope_tables_1d(T, dim=3840, theta=10000.0, max_pos=4096):
+    cos = np.empty((T, dim // 2), dtype=np.float32)
+    sin = np.empty((T, dim // 2), dtype=np.float32)
+    _check(lib.ltx_rope_tables_1d(T, dim, theta, max_pos, cos.ctypes.data, sin.ctypes.data))
+    return cos, sin
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -250,6 +270,38 @@ class Context:
         self._ck(lib.ltx_op_conv3d(self._h, _ptr(x), F, H, W, Cin, _ptr(w), _ptr(bias), Cout, int(causal), _ptr(out)))
 
     # ---- two-stage glue ----
+    # ---- text-embedding connector ----
+    def connector_load(self, path, cfg=None):
+        self._ck(lib.ltx_connector_load(self._h, str(path).encode(), C.byref(cfg) if cfg is not None else None))
+
+    def connector_init_synthetic(self, cfg=None, seed=91):
+        self._ck(lib.ltx_connector_init_synthetic(self._h, C.byref(cfg) if cfg is not None else None, seed))
+
+    def connector_unload(self):
+        self._ck(lib.ltx_connector_unload(self._h))
+
+    def connector_encode(self, hidden_bits, attention_mask, padding_right=False):
+        """``encodeFromHiddenStates``: hidden [states,B,T,dim] uint16 (bf16 bits), mask [B,T] int32 -> (context bits
+        [B,T,dim] uint16, mask [B,T] int32). HOST arrays."""
+        h = np.ascontiguousarray(hidden_bits, dtype=np.uint16)
+        m = np.ascontiguousarray(attention_mask, dtype=np.int32)
+        _, B, T, D = h.shape
+        out = np.empty((B, T, D), dtype=np.uint16)
+        om = np.empty((B, T), dtype=np.int32)
+        self._ck(lib.ltx_connector_encode(self._h, _ptr(h), _ptr(m), B, T, int(padding_right), _ptr(out), _ptr(om)))
+        return out, om
+
+    def connector_encode_dev(self, hidden, attention_mask, context, out_mask=None, padding_right=False, taps=None):
+        """Device tensors: hidden [states,B,T,dim] bf16, mask [B,T] int32, context [B,T,dim] bf16. taps = optional
+        (norm_concat, fe_out, after_registers) device tensors for parity tests."""
+        _, B, T, _ = hidden.shape
+        if taps is not None:
+            self._ck(lib.ltx_connector_encode_taps_dev(self._h, _ptr(hidden), _ptr(attention_mask), B, T, int(padding_right),
+                                                       _ptr(context), _ptr(taps[0]), _ptr(taps[1]), _ptr(taps[2])))
+        else:
+            self._ck(lib.ltx_connector_encode_dev(self._h, _ptr(hidden), _ptr(attention_mask), B, T, int(padding_right),
+                                                  _ptr(context), _ptr(out_mask)))
+
     def upscaler_load(self, path):
         self._ck(lib.ltx_upscaler_load(self._h, str(path).encode()))
 

@@ -36,6 +36,13 @@ class DenoiseOptions(C.Structure):
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_float, C.c_void_p)
 
 
+class ConnectorConfig(C.Structure):
+    """``ltx_connector_config`` / reference ``VideoGemmaTextEncoderModel`` defaults (LTXTextEncoder.swift:18-45)."""
+
+    _fields_ = [("dim", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("registers", C.c_int), ("states", C.c_int),
+                ("theta", C.c_float), ("max_pos", C.c_int)]
+
+
 class TransformerConfig(C.Structure):
     """``ltx_transformer_config`` / reference ``LTXTransformerConfig`` (LTXConfig.swift:83-177)."""
 
@@ -98,6 +105,15 @@ SIGNATURES = {
     "ltx_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _l, _ip]),
     "ltx_vae_decode_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _l, _ip]),
     "ltx_op_conv3d": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "ltx_connector_config_default": (None, [C.POINTER(ConnectorConfig)]),
+    "ltx_connector_load": (_i, [_vp, C.c_char_p, C.POINTER(ConnectorConfig)]),
+    "ltx_connector_init_synthetic": (_i, [_vp, C.POINTER(ConnectorConfig), C.c_ulong]),
+    "ltx_connector_unload": (_i, [_vp]),
+    "ltx_connector_encode_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ltx_connector_encode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ltx_connector_encode_taps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ltx_map_text_encoder_key": (_i, [C.c_char_p, C.c_char_p, _i]),
+    "ltx_rope_tables_1d": (_i, [_i, _i, _f, _i, _vp, _vp]),
     "ltx_upscaler_load": (_i, [_vp, C.c_char_p]),
     "ltx_upscaler_unload": (_i, [_vp]),
     "ltx_upscale_latent": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -4,6 +4,7 @@
 
 #include "../../include/ltxhip.h"
 #include "attention.h"
+#include "connector.h"
 #include "dit.h"
 #include "elementwise.h"
 #include "gemm.h"
@@ -130,6 +131,7 @@ void ltx_ctx_destroy(ltx_ctx* ctx) {
     if (ctx->dit) dit_destroy(ctx->dit);
     if (ctx->vae) vae_destroy(ctx->vae);
     if (ctx->upscaler) upscaler_destroy(ctx->upscaler);
+    if (ctx->connector) connector_destroy(ctx->connector);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -814,3 +816,123 @@ int ltx_op_fill_normal_f32(ltx_ctx* ctx, float* p, long n, uint64_t seed, float 
 }
 
 }  // extern "C"
+
+
+/* ---- text-embedding connector ---- */
+namespace {
+ConnectorConfig to_conn_cfg(const ltx_connector_config* c) {
+    ConnectorConfig k;
+    if (c) {
+        k.dim = c->dim; k.heads = c->heads; k.layers = c->layers; k.registers = c->registers; k.states = c->states;
+        k.theta = c->theta; k.max_pos = c->max_pos;
+    }
+    return k;
+}
+void drop_connector(ltx_ctx* ctx) {
+    if (ctx->connector) {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        connector_destroy(ctx->connector);
+        ctx->connector = nullptr;
+    }
+}
+}  // namespace
+
+void ltx_connector_config_default(ltx_connector_config* cfg) {
+    if (!cfg) return;
+    const ConnectorConfig k;
+    cfg->dim = k.dim; cfg->heads = k.heads; cfg->layers = k.layers; cfg->registers = k.registers; cfg->states = k.states;
+    cfg->theta = k.theta; cfg->max_pos = k.max_pos;
+}
+
+int ltx_connector_load(ltx_ctx* ctx, const char* path, const ltx_connector_config* cfg) {
+    if (!ctx || !path) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        drop_connector(ctx);
+        ConnectorModel* m = connector_create(to_conn_cfg(cfg));
+        try {
+            connector_load_safetensors(ctx, m, path);
+        } catch (...) {
+            connector_destroy(m);
+            throw;
+        }
+        ctx->connector = m;
+    });
+}
+
+int ltx_connector_init_synthetic(ltx_ctx* ctx, const ltx_connector_config* cfg, unsigned long seed) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        drop_connector(ctx);
+        ctx->connector = connector_create(to_conn_cfg(cfg));
+        connector_init_synthetic(ctx, ctx->connector, seed);
+    });
+}
+
+int ltx_connector_unload(ltx_ctx* ctx) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { drop_connector(ctx); });
+}
+
+int ltx_connector_encode_taps_dev(ltx_ctx* ctx, const uint16_t* hidden, const int32_t* attention_mask, int B, int T,
+                                  int padding_right, uint16_t* context, uint16_t* norm_concat, uint16_t* fe_out,
+                                  float* after_registers) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        if (!ctx->connector) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model not loaded: text-embedding connector");
+        ConnectorArgs a;
+        a.hidden = hidden; a.mask = attention_mask; a.B = B; a.T = T; a.padding_right = padding_right;
+        a.out = context; a.dbg_nc = norm_concat; a.dbg_fe = fe_out; a.dbg_reg = after_registers;
+        connector_encode(ctx, ctx->connector, a);
+    });
+}
+
+int ltx_connector_encode_dev(ltx_ctx* ctx, const uint16_t* hidden, const int32_t* attention_mask, int B, int T,
+                             int padding_right, uint16_t* context, int32_t* out_mask) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        if (!ctx->connector) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model not loaded: text-embedding connector");
+        ConnectorArgs a;
+        a.hidden = hidden; a.mask = attention_mask; a.B = B; a.T = T; a.padding_right = padding_right;
+        a.out = context; a.out_mask = out_mask;
+        connector_encode(ctx, ctx->connector, a);
+    });
+}
+
+int ltx_connector_encode(ltx_ctx* ctx, const uint16_t* hidden, const int32_t* attention_mask, int B, int T,
+                         int padding_right, uint16_t* context, int32_t* out_mask) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        if (!ctx->connector) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model not loaded: text-embedding connector");
+        LTX_REQUIRE(hidden && attention_mask && context && B >= 1 && T >= 1, "connector_encode: bad arguments");
+        const ConnectorConfig& c = ctx->connector->cfg;
+        const size_t hb = (size_t)c.states * B * T * c.dim * 2, mb = (size_t)B * T * 4, ob = (size_t)B * T * c.dim * 2;
+        ctx->h2d[0].ensure(hb);
+        ctx->h2d[1].ensure(mb);
+        ctx->h2d[2].ensure(ob);
+        ctx->h2d[3].ensure(mb);
+        HIP_CHECK(hipMemcpyAsync(ctx->h2d[0].p, hidden, hb, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(ctx->h2d[1].p, attention_mask, mb, hipMemcpyHostToDevice, ctx->stream));
+        ConnectorArgs a;
+        a.hidden = ctx->h2d[0].as<bf16_t>(); a.mask = ctx->h2d[1].as<int32_t>(); a.B = B; a.T = T; a.padding_right = padding_right;
+        a.out = ctx->h2d[2].as<bf16_t>(); a.out_mask = ctx->h2d[3].as<int32_t>();
+        connector_encode(ctx, ctx->connector, a);
+        HIP_CHECK(hipMemcpyAsync(context, ctx->h2d[2].p, ob, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_mask) HIP_CHECK(hipMemcpyAsync(out_mask, ctx->h2d[3].p, mb, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int ltx_map_text_encoder_key(const char* file_key, char* out, int cap) {
+    std::string mk;
+    if (!file_key || !map_text_encoder_file_key(file_key, &mk)) return 0;
+    return copy_str(mk, out, cap);
+}
+
+int ltx_rope_tables_1d(int T, int dim, float theta, int max_pos, float* cos_out, float* sin_out) {
+    if (!cos_out || !sin_out || T < 1 || dim < 2 || max_pos < 1) return LTX_ERR_INVALID_CONFIGURATION;
+    std::vector<float> c, s;
+    rope_tables_1d(T, dim, (double)theta, max_pos, &c, &s);
+    memcpy(cos_out, c.data(), c.size() * 4);
+    memcpy(sin_out, s.data(), s.size() * 4);
+    return LTX_OK;
+}

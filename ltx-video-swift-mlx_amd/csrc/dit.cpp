@@ -6,6 +6,7 @@
 #include "attention.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "linear_ops.h"
 
 namespace {
 
@@ -192,36 +193,6 @@ void dit_init_synthetic(ltx_ctx* ctx, DiTModel* m, uint64_t seed) {
 // forward
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
-
-void gemm_linear(const bf16_t* A, long lda, const LinearW& w, int M, GemmEpilogue ep, hipStream_t s) {
-    GemmArgs g;
-    g.A = A;
-    g.lda = lda;
-    g.B = w.w;
-    g.ldb = w.in;
-    g.M = M;
-    g.N = w.out;
-    g.K = w.in;
-    if (!ep.bias_n && !ep.bias_m) ep.bias_n = w.b;
-    g.ep = ep;
-    launch_gemm_bf16(g, s);
-}
-
-// V^T[d][token] = W_v[d][:] . X[token][:] + b_v[d]  (swapped operands -> the attention kernel's Vt layout)
-void gemm_vt(const bf16_t* X, long ldx, int tokens, const LinearW& wv, bf16_t* vt, long ldvt, hipStream_t s) {
-    GemmArgs g;
-    g.A = wv.w;
-    g.lda = wv.in;
-    g.B = X;
-    g.ldb = ldx;
-    g.M = wv.out;
-    g.N = tokens;
-    g.K = wv.in;
-    g.ep.out_bf16 = vt;
-    g.ep.ld_bf16 = ldvt;
-    g.ep.bias_m = wv.b;
-    launch_gemm_bf16(g, s);
-}
 
 void ensure_workspace(DiTModel* m, int B, int T, hipStream_t st) {
     const int D = m->D;

@@ -93,3 +93,20 @@ void launch_groupnorm_apply(const float* x, const float* stats, const float* w, 
                             int act_silu, float* out_f32, bf16_t* out_bf16, long P, int C, int G, hipStream_t stream);
 // x [P][C] f32 -> out [C][P] f32 with (x - mean[c]) / std[c]  (upsampleLatents renormalisation, SpatialUpscaler.swift:352-379)
 void launch_upscaler_finish(const float* x, const float* mean, const float* std_, float* out, long P, int C, hipStream_t stream);
+
+// ---- text-embedding connector (LTXTextEncoder.swift:62-122, :428-470) ----
+// masked (sum, min, max) over the valid tokens of every (state, batch) plane of hidden [states][B][T][D]; partials per chunk,
+// then mean and 8/(range+eps) per plane -> stats[(l*B+b)*2 + {0,1}]
+void launch_fe_stats(const bf16_t* hidden, const int32_t* mask, int states, int B, int T, int D, int padding_right, float eps,
+                     float* partials, float* stats, hipStream_t stream);
+// out[b][t][d*states + l] = valid ? bf16(8*(x-mean)/(range+eps)) : 0
+long fe_stats_partials_floats(int states, int B, int T, int D);
+void launch_fe_norm_concat(const bf16_t* hidden, const int32_t* mask, const float* stats, int states, int B, int T, int D,
+                           int padding_right, float eps, bf16_t* out, hipStream_t stream);
+// src[b][p] = token index whose row lands at position p, or -1 for a learnable register (valid tokens first, in order;
+// position p keeps a token where reverse(valid)[p] is set)
+void launch_register_plan(const int32_t* mask, int B, int T, int32_t* src, hipStream_t stream);
+// x[b][p][:] = src >= 0 ? enc[b][src][:] : registers[p % R][:]   (f32 stream)
+void launch_register_gather(const bf16_t* enc, const float* registers, const int32_t* src, int B, int T, int D, int R, float* x,
+                            hipStream_t stream);
+void launch_fill_const_i32(int32_t* p, long n, int32_t v, hipStream_t stream);

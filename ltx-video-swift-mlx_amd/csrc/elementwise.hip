@@ -697,3 +697,187 @@ void launch_upscaler_finish(const float* x, const float* mean, const float* std_
     hipLaunchKernelGGL(upscaler_finish_kernel, dim3(cdiv(P, 32), cdiv(C, 32)), dim3(256), 0, stream, x, mean, std_, out, P, C);
     HIP_CHECK(hipGetLastError());
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// text-embedding connector kernels
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int FE_CHUNK = 16384;  // elements of one (state, batch) plane per workgroup
+
+LTX_DEVFN bool fe_token_valid(const int32_t* mrow, int t, int T, int n_valid, int padding_right) {
+    // the reference rebuilds the mask from the sequence length and the padding side (LTXTextEncoder.swift:75-84)
+    return padding_right ? (t < n_valid) : (t >= T - n_valid);
+}
+
+__global__ __launch_bounds__(256) void fe_stats_partial_kernel(const bf16_t* __restrict__ hidden, const int32_t* __restrict__ mask,
+                                                               int B, int T, int D, int padding_right,
+                                                               float* __restrict__ partials, int nchunk) {
+    __shared__ float red[3][4];
+    __shared__ int s_nvalid;
+    const int plane = blockIdx.y;  // l*B + b
+    const int b = plane % B;
+    if (threadIdx.x == 0) s_nvalid = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int t = threadIdx.x; t < T; t += 256) cnt += mask[(long)b * T + t] != 0;
+    atomicAdd(&s_nvalid, cnt);
+    __syncthreads();
+    const int n_valid = s_nvalid;
+    const bf16_t* x = hidden + (long)plane * T * D;
+    const long total = (long)T * D;
+    const long beg = (long)blockIdx.x * FE_CHUNK;
+    const long end = beg + FE_CHUNK < total ? beg + FE_CHUNK : total;
+    float s = 0.f, mn = INFINITY, mx = -INFINITY;
+    for (long i = beg + threadIdx.x * 8; i < end; i += 256 * 8) {
+        const int t = (int)(i / D);  // D % 8 == 0: the 8 elements share a token
+        if (!fe_token_valid(nullptr, t, T, n_valid, padding_right)) continue;
+        const uint4 raw = *(const uint4*)(x + i);
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = bf16_to_f32((bf16_t)(w[k] & 0xffff)), c = bf16_to_f32((bf16_t)(w[k] >> 16));
+            s += a + c;
+            mn = fminf(mn, fminf(a, c));
+            mx = fmaxf(mx, fmaxf(a, c));
+        }
+    }
+    s = wave_reduce_sum(s);
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    }
+    const int lane = threadIdx.x & 63, w_ = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][w_] = s;
+        red[1][w_] = mn;
+        red[2][w_] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* p = partials + ((long)plane * nchunk + blockIdx.x) * 3;
+        p[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        p[1] = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+        p[2] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+    }
+}
+
+__global__ void fe_stats_final_kernel(const float* __restrict__ partials, const int32_t* __restrict__ mask, int B, int T, int D,
+                                      float eps, int nchunk, float* __restrict__ stats, int planes) {
+    const int plane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (plane >= planes) return;
+    const int b = plane % B;
+    int n_valid = 0;
+    for (int t = 0; t < T; ++t) n_valid += mask[(long)b * T + t] != 0;
+    double s = 0.0;  // fixed order over the chunks
+    float mn = INFINITY, mx = -INFINITY;
+    for (int c = 0; c < nchunk; ++c) {
+        const float* p = partials + ((long)plane * nchunk + c) * 3;
+        s += (double)p[0];
+        mn = fminf(mn, p[1]);
+        mx = fmaxf(mx, p[2]);
+    }
+    const float denom = (float)n_valid * (float)D + eps;
+    stats[plane * 2 + 0] = (float)s / denom;
+    stats[plane * 2 + 1] = (mx - mn) + eps;
+}
+
+__global__ __launch_bounds__(256) void fe_norm_concat_kernel(const bf16_t* __restrict__ hidden, const int32_t* __restrict__ mask,
+                                                             const float* __restrict__ stats, int states, int B, int T, int D,
+                                                             int padding_right, bf16_t* __restrict__ out) {
+    __shared__ int s_nvalid;
+    const int bt = blockIdx.x;  // b*T + t
+    const int b = bt / T, t = bt - b * T;
+    if (threadIdx.x == 0) s_nvalid = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = threadIdx.x; i < T; i += 256) cnt += mask[(long)b * T + i] != 0;
+    atomicAdd(&s_nvalid, cnt);
+    __syncthreads();
+    const bool valid = fe_token_valid(nullptr, t, T, s_nvalid, padding_right);
+    bf16_t* orow = out + (long)bt * D * states;
+    const long plane_stride = (long)B * T * D;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const bf16_t* x = hidden + ((long)b * T + t) * D + d;
+        bf16_t* o = orow + (long)d * states;
+        for (int l = 0; l < states; ++l) {
+            float v = 0.f;
+            if (valid) {
+                const float xv = bf16_to_f32(x[(long)l * plane_stride]);
+                v = 8.0f * (xv - stats[(l * B + b) * 2 + 0]) / stats[(l * B + b) * 2 + 1];
+            }
+            o[l] = f32_to_bf16(v);
+        }
+    }
+}
+
+__global__ void register_plan_kernel(const int32_t* __restrict__ mask, int T, int32_t* __restrict__ src) {
+    // one thread per batch row: T <= a few thousand, runs once per prompt
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const int32_t* m = mask + (long)b * T;
+    int32_t* s = src + (long)b * T;
+    int n = 0;
+    for (int t = 0; t < T; ++t)
+        if (m[t] != 0) s[n++] = t;  // valid tokens first, in order
+    for (int t = 0; t < T; ++t)
+        if (m[t] == 0) s[n++] = t;  // padded tokens after them (never kept unless the padding is on the right)
+    for (int p = 0; p < T; ++p)
+        if (m[T - 1 - p] == 0) s[p] = -1;  // reverse(valid)[p] == 0 -> learnable register
+}
+
+__global__ __launch_bounds__(256) void register_gather_kernel(const bf16_t* __restrict__ enc, const float* __restrict__ registers,
+                                                              const int32_t* __restrict__ src, int T, int D, int R,
+                                                              float* __restrict__ x) {
+    const int bp = blockIdx.x;
+    const int b = bp / T, p = bp - b * T;
+    const int sidx = src[bp];
+    float* o = x + (long)bp * D;
+    if (sidx >= 0) {
+        const bf16_t* e = enc + ((long)b * T + sidx) * D;
+        for (int d = threadIdx.x; d < D; d += 256) o[d] = bf16_to_f32(e[d]);
+    } else {
+        const float* rg = registers + (long)(p % R) * D;
+        for (int d = threadIdx.x; d < D; d += 256) o[d] = rg[d];
+    }
+}
+
+__global__ void fill_const_i32_kernel(int32_t* p, long n, int32_t v) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+}  // namespace
+
+void launch_fe_stats(const bf16_t* hidden, const int32_t* mask, int states, int B, int T, int D, int padding_right, float eps,
+                     float* partials, float* stats, hipStream_t stream) {
+    LTX_REQUIRE(D % 8 == 0, "connector: hidden dim %d must be a multiple of 8", D);
+    const int nchunk = (int)(((long)T * D + FE_CHUNK - 1) / FE_CHUNK);
+    hipLaunchKernelGGL(fe_stats_partial_kernel, dim3(nchunk, states * B), dim3(256), 0, stream, hidden, mask, B, T, D, padding_right,
+                       partials, nchunk);
+    HIP_CHECK(hipGetLastError());
+    const int planes = states * B;
+    hipLaunchKernelGGL(fe_stats_final_kernel, dim3((planes + 63) / 64), dim3(64), 0, stream, partials, mask, B, T, D, eps, nchunk, stats,
+                       planes);
+    HIP_CHECK(hipGetLastError());
+}
+long fe_stats_partials_floats(int states, int B, int T, int D) {
+    return (long)states * B * (((long)T * D + FE_CHUNK - 1) / FE_CHUNK) * 3;
+}
+void launch_fe_norm_concat(const bf16_t* hidden, const int32_t* mask, const float* stats, int states, int B, int T, int D,
+                           int padding_right, float eps, bf16_t* out, hipStream_t stream) {
+    (void)eps;
+    hipLaunchKernelGGL(fe_norm_concat_kernel, dim3(B * T), dim3(256), 0, stream, hidden, mask, stats, states, B, T, D, padding_right, out);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_register_plan(const int32_t* mask, int B, int T, int32_t* src, hipStream_t stream) {
+    hipLaunchKernelGGL(register_plan_kernel, dim3(B), dim3(64), 0, stream, mask, T, src);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_register_gather(const bf16_t* enc, const float* registers, const int32_t* src, int B, int T, int D, int R, float* x,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(register_gather_kernel, dim3(B * T), dim3(256), 0, stream, enc, registers, src, T, D, R, x);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_fill_const_i32(int32_t* p, long n, int32_t v, hipStream_t stream) {
+    hipLaunchKernelGGL(fill_const_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, v);
+    HIP_CHECK(hipGetLastError());
+}

@@ -317,3 +317,79 @@ bool map_lora_key(const std::string& lora_base, std::string* out) {
     *out = k + ".weight";
     return true;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// text-embedding connector helpers
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+bool starts_with(const std::string& s, const char* p) { return s.compare(0, strlen(p), p) == 0; }
+void replace_all(std::string& s, const std::string& a, const std::string& b) {
+    size_t pos = 0;
+    while ((pos = s.find(a, pos)) != std::string::npos) {
+        s.replace(pos, a.size(), b);
+        pos += b.size();
+    }
+}
+std::string connector_internal(std::string k) {
+    replace_all(k, "transformer_blocks.", "transformer_1d_blocks.");
+    replace_all(k, ".norm_q.", ".q_norm.");
+    replace_all(k, ".norm_k.", ".k_norm.");
+    replace_all(k, ".to_out.0.", ".to_out.");
+    replace_all(k, ".ff.net.0.proj.", ".ff.project_in.proj.");
+    replace_all(k, ".ff.net.2.", ".ff.project_out.");
+    return k;
+}
+}  // namespace
+
+bool map_text_encoder_file_key(const std::string& file_key, std::string* module_key) {
+    std::string k = file_key;
+    static const char* pre[3][2] = {{"model.diffusion_model.video_embeddings_connector.", "video_embeddings_connector."},
+                                    {"model.diffusion_model.audio_embeddings_connector.", "audio_embeddings_connector."},
+                                    {"model.diffusion_model.text_embedding_projection.", "text_embedding_projection."}};
+    for (auto& p : pre)
+        if (starts_with(k, p[0])) {
+            k = std::string(p[1]) + k.substr(strlen(p[0]));
+            break;
+        }
+    if (starts_with(k, "text_proj_in.")) {
+        replace_all(k, "text_proj_in.", "feature_extractor.aggregate_embed.");
+    } else if (starts_with(k, "video_connector.")) {
+        replace_all(k, "video_connector.", "embeddings_connector.");
+        k = connector_internal(k);
+    } else if (starts_with(k, "audio_connector.")) {
+        replace_all(k, "audio_connector.", "audio_embeddings_connector.");
+        k = connector_internal(k);
+    } else if (starts_with(k, "text_embedding_projection.")) {
+        replace_all(k, "text_embedding_projection.", "feature_extractor.");
+    } else if (starts_with(k, "video_embeddings_connector.")) {
+        replace_all(k, "video_embeddings_connector.", "embeddings_connector.");
+        k = connector_internal(k);
+    } else if (starts_with(k, "audio_embeddings_connector.")) {
+        k = connector_internal(k);
+    } else {
+        return false;
+    }
+    *module_key = k;
+    return true;
+}
+
+void rope_tables_1d(int T, int dim, double theta, int max_pos, std::vector<float>* cos_out, std::vector<float>* sin_out) {
+    const int n_idx = dim / 2 > 1 ? dim / 2 : 1;
+    const double log_start = log(1.0) / log(theta), log_end = log(theta) / log(theta);
+    std::vector<double> idx(n_idx);
+    for (int i = 0; i < n_idx; ++i) {
+        const double t = n_idx > 1 ? log_start + (log_end - log_start) * (double)i / (double)(n_idx - 1) : log_start;
+        idx[i] = pow(theta, t) * (M_PI / 2.0);
+    }
+    cos_out->assign((size_t)T * n_idx, 0.f);
+    sin_out->assign((size_t)T * n_idx, 0.f);
+    for (int t = 0; t < T; ++t) {
+        const double scaled = ((double)(float)t / (double)max_pos) * 2.0 - 1.0;
+        for (int i = 0; i < n_idx; ++i) {
+            const double v = idx[i] * scaled;
+            (*cos_out)[(size_t)t * n_idx + i] = (float)cos(v);
+            (*sin_out)[(size_t)t * n_idx + i] = (float)sin(v);
+        }
+    }
+}

@@ -54,3 +54,9 @@ bool map_transformer_file_key(const std::string& file_key, std::string* module_k
 bool map_vae_file_key(const std::string& file_key, std::string* module_key);
 // LoRA key -> module weight key (LoRALoader.swift:209-243)
 bool map_lora_key(const std::string& lora_base, std::string* module_weight_key);
+// text-embedding connector: file key -> module key of VideoGemmaTextEncoderModel
+// (ModelDownloader.swift:911-968 after the unified-file prefix strip of :1353-1399); false = dropped
+bool map_text_encoder_file_key(const std::string& file_key, std::string* module_key);
+// connector RoPE: integer positions 0..T-1 on one axis, split type, f64 math (LTXTextEncoder.swift:482-497,
+// LTXRoPE.swift:375-490). cos/sin [T][dim/2] f32 (no padding slots: one axis -> dim/2 frequencies).
+void rope_tables_1d(int T, int dim, double theta, int max_pos, std::vector<float>* cos_out, std::vector<float>* sin_out);

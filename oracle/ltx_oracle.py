@@ -964,3 +964,203 @@ def two_stage_latent(w, cfg, wu, mean, std, noise1, noise2, context, mask, width
     s2 = np.array(STAGE_2_DISTILLED_SIGMA_VALUES, F32)
     lat = (s2[0] * noise2.astype(F32) + (F32(1.0) - s2[0]) * lat).astype(F32)
     return denoise(w, cfg, lat, s2, context, mask, F2, H2, W2, num_layers=num_layers)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# text-embedding connector (the step immediately before the denoise loop). Restates
+# Models/TextEncoder/LTXTextEncoder.swift: norm_and_concat (:62-122), GemmaFeaturesExtractor (:126-187),
+# ConnectorAttention (:197-269), BasicTransformerBlock1D (:316-371), Embeddings1DConnector (:375-522),
+# encodeFromHiddenStates (:574-643). The Gemma-3 language model itself stays out of scope: its 49 hidden states are
+# the INPUT here. Activations are bf16 in the reference (the hidden states arrive as bf16); every op output is rounded
+# to bf16 below where MLX would store bf16. PARITY UNPINNED like the rest of this file.
+# ---------------------------------------------------------------------------------------------------------------
+CONNECTOR_DIM = 3840
+CONNECTOR_HEADS = 30
+CONNECTOR_LAYERS = 2
+CONNECTOR_REGISTERS = 128
+GEMMA_STATES = 49
+
+
+def rope_tables_1d(seq_len, dim=CONNECTOR_DIM, num_heads=CONNECTOR_HEADS, theta=10000.0, max_pos=4096):
+    """precomputeFreqsCisDoublePrecision with a [1,1,T] grid of integer positions (LTXTextEncoder.swift:482-497,
+    LTXRoPE.swift:375-490): one position dim -> dim/2 frequencies, no padding. cos/sin [T][dim/2] f32 (head h owns
+    columns h*64..), before the connector's cast to bf16."""
+    n_idx = max(1, dim // 2)
+    log_start = math.log(1.0) / math.log(theta)
+    log_end = math.log(theta) / math.log(theta)
+    idx = [math.pow(theta, log_start + (log_end - log_start) * i / (n_idx - 1) if n_idx > 1 else log_start) * (math.pi / 2.0)
+           for i in range(n_idx)]
+    cos = np.empty((seq_len, n_idx), F32)
+    sin = np.empty((seq_len, n_idx), F32)
+    for t in range(seq_len):
+        scaled = (float(np.float32(t)) / float(max_pos)) * 2.0 - 1.0
+        for i in range(n_idx):
+            v = idx[i] * scaled
+            cos[t, i] = math.cos(v)
+            sin[t, i] = math.sin(v)
+    return cos, sin
+
+
+def norm_and_concat(stacked, seq_lens, padding_side="left", eps=1e-6):
+    """normAndConcatPaddedBatch (LTXTextEncoder.swift:62-122). stacked [B,T,D,L] (bf16 values); returns [B,T,D*L] bf16
+    values, zero at padded positions; statistics per (batch, layer) over the valid tokens, in f32."""
+    x = stacked.astype(F32)
+    b, t, d, nl = x.shape
+    idx = np.arange(t)[None, :]
+    sl = np.asarray(seq_lens).reshape(b, 1)
+    mask = (idx < sl) if padding_side == "right" else (idx >= (t - sl))
+    m4 = mask[:, :, None, None]
+    masked = np.where(m4, x, F32(0))
+    denom = (sl.astype(F32) * F32(d)).reshape(b, 1, 1, 1) + F32(eps)
+    mean = masked.sum(axis=(1, 2), keepdims=True, dtype=np.float64).astype(F32) / denom
+    xmin = np.where(m4, x, F32(np.inf)).min(axis=(1, 2), keepdims=True)
+    xmax = np.where(m4, x, F32(-np.inf)).max(axis=(1, 2), keepdims=True)
+    rng = xmax - xmin
+    normed = bf16_round(F32(8.0) * (x - mean) / (rng + F32(eps)))
+    normed = normed.reshape(b, t, d * nl)
+    return np.where(mask[:, :, None], normed, F32(0)).astype(F32)
+
+
+def connector_param_shapes(dim=CONNECTOR_DIM, layers=CONNECTOR_LAYERS, registers=CONNECTOR_REGISTERS, states=GEMMA_STATES):
+    sh = {"feature_extractor.aggregate_embed.weight": (dim, dim * states),
+          "embeddings_connector.learnable_registers": (registers, dim)}
+    for i in range(layers):
+        p = f"embeddings_connector.transformer_1d_blocks.{i}."
+        for n in ("to_q", "to_k", "to_v", "to_out"):
+            sh[p + f"attn1.{n}.weight"] = (dim, dim)
+            sh[p + f"attn1.{n}.bias"] = (dim,)
+        sh[p + "attn1.q_norm.weight"] = (dim,)
+        sh[p + "attn1.k_norm.weight"] = (dim,)
+        sh[p + "ff.project_in.proj.weight"] = (4 * dim, dim)
+        sh[p + "ff.project_in.proj.bias"] = (4 * dim,)
+        sh[p + "ff.project_out.weight"] = (dim, 4 * dim)
+        sh[p + "ff.project_out.bias"] = (dim,)
+    return sh
+
+
+def synth_connector_weights(dim=CONNECTOR_DIM, heads=CONNECTOR_HEADS, layers=CONNECTOR_LAYERS,
+                            registers=CONNECTOR_REGISTERS, states=GEMMA_STATES, seed=91):
+    rng = np.random.default_rng(seed)
+    w = {}
+    for k, shp in connector_param_shapes(dim, layers, registers, states).items():
+        if k.endswith("learnable_registers"):
+            v = rng.uniform(-1.0, 1.0, shp)  # reference initialiser (LTXTextEncoder.swift:421-425)
+        elif k.endswith("_norm.weight"):
+            v = 1.0 + 0.02 * rng.standard_normal(shp)
+        elif k.endswith(".bias"):
+            v = 0.01 * rng.standard_normal(shp)
+        elif "aggregate_embed" in k:
+            v = rng.standard_normal(shp) / math.sqrt(shp[1])
+        else:
+            v = 0.02 * rng.standard_normal(shp)
+        w[k] = bf16_round(v.astype(F32))
+    return w
+
+
+def replace_padded_with_registers(hidden, valid, registers):
+    """replacePaddedWithLearnableRegisters (LTXTextEncoder.swift:428-470): valid tokens are moved to the front in order,
+    then position p keeps the moved token where reverse(valid)[p] is set and takes register p mod R elsewhere."""
+    b, t, d = hidden.shape
+    r = registers.shape[0]
+    assert t % r == 0, "sequence length must be divisible by the number of registers"
+    out = np.empty_like(hidden)
+    tiled = np.tile(registers, (t // r, 1))
+    for bi in range(b):
+        v = valid[bi].astype(np.int64)
+        order = np.argsort((1 - v) * t + np.arange(t), kind="stable")
+        adjusted = hidden[bi][order]
+        flipped = valid[bi][::-1].astype(F32)[:, None]
+        out[bi] = bf16_round(flipped * adjusted + (F32(1) - flipped) * tiled)
+    return out
+
+
+def connector_block(w, p, x, heads, cos, sin):
+    """BasicTransformerBlock1D (LTXTextEncoder.swift:316-371) with ConnectorAttention (:197-269)."""
+    n = bf16_round(rms_norm(x))
+    q = bf16_round(linear(n, w[p + "attn1.to_q.weight"], w[p + "attn1.to_q.bias"]))
+    k = bf16_round(linear(n, w[p + "attn1.to_k.weight"], w[p + "attn1.to_k.bias"]))
+    v = bf16_round(linear(n, w[p + "attn1.to_v.weight"], w[p + "attn1.to_v.bias"]))
+    q = bf16_round(rms_norm(q, w[p + "attn1.q_norm.weight"]))
+    k = bf16_round(rms_norm(k, w[p + "attn1.k_norm.weight"]))
+    q = bf16_round(apply_split_rope(q, cos, sin, heads))
+    k = bf16_round(apply_split_rope(k, cos, sin, heads))
+    a = bf16_round(sdpa(q, k, v, heads, 1.0 / math.sqrt(q.shape[-1] // heads)))
+    x = bf16_round(x + bf16_round(linear(a, w[p + "attn1.to_out.weight"], w[p + "attn1.to_out.bias"])))
+    n = bf16_round(rms_norm(x))
+    hdn = bf16_round(gelu_tanh(bf16_round(linear(n, w[p + "ff.project_in.proj.weight"], w[p + "ff.project_in.proj.bias"]))))
+    return bf16_round(x + bf16_round(linear(hdn, w[p + "ff.project_out.weight"], w[p + "ff.project_out.bias"])))
+
+
+def connector_encode(w, hidden_states, attention_mask, padding_side="left", heads=CONNECTOR_HEADS, layers=CONNECTOR_LAYERS,
+                     return_intermediates=False):
+    """encodeFromHiddenStates (LTXTextEncoder.swift:574-643): hidden_states [L][B][T][D] bf16 values, attention_mask [B][T]
+    0/1 -> (video_encoding [B,T,D] bf16 values, mask [B,T] int32 all ones)."""
+    hs = np.asarray(hidden_states, dtype=F32)
+    nl, b, t, d = hs.shape
+    stacked = np.moveaxis(hs, 0, -1)  # [B,T,D,L]
+    am = np.asarray(attention_mask)
+    seq = am.sum(-1).astype(np.int32)
+    nc = norm_and_concat(stacked, seq, padding_side)
+    enc = bf16_round(linear(nc, w["feature_extractor.aggregate_embed.weight"]))  # f32 matmul, then cast (:180-186)
+    valid = am.astype(bool)  # additive mask (m-1)*3.38e38 >= -9000  <=>  m == 1
+    x = replace_padded_with_registers(enc, valid, w["embeddings_connector.learnable_registers"].astype(F32))
+    cos, sin = rope_tables_1d(t, d, heads)
+    cos, sin = bf16_round(cos), bf16_round(sin)  # cast to the input dtype (:498)
+    inter = {"norm_concat": nc, "fe": enc, "registers": x}
+    for i in range(layers):
+        x = connector_block(w, f"embeddings_connector.transformer_1d_blocks.{i}.", x, heads, cos, sin)
+    x = bf16_round(rms_norm(x))
+    out_mask = np.ones((b, t), np.int32)  # mask cleared after register replacement (:466-468, :622-626)
+    if return_intermediates:
+        return x, out_mask, inter
+    return x, out_mask
+
+
+def map_text_encoder_key(key):
+    """mapTextEncoderWeights + applyConnectorInternalMapping (ModelDownloader.swift:911-968) preceded by the unified-file
+    prefix strip of splitUnifiedWeightsDict (:1353-1399). Returns the module key or None (dropped). Audio connector keys
+    map too (kept for completeness; this build loads the video connector only)."""
+    k = key
+    for pre, new in (("model.diffusion_model.video_embeddings_connector.", "video_embeddings_connector."),
+                     ("model.diffusion_model.audio_embeddings_connector.", "audio_embeddings_connector."),
+                     ("model.diffusion_model.text_embedding_projection.", "text_embedding_projection.")):
+        if k.startswith(pre):
+            k = new + k[len(pre):]
+            break
+
+    def internal(s):
+        for a, b_ in (("transformer_blocks.", "transformer_1d_blocks."), (".norm_q.", ".q_norm."), (".norm_k.", ".k_norm."),
+                      (".to_out.0.", ".to_out."), (".ff.net.0.proj.", ".ff.project_in.proj."), (".ff.net.2.", ".ff.project_out.")):
+            s = s.replace(a, b_)
+        return s
+
+    if k.startswith("text_proj_in."):
+        return k.replace("text_proj_in.", "feature_extractor.aggregate_embed.")
+    if k.startswith("video_connector."):
+        return internal(k.replace("video_connector.", "embeddings_connector."))
+    if k.startswith("audio_connector."):
+        return internal(k.replace("audio_connector.", "audio_embeddings_connector."))
+    if k.startswith("text_embedding_projection."):
+        return k.replace("text_embedding_projection.", "feature_extractor.")
+    if k.startswith("video_embeddings_connector."):
+        return internal(k.replace("video_embeddings_connector.", "embeddings_connector."))
+    if k.startswith("audio_embeddings_connector."):
+        return internal(k)
+    return None
+
+
+def connector_file_keys(w, unified=True):
+    """Module keys -> the names a checkpoint carries (inverse of map_text_encoder_key), for loader tests."""
+    out = {}
+    for k, v in w.items():
+        if k.startswith("feature_extractor."):
+            fk = ("model.diffusion_model.text_embedding_projection." + k[len("feature_extractor."):]) if unified \
+                else k.replace("feature_extractor.aggregate_embed.", "text_proj_in.")
+        else:
+            s = k[len("embeddings_connector."):]
+            for a, b_ in (("transformer_1d_blocks.", "transformer_blocks."), (".q_norm.", ".norm_q."), (".k_norm.", ".norm_k."),
+                          (".to_out.", ".to_out.0."), (".ff.project_in.proj.", ".ff.net.0.proj."), (".ff.project_out.", ".ff.net.2.")):
+                s = s.replace(a, b_)
+            fk = ("model.diffusion_model.video_embeddings_connector." if unified else "video_connector.") + s
+        out[fk] = v
+    return out

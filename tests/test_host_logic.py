@@ -253,3 +253,71 @@ def test_ctx_create_without_gpu_fails_loudly(ltx):
     with pytest.raises(ltx.LTXError) as e:
         ltx.Context(0, use_torch_stream=False)
     assert e.value.case == "hipError"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# text-embedding connector host logic
+# ---------------------------------------------------------------------------------------------------------------
+def test_text_encoder_key_mapping(ltx, oracle):
+    kat = {
+        # unified checkpoint (ModelDownloader.swift:1353-1399 then :935-940)
+        "model.diffusion_model.text_embedding_projection.aggregate_embed.weight": "feature_extractor.aggregate_embed.weight",
+        "model.diffusion_model.video_embeddings_connector.learnable_registers": "embeddings_connector.learnable_registers",
+        "model.diffusion_model.video_embeddings_connector.transformer_blocks.1.attn1.to_out.0.bias":
+            "embeddings_connector.transformer_1d_blocks.1.attn1.to_out.bias",
+        "model.diffusion_model.video_embeddings_connector.transformer_blocks.0.attn1.norm_q.weight":
+            "embeddings_connector.transformer_1d_blocks.0.attn1.q_norm.weight",
+        "model.diffusion_model.video_embeddings_connector.transformer_blocks.0.ff.net.0.proj.weight":
+            "embeddings_connector.transformer_1d_blocks.0.ff.project_in.proj.weight",
+        "model.diffusion_model.video_embeddings_connector.transformer_blocks.0.ff.net.2.bias":
+            "embeddings_connector.transformer_1d_blocks.0.ff.project_out.bias",
+        "model.diffusion_model.audio_embeddings_connector.transformer_blocks.0.attn1.norm_k.weight":
+            "audio_embeddings_connector.transformer_1d_blocks.0.attn1.k_norm.weight",
+        # standalone connector file (:920-933)
+        "text_proj_in.weight": "feature_extractor.aggregate_embed.weight",
+        "video_connector.transformer_blocks.0.attn1.to_k.weight": "embeddings_connector.transformer_1d_blocks.0.attn1.to_k.weight",
+        "audio_connector.learnable_registers": "audio_embeddings_connector.learnable_registers",
+        # not text-encoder tensors
+        "model.diffusion_model.transformer_blocks.0.attn1.to_q.weight": None,
+        "vae.decoder.conv_in.conv.weight": None,
+    }
+    for k, v in kat.items():
+        assert ltx.map_text_encoder_key(k) == v, k
+        assert oracle.map_text_encoder_key(k) == v, k
+    w = oracle.connector_param_shapes(dim=256, layers=2, registers=8, states=5)
+    for unified in (True, False):
+        for fk in oracle.connector_file_keys({k: None for k in w}, unified=unified):
+            assert ltx.map_text_encoder_key(fk) in w
+
+
+def test_rope_tables_1d(ltx, oracle):
+    """Positions 0..T-1 scaled to [-1,1) over max_pos 4096, dim/2 log-spaced frequencies pi/2 .. theta*pi/2, f64 math."""
+    for T, dim in ((8, 256), (128, 3840)):
+        c, s = ltx.rope_tables_1d(T, dim)
+        oc, os_ = oracle.rope_tables_1d(T, dim, num_heads=dim // 128)
+        assert np.array_equal(c.view(np.uint32), oc.view(np.uint32))
+        assert np.array_equal(s.view(np.uint32), os_.view(np.uint32))
+    c, s = ltx.rope_tables_1d(4, 256)
+    # token 0: scaled position -1 -> angle -idx; first frequency index = pi/2: cos(-pi/2) ~ 6.1e-17, sin = -1
+    assert abs(c[0, 0]) < 1e-7 and s[0, 0] == np.float32(-1.0)
+    # last frequency = theta*pi/2 at position 2/4096*2-1
+    import math
+    ang = 10000.0 * math.pi / 2 * (2.0 / 4096 * 2 - 1)
+    assert c[2, -1] == np.float32(math.cos(ang)) and s[2, -1] == np.float32(math.sin(ang))
+
+
+def test_connector_oracle_internals(oracle):
+    """Hand-checkable pieces of the restatement: per-layer statistics ignore padded tokens; register plan."""
+    rng = np.random.default_rng(0)
+    B, T, D, L = 1, 4, 8, 2
+    x = oracle.bf16_round(rng.standard_normal((B, T, D, L)).astype(np.float32))
+    x[0, 0] = 1000.0  # padded token must not influence mean / range
+    nc = oracle.norm_and_concat(x, np.array([3]), "left")
+    assert np.all(nc[0, 0] == 0)
+    v = x[0, 1:, :, 1].astype(np.float64)
+    exp = 8.0 * (x[0, 2, 5, 1] - v.sum() / (3 * D + 1e-6)) / (v.max() - v.min() + 1e-6)
+    assert abs(nc[0, 2, 5 * L + 1] - exp) <= abs(exp) * 2.0 ** -7
+    hid = np.arange(8, dtype=np.float32).reshape(1, 8, 1) + 1
+    reg = -np.arange(4, dtype=np.float32).reshape(4, 1) - 1
+    out = oracle.replace_padded_with_registers(hid, np.array([[0, 0, 0, 1, 1, 1, 1, 1]], bool), reg)
+    assert out[0, :, 0].tolist() == [4, 5, 6, 7, 8, -2, -3, -4]  # 5 valid tokens first, then registers 5%4, 6%4, 7%4
