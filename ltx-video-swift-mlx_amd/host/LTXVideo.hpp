@@ -184,6 +184,40 @@ class LTXPipeline {
         return n;
     }
     void loadUpscaler(const std::string& path) { check(ltx_upscaler_load(ctx_, path.c_str())); }
+    // Connector part of the text encoder (VideoGemmaTextEncoderModel, LTXTextEncoder.swift:535-643; loaded in
+    // loadModels, LTXPipeline.swift:420-540): reads text_embedding_projection.* / video_embeddings_connector.* from the
+    // unified checkpoint or text_proj_in.* / video_connector.* from a standalone connector file.
+    void loadConnector(const std::string& path, const ltx_connector_config* cfg = nullptr) {
+        check(ltx_connector_load(ctx_, path.c_str(), cfg));
+        if (cfg) connCfg_ = *cfg; else ltx_connector_config_default(&connCfg_);
+        connectorLoaded_ = true;
+    }
+    // encodeFromHiddenStates (LTXTextEncoder.swift:574-643): the 49 Gemma-3 hidden states [49][1][T][3840] (bf16 bits)
+    // + the tokenizer's attention mask -> the PrecomputedEmbeddings the generate* calls take. Gemma itself is not part
+    // of this library. nullHiddenStates (same layout) is optional, for CFG.
+    PrecomputedEmbeddings encodeFromHiddenStates(const std::vector<uint16_t>& hiddenStates, const std::vector<int32_t>& attentionMask,
+                                                 int T, bool paddingRight = false, const std::vector<uint16_t>* nullHiddenStates = nullptr,
+                                                 const std::vector<int32_t>* nullAttentionMask = nullptr) {
+        if (!connectorLoaded_) throw LTXError(LTXError::modelNotLoaded, "Model not loaded: text-embedding connector");
+        const size_t need = size_t(connCfg_.states) * T * connCfg_.dim;
+        if (hiddenStates.size() != need || attentionMask.size() != size_t(T))
+            throw LTXError(LTXError::textEncodingFailed, "hidden states must be [states][1][T][dim] bf16 with a [1][T] mask");
+        PrecomputedEmbeddings e;
+        e.S = T;
+        e.promptEmbeddings.resize(size_t(T) * connCfg_.dim);
+        e.promptMask.resize(T);
+        check(ltx_connector_encode(ctx_, hiddenStates.data(), attentionMask.data(), 1, T, paddingRight ? 1 : 0, e.promptEmbeddings.data(),
+                                   e.promptMask.data()));
+        if (nullHiddenStates && nullAttentionMask) {
+            if (nullHiddenStates->size() != need || nullAttentionMask->size() != size_t(T))
+                throw LTXError(LTXError::textEncodingFailed, "null-prompt hidden states must match the prompt's shape");
+            e.nullEmbeddings.resize(size_t(T) * connCfg_.dim);
+            e.nullMask.resize(T);
+            check(ltx_connector_encode(ctx_, nullHiddenStates->data(), nullAttentionMask->data(), 1, T, paddingRight ? 1 : 0,
+                                       e.nullEmbeddings.data(), e.nullMask.data()));
+        }
+        return e;
+    }
 
     // generateVideo (LTXPipeline.swift:586-1046), text-to-video. `noise`: [1,128,F',H',W'] N(0,1) or empty (then
     // config.seed drives generateNoise above).
@@ -317,7 +351,8 @@ class LTXPipeline {
     LTXModel model_;
     LTXQuantizationConfig quant_;
     MemoryOptimizationConfig mem_;
-    bool ditLoaded_ = false, vaeLoaded_ = false;
+    bool ditLoaded_ = false, vaeLoaded_ = false, connectorLoaded_ = false;
+    ltx_connector_config connCfg_{};
 };
 
 }  // namespace ltx
