@@ -209,6 +209,13 @@ int ltx_adain_filter_latent_dev(ltx_ctx* ctx, float* latent, long n_per_channel,
 /* Stage-2 re-noise (LTXPipeline.swift:2644-2647): latent = sigma*noise + (1-sigma)*latent. DEVICE pointers. */
 int ltx_renoise_dev(ltx_ctx* ctx, float* latent, const float* noise, float sigma, long n);
 
+/* One forward with PER-TOKEN timesteps (image-to-video; LTXTransformer.prepareTimestep, LTXTransformer.swift:105-124):
+ * token_timesteps [B][T] f32 sigmas. The adaLN path is evaluated once per distinct value of a batch row (at most 8 distinct
+ * (batch, value) pairs in total - I2V has two per row: 0 for frame 0 and sigma elsewhere). Other arguments as
+ * ltx_dit_forward. HOST pointers. */
+int ltx_dit_forward_tokens(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* context, const float* token_timesteps,
+                           const int32_t* mask, int B, int F, int H, int W, int S, float* velocity);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Text-embedding connector (VideoGemmaTextEncoderModel.encodeFromHiddenStates,
  * LTXTextEncoder.swift:574-643 - call site LTXPipeline.swift:640-700): from the 49 Gemma-3 hidden states to the
@@ -264,6 +271,15 @@ typedef struct ltx_denoise_options {
     const int* stg_blocks;  /* default [29] */
     int n_stg_blocks;
     float ge_gamma;         /* GE momentum (LTXPipeline.swift:924-927) */
+    /* Image-to-video (denoise(...) with conditioningMask / conditionedLatent, LTXPipeline.swift:2191-2401).
+     * cond_latent: the encoded conditioning image [1][C][1][H][W] f32, in the same memory space as `latent` (NULL = text-to-video).
+     * The VAE encoder is outside this library, so the image latent is an input. Frame 0 of `latent` is set to it (:2092-2094),
+     * its tokens run at timestep 0 (:2237-2252) and the Euler step leaves it untouched (:2344-2357).
+     * cond_noise: optional N(0,1) draws [n_sigmas-1][C][1][H][W] for the per-step re-noising of frame 0,
+     * frame0 = cond + image_cond_noise_scale * cond_noise[step] * sigma^2 (:2225-2229); NULL = no re-noising. */
+    const float* cond_latent;
+    float image_cond_noise_scale;
+    const float* cond_noise;
 } ltx_denoise_options;
 
 /* Replaces the denoise loop of generateVideo (LTXPipeline.swift:800-956) / denoise(...) (:2191-2401), T2V.

@@ -213,6 +213,19 @@ class Context:
                                      _ptr(ts), _ptr(m), B, F, H, W, S, _ptr(vel)))
         return vel
 
+    def dit_forward_tokens(self, latent_bf16, context_bf16, token_timesteps, mask, F, H, W):
+        """Per-token timesteps [B,T] (image-to-video, ``prepareTimestep``); otherwise as ``dit_forward``."""
+        B, T, _ = latent_bf16.shape
+        S = context_bf16.shape[1]
+        assert T == F * H * W
+        vel = np.empty((B, T, latent_bf16.shape[2]), dtype=np.float32)
+        ts = np.ascontiguousarray(token_timesteps, dtype=np.float32)
+        assert ts.shape == (B, T)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.int32)
+        self._ck(lib.ltx_dit_forward_tokens(self._h, _ptr(np.ascontiguousarray(latent_bf16)), _ptr(np.ascontiguousarray(context_bf16)),
+                                            _ptr(ts), _ptr(m), B, F, H, W, S, _ptr(vel)))
+        return vel
+
     def dit_forward_dev(self, latent, context, timesteps, mask, F, H, W, velocity, ctx_version=0, mask_all_ones=False):
         B, T = latent.shape[0], latent.shape[1]
         S = context.shape[1]
@@ -347,10 +360,17 @@ class Context:
 
     # ---- denoise loop ----
     @staticmethod
-    def _options(cfg_scale=1.0, guidance_rescale=0.0, stg_scale=0.0, stg_blocks=(29,), ge_gamma=0.0):
+    def _options(cfg_scale=1.0, guidance_rescale=0.0, stg_scale=0.0, stg_blocks=(29,), ge_gamma=0.0, cond_latent=None,
+                 image_cond_noise_scale=0.0, cond_noise=None):
+        """cond_latent / cond_noise (image-to-video): numpy arrays for the host entry point, torch tensors for the device one."""
         arr = (C.c_int * max(1, len(stg_blocks)))(*stg_blocks)
-        o = DenoiseOptions(cfg_scale, guidance_rescale, stg_scale, C.cast(arr, C.POINTER(C.c_int)), len(stg_blocks), ge_gamma)
-        o._keep = arr
+        if isinstance(cond_latent, np.ndarray):
+            cond_latent = np.ascontiguousarray(cond_latent, dtype=np.float32)
+        if isinstance(cond_noise, np.ndarray):
+            cond_noise = np.ascontiguousarray(cond_noise, dtype=np.float32)
+        o = DenoiseOptions(cfg_scale, guidance_rescale, stg_scale, C.cast(arr, C.POINTER(C.c_int)), len(stg_blocks), ge_gamma,
+                           _ptr(cond_latent), image_cond_noise_scale, _ptr(cond_noise))
+        o._keep = (arr, cond_latent, cond_noise)
         return o
 
     def denoise(self, latent, sigmas_, context_bf16, mask, F, H, W, on_progress=None, **opts):

@@ -30,7 +30,8 @@ class DenoiseOptions(C.Structure):
     """``ltx_denoise_options``: the sampling knobs of ``LTXVideoGenerationConfig`` (LTXConfig.swift:216-300)."""
 
     _fields_ = [("cfg_scale", C.c_float), ("guidance_rescale", C.c_float), ("stg_scale", C.c_float),
-                ("stg_blocks", C.POINTER(C.c_int)), ("n_stg_blocks", C.c_int), ("ge_gamma", C.c_float)]
+                ("stg_blocks", C.POINTER(C.c_int)), ("n_stg_blocks", C.c_int), ("ge_gamma", C.c_float),
+                ("cond_latent", C.c_void_p), ("image_cond_noise_scale", C.c_float), ("cond_noise", C.c_void_p)]
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_float, C.c_void_p)
@@ -94,6 +95,7 @@ SIGNATURES = {
     "ltx_dit_quantize": (_i, [_vp, _i, _i]),
     "ltx_dit_fuse_lora": (_i, [_vp, C.c_char_p, _f, _ip]),
     "ltx_dit_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ltx_dit_forward_tokens": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ltx_dit_forward_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _vp]),
     "ltx_dit_set_cross_attn_scale": (_i, [_vp, _f, _i, _i]),
     "ltx_dit_set_stg": (_i, [_vp, _ip, _i, _i, _i]),

@@ -2,6 +2,9 @@
 // exceptions into an ltx_status + message; nothing here computes on the CPU on behalf of the GPU path.
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "../../include/ltxhip.h"
 #include "attention.h"
 #include "connector.h"
@@ -407,6 +410,70 @@ int ltx_dit_forward(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* contex
     });
 }
 
+int ltx_dit_forward_tokens(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* context, const float* token_timesteps,
+                           const int32_t* mask, int B, int F, int H, int W, int S, float* velocity) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        DiTModel* m = need_dit(ctx);
+        LTX_REQUIRE(latent && context && token_timesteps && velocity && B >= 1 && F >= 1 && H >= 1 && W >= 1 && S >= 1,
+                    "ltx_dit_forward_tokens: bad arguments");
+        const long T = (long)F * H * W;
+        // distinct timestep values per batch row -> groups (order of first appearance); G = the largest count
+        std::vector<std::vector<float>> uniq(B);
+        std::vector<int32_t> rowmap((size_t)B * T);
+        int G = 1;
+        for (int b = 0; b < B; ++b) {
+            for (long t = 0; t < T; ++t) {
+                const float v = token_timesteps[(size_t)b * T + t];
+                size_t g = 0;
+                while (g < uniq[b].size() && uniq[b][g] != v) ++g;
+                if (g == uniq[b].size()) uniq[b].push_back(v);
+                rowmap[(size_t)b * T + t] = (int32_t)g;
+                LTX_REQUIRE(uniq[b].size() <= 8, "ltx_dit_forward_tokens: more than 8 distinct timesteps in batch row %d", b);
+            }
+            G = std::max(G, (int)uniq[b].size());
+        }
+        LTX_REQUIRE(B * G <= 8, "ltx_dit_forward_tokens: batch x distinct timesteps = %d exceeds 8", B * G);
+        std::vector<float> ts((size_t)B * G);
+        for (int b = 0; b < B; ++b)
+            for (int g = 0; g < G; ++g) ts[(size_t)b * G + g] = uniq[b][g < (int)uniq[b].size() ? g : 0];
+        for (int b = 0; b < B; ++b)
+            for (long t = 0; t < T; ++t) rowmap[(size_t)b * T + t] += b * G;
+        const size_t n_lat = (size_t)B * T * m->cfg.in_channels * 2;
+        const size_t n_ctx = (size_t)B * S * m->cfg.caption_channels * 2;
+        const size_t n_vel = (size_t)B * T * m->cfg.out_channels * 4;
+        ctx->h2d[0].ensure(n_lat);
+        ctx->h2d[1].ensure(n_ctx);
+        ctx->h2d[2].ensure(8 * 4);
+        ctx->h2d[3].ensure((size_t)B * S * 4);
+        ctx->h2d[4].ensure(n_vel);
+        ctx->dn_rowmap.ensure(std::max((size_t)B * T * 4, (size_t)2 * T * 4));
+        hipStream_t st = ctx->stream;
+        int all_ones = 1;
+        if (mask)
+            for (long i = 0; i < (long)B * S; ++i)
+                if (mask[i] != 1) { all_ones = 0; break; }
+        HIP_CHECK(hipMemcpyAsync(ctx->h2d[0].p, latent, n_lat, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(ctx->h2d[1].p, context, n_ctx, hipMemcpyHostToDevice, st));
+        if (mask) HIP_CHECK(hipMemcpyAsync(ctx->h2d[3].p, mask, (size_t)B * S * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(ctx->h2d[2].p, ts.data(), ts.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(ctx->dn_rowmap.p, rowmap.data(), rowmap.size() * 4, hipMemcpyHostToDevice, st));
+        DiTForwardArgs a;
+        a.latent = ctx->h2d[0].as<bf16_t>();
+        a.context = ctx->h2d[1].as<bf16_t>();
+        a.timesteps = ctx->h2d[2].as<float>();
+        a.mask = mask ? ctx->h2d[3].as<int32_t>() : nullptr;
+        a.mask_all_ones = all_ones;
+        a.B = B; a.F = F; a.H = H; a.W = W; a.S = S;
+        a.n_groups = G;
+        a.row_map = ctx->dn_rowmap.as<int32_t>();
+        a.velocity = ctx->h2d[4].as<float>();
+        dit_forward(ctx, m, a);
+        HIP_CHECK(hipMemcpyAsync(velocity, ctx->h2d[4].p, n_vel, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));  // also keeps ts / rowmap alive until the copies are done
+    });
+}
+
 int ltx_dit_set_cross_attn_scale(ltx_ctx* ctx, float scale, int first_block, int last_block) {
     if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
     return guarded(ctx, [&] {
@@ -654,6 +721,9 @@ static void fill_params(DenoiseParams& p, const ltx_denoise_options* o) {
     p.stg_blocks = o->stg_blocks;
     p.n_stg = o->n_stg_blocks;
     p.ge_gamma = o->ge_gamma;
+    p.cond_latent = o->cond_latent;  // device variant: used as given; host variant: replaced by staged copies below
+    p.image_cond_noise_scale = o->image_cond_noise_scale;
+    p.cond_noise = o->cond_noise;
 }
 
 int ltx_denoise_dev(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* sigmas, int n_sigmas,
@@ -704,6 +774,17 @@ int ltx_denoise(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* s
         p.mask_all_ones = all_ones; p.S = S;
         p.ctx_version = (hv >> 3) | 1;  // room for the per-pass sub-keys derived in denoise_run
         fill_params(p, opt);
+        if (opt && opt->cond_latent) {  // image-to-video: stage the image latent (and the re-noising draws) on the device
+            const size_t n_c = (size_t)m->cfg.in_channels * H * W * 4;
+            ctx->i2v_cond.ensure(n_c);
+            HIP_CHECK(hipMemcpyAsync(ctx->i2v_cond.p, opt->cond_latent, n_c, hipMemcpyHostToDevice, st));
+            p.cond_latent = ctx->i2v_cond.as<float>();
+            if (opt->cond_noise) {
+                ctx->i2v_noise.ensure(n_c * (n_sigmas - 1));
+                HIP_CHECK(hipMemcpyAsync(ctx->i2v_noise.p, opt->cond_noise, n_c * (n_sigmas - 1), hipMemcpyHostToDevice, st));
+                p.cond_noise = ctx->i2v_noise.as<float>();
+            }
+        }
         p.progress = cb; p.user = user;
         denoise_run(ctx, p);
         HIP_CHECK(hipMemcpyAsync(latent, ctx->h2d[5].p, n_lat, hipMemcpyDeviceToHost, st));

@@ -209,13 +209,13 @@ void ensure_workspace(DiTModel* m, int B, int T, hipStream_t st) {
     if (m->ws_vt.ensure((size_t)B * D * Tpad * 2) || Tpad != m->ws_Tpad) HIP_CHECK(hipMemsetAsync(m->ws_vt.p, 0, m->ws_vt.bytes, st));
     m->ws_ao.ensure(rows * D * 2);
     m->ws_ffh.ensure(rows * 4 * D * 2);
-    m->ws_ts.ensure(B * 4);
-    m->ws_emb256.ensure(B * 256 * 4);
-    m->ws_h1.ensure((size_t)B * D * 4);
-    m->ws_embts.ensure((size_t)B * D * 4);
-    m->ws_ada.ensure((size_t)B * 6 * D * 4);
-    m->ws_mod.ensure((size_t)B * m->L * 6 * D * 4);
-    m->ws_modout.ensure((size_t)B * 2 * D * 4);
+    m->ws_ts.ensure(8 * 4);
+    m->ws_emb256.ensure(8 * 256 * 4);
+    m->ws_h1.ensure((size_t)8 * D * 4);
+    m->ws_embts.ensure((size_t)8 * D * 4);
+    m->ws_ada.ensure((size_t)8 * 6 * D * 4);
+    m->ws_mod.ensure((size_t)8 * m->L * 6 * D * 4);
+    m->ws_modout.ensure((size_t)8 * 2 * D * 4);
     m->ws_rows = (int)rows;
     m->ws_B = B;
     m->ws_Tpad = Tpad;
@@ -303,6 +303,11 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     const int D = m->D, L = m->L, B = a.B;
     const int T = a.F * a.H * a.W;
     LTX_REQUIRE(B >= 1 && B <= 8 && T >= 1 && a.S >= 1, "dit_forward: bad shapes B=%d T=%d S=%d", B, T, a.S);
+    const int G = a.n_groups < 1 ? 1 : a.n_groups;
+    const int BG = B * G;  // rows of the timestep path / modulation tables
+    LTX_REQUIRE(BG <= 8, "dit_forward: batch x timestep groups = %d exceeds 8", BG);
+    LTX_REQUIRE(G == 1 || a.row_map, "dit_forward: timestep groups need a row map");
+    const int32_t* rmap = G > 1 ? a.row_map : nullptr;
     LTX_REQUIRE(a.latent && a.context && a.timesteps && a.velocity, "dit_forward: null argument");
     hipStream_t st = ctx->stream;
     const long rows = (long)B * T;
@@ -336,15 +341,15 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
         gemm_linear(a.latent, m->cfg.in_channels, m->patchify, (int)rows, e, st);
     }
     // 2. timestep path in f32 activations x bf16 weights (LTXTimestepEmbedding.swift:62-124)
-    launch_timestep_embedding(a.timesteps, m->cfg.timestep_scale_multiplier, m->ws_emb256.as<float>(), B, 256, st);
-    launch_gemv_f32(m->ws_emb256.as<float>(), 256, m->ada_l1.w, 256, m->ada_l1.b, m->ws_h1.as<float>(), D, B, D, 256, LTX_ACT_NONE, st);
-    launch_gemv_f32(m->ws_h1.as<float>(), D, m->ada_l2.w, D, m->ada_l2.b, m->ws_embts.as<float>(), D, B, D, D, LTX_ACT_SILU, st);
-    launch_gemv_f32(m->ws_embts.as<float>(), D, m->ada_lin.w, D, m->ada_lin.b, m->ws_ada.as<float>(), 6 * D, B, 6 * D, D, LTX_ACT_SILU, st);
-    launch_make_mod(m->sst_blocks, m->ws_ada.as<float>(), mod, B, L, 6, D, st);
+    launch_timestep_embedding(a.timesteps, m->cfg.timestep_scale_multiplier, m->ws_emb256.as<float>(), BG, 256, st);
+    launch_gemv_f32(m->ws_emb256.as<float>(), 256, m->ada_l1.w, 256, m->ada_l1.b, m->ws_h1.as<float>(), D, BG, D, 256, LTX_ACT_NONE, st);
+    launch_gemv_f32(m->ws_h1.as<float>(), D, m->ada_l2.w, D, m->ada_l2.b, m->ws_embts.as<float>(), D, BG, D, D, LTX_ACT_SILU, st);
+    launch_gemv_f32(m->ws_embts.as<float>(), D, m->ada_lin.w, D, m->ada_lin.b, m->ws_ada.as<float>(), 6 * D, BG, 6 * D, D, LTX_ACT_SILU, st);
+    launch_make_mod(m->sst_blocks, m->ws_ada.as<float>(), mod, BG, L, 6, D, st);
     // output modulation: shift = SST_out[0] + emb_ts, scale = SST_out[1] + emb_ts (LTXTransformer.swift:208-224)
     for (int j = 0; j < 2; ++j) {
         // mod_out[b][j][:] = sst_out[j] + emb_ts[b]
-        for (int b = 0; b < B; ++b)
+        for (int b = 0; b < BG; ++b)
             launch_lincomb(m->sst_out + (long)j * D, m->ws_embts.as<float>() + (long)b * D, 1.f, 1.f,
                            m->ws_modout.as<float>() + ((long)b * 2 + j) * D, D, st);
     }
@@ -354,7 +359,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
         const DiTBlock& blk = m->blocks[l];
         const float* ml = mod + (long)l * 6 * D;  // rows: 0 shift_msa 1 scale_msa 2 gate_msa 3 shift_mlp 4 scale_mlp 5 gate_mlp
         if (!blk.skip_attn) {
-            launch_norm_mod(x, D, ml + 1 * D, ml + 0 * D, mod_bs, T, xn, D, (int)rows, D, LTX_NORM_RMS, eps, l == 0 ? 1 : 0, st);
+            launch_norm_mod(x, D, ml + 1 * D, ml + 0 * D, mod_bs, T, xn, D, (int)rows, D, LTX_NORM_RMS, eps, l == 0 ? 1 : 0, st, rmap);
             GemmEpilogue eqk;
             eqk.out_f32 = qk;
             eqk.ld_f32 = 2 * D;
@@ -376,6 +381,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             eo.gate = ml + 2 * D;
             eo.gate_bstride = mod_bs;
             eo.rows_per_batch = T;
+            eo.gate_rowmap = rmap;
             eo.out_bf16 = xb;
             eo.ld_bf16 = D;
             gemm_linear(ao, D, blk.o1, (int)rows, eo, st);
@@ -407,7 +413,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             gemm_linear(ao, D, blk.o2, (int)rows, eo, st);
         }
         if (!blk.skip_ff) {
-            launch_norm_mod(x, D, ml + 4 * D, ml + 3 * D, mod_bs, T, xn, D, (int)rows, D, LTX_NORM_RMS, eps, 0, st);
+            launch_norm_mod(x, D, ml + 4 * D, ml + 3 * D, mod_bs, T, xn, D, (int)rows, D, LTX_NORM_RMS, eps, 0, st, rmap);
             GemmEpilogue e1;
             e1.out_bf16 = ffh;
             e1.ld_bf16 = 4 * D;
@@ -420,6 +426,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             e2.gate = ml + 5 * D;
             e2.gate_bstride = mod_bs;
             e2.rows_per_batch = T;
+            e2.gate_rowmap = rmap;
             e2.out_bf16 = xb;
             e2.ld_bf16 = D;
             gemm_linear(ffh, 4 * D, blk.ff2, (int)rows, e2, st);
@@ -430,7 +437,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     // 6. output head: LayerNorm (no affine) * (1+scale) + shift -> proj_out (LTXTransformer.swift:208-224)
     {
         const float* mo = m->ws_modout.as<float>();
-        launch_norm_mod(x, D, mo + D, mo, 2L * D, T, xn, D, (int)rows, D, LTX_NORM_LAYER, eps, 0, st);
+        launch_norm_mod(x, D, mo + D, mo, 2L * D, T, xn, D, (int)rows, D, LTX_NORM_LAYER, eps, 0, st, rmap);
         GemmEpilogue e;
         e.out_f32 = a.velocity;
         e.ld_f32 = m->cfg.out_channels;

@@ -87,7 +87,12 @@ void dit_init_synthetic(ltx_ctx* ctx, DiTModel* m, uint64_t seed);
 struct DiTForwardArgs {
     const bf16_t* latent = nullptr;   // device [B][T][in_channels] bf16
     const bf16_t* context = nullptr;  // device [B][S][caption_channels] bf16
-    const float* timesteps = nullptr; // device [B] f32 (sigma, unscaled)
+    const float* timesteps = nullptr; // device [B*n_groups] f32 (sigma, unscaled): group g of batch element b at b*n_groups+g
+    // per-token timesteps (image-to-video, LTXTransformer.swift:105-124, LTXPipeline.swift:2237-2252): tokens are
+    // partitioned into n_groups timestep groups; row_map[b*T+t] = b*n_groups + group(b,t). The adaLN tables are built
+    // per (b, group) row and the kernels pick their row through the map. n_groups = 1, row_map = null: one timestep per b.
+    int n_groups = 1;
+    const int32_t* row_map = nullptr;  // device [B][T] int32
     const int32_t* mask = nullptr;    // device [B][S] int32 or null
     int mask_all_ones = 0;            // host hint: skip the additive bias entirely (bit-identical: +0.0)
     int B = 1, F = 0, H = 0, W = 0, S = 0;

@@ -13,7 +13,7 @@ enum { LTX_NORM_RMS = 0, LTX_NORM_LAYER = 1 };
 // reference, so MLXFast.rmsNorm returns bf16 there - SURVEY R10 dtype column).
 void launch_norm_mod(const float* x, long ldx, const float* scale, const float* shift, long mod_bstride,
                      int rows_per_batch, bf16_t* out, long ldo, int rows, int D, int norm_kind, float eps,
-                     int round_norm_bf16, hipStream_t stream);
+                     int round_norm_bf16, hipStream_t stream, const int32_t* row_map = nullptr);
 
 // q/k RMSNorm across ALL heads with learnable weight, then split-RoPE per head (LTXAttention.swift:179-189,
 // LTXRoPE.swift:84-149). x: f32 [rows][ldx] (D valid columns), w: f32 [D], cos/sin: f32 [T][D/2] indexed by
@@ -44,7 +44,12 @@ void launch_patchify_bf16(const float* latent, bf16_t* tokens, int B, int C, int
 void launch_unpatchify_f32(const float* tokens, float* latent, int B, int C, int T, hipStream_t stream);
 
 // Euler flow-matching update (LTXScheduler.swift:305-327): den = x - s*v; x' = s_next>0 ? den + s_next*(x-den)/s : den
-void launch_euler_step(float* latent, const float* velocity, float sigma, float sigma_next, long n, hipStream_t stream);
+void launch_euler_step(float* latent, const float* velocity, float sigma, float sigma_next, long n, hipStream_t stream,
+                       int skip_hw = 0, int frames = 1);
+// image-to-video helpers (LTXPipeline.swift:2092-2094, :2225-2252)
+void launch_set_frame0(float* latent, const float* cond, const float* noise, float scale, float sigma2, int C, int F, int HW,
+                       hipStream_t stream);
+void launch_i2v_rowmap(int32_t* row_map, int B, int T, int first, int G, hipStream_t stream);
 // CFG combine v = cond + (scale-1)*(cond-uncond) (LatentUtils.swift:131-141)
 void launch_cfg_combine(const float* uncond, const float* cond, float scale, float* out, long n, hipStream_t stream);
 // out = a + s*(a - b)   (STG: LTXPipeline.swift:920) ; out = g*(a-b)+b (GE: :924-927) share one kernel

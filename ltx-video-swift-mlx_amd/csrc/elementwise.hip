@@ -27,11 +27,12 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift, long mod_bstride,
                                                        int rows_per_batch, bf16_t* __restrict__ out, long ldo, int D,
-                                                       int norm_kind, float eps, int round_norm_bf16) {
+                                                       int norm_kind, float eps, int round_norm_bf16,
+                                                       const int32_t* __restrict__ row_map) {
     __shared__ float red[4];
     const int row = blockIdx.x;
     const float* xr = x + (long)row * ldx;
-    const long b = row / rows_per_batch;
+    const long b = row_map ? row_map[row] : row / rows_per_batch;  // modulation row (per-token timestep groups: I2V)
     const float* sc = scale ? scale + b * mod_bstride : nullptr;
     const float* sh = shift ? shift + b * mod_bstride : nullptr;
     f32x4 v[NV], s4[NV], h4[NV];
@@ -276,10 +277,13 @@ __global__ __launch_bounds__(256) void unpatchify_f32_kernel(const float* __rest
     }
 }
 
+// skip_hw > 0: image-to-video slice step - frame 0 of every channel ([C][F][H*W] layout, skip_hw = H*W, frames = F) keeps its
+// value (LTXPipeline.swift:2344-2357)
 __global__ void euler_step_kernel(float* __restrict__ latent, const float* __restrict__ vel, float sigma,
-                                  float sigma_next, long n) {
+                                  float sigma_next, long n, int skip_hw, int frames) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (skip_hw > 0 && (i / skip_hw) % frames == 0) return;
     const float x = latent[i];
     const float den = x - sigma * vel[i];
     latent[i] = (sigma_next > 0.f) ? den + sigma_next * (x - den) / sigma : den;
@@ -535,13 +539,13 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 void launch_norm_mod(const float* x, long ldx, const float* scale, const float* shift, long mod_bstride,
                      int rows_per_batch, bf16_t* out, long ldo, int rows, int D, int norm_kind, float eps,
-                     int round_norm_bf16, hipStream_t stream) {
+                     int round_norm_bf16, hipStream_t stream, const int32_t* row_map) {
     LTX_REQUIRE(D % 4 == 0 && D <= MAXV * 1024 && ldx % 4 == 0 && ldo % 4 == 0, "norm_mod: D=%d ldx=%ld ldo=%ld", D, ldx, ldo);
     LTX_REQUIRE((scale == nullptr) == (shift == nullptr), "norm_mod: scale/shift must both be set or both null");
     const int rpb = rows_per_batch < 1 ? 1 : rows_per_batch;
 #define LTX_NORM_LAUNCH(NV)                                                                                              \
     hipLaunchKernelGGL(norm_mod_kernel<NV>, dim3(rows), dim3(256), 0, stream, x, ldx, scale, shift, mod_bstride, rpb, out, \
-                       ldo, D, norm_kind, eps, round_norm_bf16)
+                       ldo, D, norm_kind, eps, round_norm_bf16, row_map)
     if (D <= 1024) LTX_NORM_LAUNCH(1);
     else if (D <= 2048) LTX_NORM_LAUNCH(2);
     else if (D <= 4096) LTX_NORM_LAUNCH(4);
@@ -600,8 +604,45 @@ void launch_unpatchify_f32(const float* tokens, float* latent, int B, int C, int
     hipLaunchKernelGGL(unpatchify_f32_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, stream, tokens, latent, C, T);
     HIP_CHECK(hipGetLastError());
 }
-void launch_euler_step(float* latent, const float* velocity, float sigma, float sigma_next, long n, hipStream_t stream) {
-    hipLaunchKernelGGL(euler_step_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, latent, velocity, sigma, sigma_next, n);
+void launch_euler_step(float* latent, const float* velocity, float sigma, float sigma_next, long n, hipStream_t stream, int skip_hw,
+                       int frames) {
+    hipLaunchKernelGGL(euler_step_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, latent, velocity, sigma, sigma_next, n, skip_hw,
+                       frames < 1 ? 1 : frames);
+    HIP_CHECK(hipGetLastError());
+}
+
+namespace {
+// latent[c][0][hw] = cond[c][hw] (+ s * noise[c][hw])   (LTXPipeline.swift:2092-2094, :2225-2229)
+// the reference evaluates cond + (scale * noise) * sigma^2 as three separate f32 ops: no fused multiply-add here
+__global__ void set_frame0_kernel(float* __restrict__ latent, const float* __restrict__ cond, const float* __restrict__ noise,
+                                  float scale, float sigma2, int C, int F, int HW) {
+#pragma clang fp contract(off)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)C * HW) return;
+    const long c = i / HW, hw = i - c * HW;
+    float v = cond[i];
+    if (noise) {
+        const float a = scale * noise[i];
+        const float b = a * sigma2;
+        v = v + b;
+    }
+    latent[(c * F) * HW + hw] = v;
+}
+// row_map[b*T + t] = b*G + (t < first ? 1 : 0): tokens of frame 0 use timestep group 1 (sigma 0), the rest group 0
+__global__ void i2v_rowmap_kernel(int32_t* __restrict__ row_map, int B, int T, int first, int G) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * T) return;
+    const int b = (int)(i / T), t = (int)(i - (long)b * T);
+    row_map[i] = b * G + (t < first ? 1 : 0);
+}
+}  // namespace
+void launch_set_frame0(float* latent, const float* cond, const float* noise, float scale, float sigma2, int C, int F, int HW,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(set_frame0_kernel, dim3(cdiv((long)C * HW, 256)), dim3(256), 0, stream, latent, cond, noise, scale, sigma2, C, F, HW);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_i2v_rowmap(int32_t* row_map, int B, int T, int first, int G, hipStream_t stream) {
+    hipLaunchKernelGGL(i2v_rowmap_kernel, dim3(cdiv((long)B * T, 256)), dim3(256), 0, stream, row_map, B, T, first, G);
     HIP_CHECK(hipGetLastError());
 }
 void launch_cfg_combine(const float* uncond, const float* cond, float scale, float* out, long n, hipStream_t stream) {

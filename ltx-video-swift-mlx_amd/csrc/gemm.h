@@ -26,6 +26,7 @@ struct GemmEpilogue {
     const float* gate = nullptr;
     long gate_bstride = 0;
     int rows_per_batch = 1;
+    const int32_t* gate_rowmap = nullptr;  // optional: gate row of output row m = gate_rowmap[m] (per-token timestep groups, I2V)
     float gate_scalar = 1.0f;
     const float* resid_src = nullptr;  // defaults to out_f32 (in-place) when null
     long ld_resid = 0;

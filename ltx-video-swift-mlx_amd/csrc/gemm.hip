@@ -99,7 +99,7 @@ LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const G
                 gm = gm < g.M ? gm : g.M - 1;
                 rs[buf][it] = *(const f32x4*)(rbase + (long)gm * rld + gn_w + c4);
                 if (ep.gate)
-                    gt[buf][it] = *(const f32x4*)(ep.gate + (long)(gm / ep.rows_per_batch) * ep.gate_bstride + gn_w + c4);
+                    gt[buf][it] = *(const f32x4*)(ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[gm] : gm / ep.rows_per_batch) * ep.gate_bstride + gn_w + c4);
                 else
                     gt[buf][it] = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
             }
@@ -235,7 +235,7 @@ LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const G
                 const float* rs = (ep.resid_src ? ep.resid_src + (long)gm * ep.ld_resid : ep.out_f32 + (long)gm * ep.ld_f32) + gn;
                 f32x4 gt;
                 if (ep.gate) {
-                    const float* gp = ep.gate + (long)(gm / ep.rows_per_batch) * ep.gate_bstride + gn;
+                    const float* gp = ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[gm] : gm / ep.rows_per_batch) * ep.gate_bstride + gn;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) gt[e] = (e < nv) ? gp[e] : 0.f;
                 } else {
@@ -964,7 +964,7 @@ void launch_v2(const GemmArgs& a, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     if (a.split_k > 1) {
         const GemmEpilogue& e = a.ep;
-        LTX_REQUIRE(a.split_ws && a.N % 4 == 0 && !e.d2s && !e.gate && !e.bias_m && !e.round_bf16, "gemm split-K: unsupported epilogue");
+        LTX_REQUIRE(a.split_ws && a.N % 4 == 0 && !e.d2s && !e.gate && !e.gate_rowmap && !e.bias_m && !e.round_bf16, "gemm split-K: unsupported epilogue");
         LTX_REQUIRE(a.split_k <= a.K / BK, "gemm split-K: %d splits for %d K-tiles", a.split_k, a.K / BK);
     }
     hipLaunchKernelGGL((gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN>), dim3(tiles, a.split_k > 1 ? a.split_k : 1),

@@ -24,7 +24,16 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
     ctx->dn_vel2.ensure((size_t)n * 4);
     ctx->dn_vel3.ensure((size_t)n * 4);
     ctx->dn_prev.ensure((size_t)n * 4);
-    ctx->dn_ts.ensure(2 * 4);
+    ctx->dn_ts.ensure(8 * 4);
+    const bool i2v = p.cond_latent != nullptr;
+    const int HW = p.H * p.W;
+    const int G = i2v ? 2 : 1;  // timestep groups per batch element: 0 = sigma, 1 = frame-0 tokens at 0
+    if (i2v) {
+        LTX_REQUIRE(p.F >= 2, "denoise: image-to-video needs at least two latent frames");
+        ctx->dn_rowmap.ensure((size_t)2 * T * 4);
+        launch_i2v_rowmap(ctx->dn_rowmap.as<int32_t>(), 2, T, HW, G, st);
+        launch_set_frame0(p.latent, p.cond_latent, nullptr, 0.f, 0.f, C, p.F, HW, st);  // LTXPipeline.swift:2092-2094
+    }
     ctx->dn_stats.ensure(16 * 4);
     bf16_t* tokens = ctx->dn_tokens.as<bf16_t>();
     float* vel_tok = ctx->dn_vel_tok.as<float>();
@@ -49,6 +58,10 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
         a.B = b; a.F = p.F; a.H = p.H; a.W = p.W; a.S = p.S;
         a.ctx_version = version;
         a.velocity = out_tok;
+        if (i2v) {
+            a.n_groups = G;
+            a.row_map = ctx->dn_rowmap.as<int32_t>();
+        }
         dit_forward(ctx, m, a);
     };
 
@@ -56,7 +69,18 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
     for (int step = 0; step < steps; ++step) {
         const float sigma = p.sigmas[step], sigma_next = p.sigmas[step + 1];
         if (p.progress) p.progress(step, steps, sigma, p.user);  // before the forward (LTXPipeline.swift:805-810)
-        launch_fill_const_f32(ctx->dn_ts.as<float>(), 2, sigma, st);
+        if (i2v) {
+            // re-noise the conditioned frame (LTXPipeline.swift:2225-2229), then per-token timesteps sigma*(1-mask) (:2237-2252)
+            if (p.image_cond_noise_scale > 0.f && sigma > 0.f && p.cond_noise)
+                launch_set_frame0(p.latent, p.cond_latent, p.cond_noise + (size_t)step * C * HW, p.image_cond_noise_scale, sigma * sigma, C,
+                                  p.F, HW, st);
+            float* ts = ctx->dn_ts.as<float>();  // [b][group] = {sigma, 0, sigma, 0}
+            launch_fill_const_f32(ts, 4, sigma, st);
+            launch_fill_const_f32(ts + 1, 1, 0.f, st);
+            launch_fill_const_f32(ts + 3, 1, 0.f, st);
+        } else {
+            launch_fill_const_f32(ctx->dn_ts.as<float>(), 2, sigma, st);
+        }
         // patchify + .asType(.bfloat16) (LTXPipeline.swift:815)
         launch_patchify_bf16(p.latent, tokens, 1, C, T, st);
         if (B == 2) HIP_CHECK(hipMemcpyAsync(tokens + n, tokens, (size_t)n * 2, hipMemcpyDeviceToDevice, st));
@@ -102,6 +126,6 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
             HIP_CHECK(hipMemcpyAsync(prev, v, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
             have_prev = true;
         }
-        launch_euler_step(p.latent, v, sigma, sigma_next, n, st);
+        launch_euler_step(p.latent, v, sigma, sigma_next, n, st, i2v ? HW : 0, p.F);  // I2V: frames 1+ only (:2344-2357)
     }
 }

@@ -22,6 +22,13 @@ struct DenoiseParams {
     const int* stg_blocks = nullptr;
     int n_stg = 0;
     float ge_gamma = 0.0f;
+    // image-to-video (denoise(...) with conditioningMask / conditionedLatent, LTXPipeline.swift:2191-2401): the encoded image
+    // latent [1][C][1][H][W] (device f32; the VAE encoder is outside this path, so it is an input like the text embeddings).
+    // Frame 0 is set to it, optionally re-noised per step with cond_noise[step] * image_cond_noise_scale * sigma^2, its tokens
+    // run at timestep 0 and the Euler step leaves it untouched.
+    const float* cond_latent = nullptr;
+    float image_cond_noise_scale = 0.0f;
+    const float* cond_noise = nullptr;  // device f32 [n_sigmas-1][C][1][H][W] N(0,1) draws, or null (no injection)
     ltx_progress_fn progress = nullptr;
     void* user = nullptr;
     // multi-GPU CFG sharding hook (config 3): when set, this rank evaluates only branch `cfg_branch`

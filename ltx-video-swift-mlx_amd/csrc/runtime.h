@@ -138,6 +138,8 @@ struct ltx_ctx {
     Profiler prof;
     // denoise-loop scratch (device)
     DevBuf dn_tokens, dn_vel_tok, dn_vel, dn_vel2, dn_vel3, dn_prev, dn_ts, dn_stats, dn_lat2;
+    DevBuf dn_rowmap;  // I2V token -> timestep-group map
+    DevBuf i2v_cond, i2v_noise;  // staged image latent / re-noising draws of the host-pointer denoise entry
     DevBuf op_ws;  // split-K workspace of the kernel-level test hook
 };
 

@@ -97,6 +97,7 @@ struct LTXVideoGenerationConfig {
     float cfgScale = 1.0f;
     std::optional<uint64_t> seed;
     float guidanceRescale = 0.0f, crossAttentionScale = 1.0f, geGamma = 0.0f, stgScale = 0.0f;
+    float imageCondNoiseScale = 0.0f;  // LTXConfig.swift:271,289
     std::vector<int> stgBlocks{29};
     bool twoStage = false;
     void validate() const {
@@ -137,6 +138,14 @@ struct PrecomputedEmbeddings {
     std::vector<uint16_t> nullEmbeddings;    // optional (CFG)
     std::vector<int32_t> nullMask;           // optional; defaults to zeros (LTXPipeline.swift:642)
     int S = 0;
+};
+
+// Image-to-video conditioning (generateVideo(image:...), LTXPipeline.swift:2000-2125): the VAE-encoded image latent
+// [1][128][1][H'][W'] is an input (the encoder is outside this path); injectionNoise = [numSteps][128][1][H'][W'] N(0,1) draws
+// for the per-step re-noising of frame 0, used when config.imageCondNoiseScale > 0 (empty = none).
+struct ImageConditioning {
+    std::vector<float> imageLatent;
+    std::vector<float> injectionNoise;
 };
 
 // Deterministic N(0,1) generator used when the caller supplies a seed instead of a noise tensor.
@@ -223,13 +232,20 @@ class LTXPipeline {
     // config.seed drives generateNoise above).
     VideoGenerationResult generateVideo(const LTXVideoGenerationConfig& config, const PrecomputedEmbeddings& emb,
                                         const std::vector<float>& noise = {}, GenerationProgressCallback onProgress = nullptr,
-                                        bool profile = false, const std::vector<float>& vaeNoise = {}) {
+                                        bool profile = false, const std::vector<float>& vaeNoise = {},
+                                        const ImageConditioning* image = nullptr) {
         config.validate();
         if (!isLoaded()) throw LTXError(LTXError::modelNotLoaded, "Models not loaded. Call loadModels() first.");
         const auto t0 = std::chrono::steady_clock::now();
         GenerationTimings timings;
         const bool useCFG = config.cfgScale > 1.0f;
         const int F = config.latentFrames(), H = config.latentHeight(), W = config.latentWidth();
+        if (image) {
+            if (image->imageLatent.size() != size_t(128) * H * W)
+                throw LTXError(LTXError::invalidConfiguration, "image latent must be [1][128][1][H/32][W/32]");
+            if (!image->injectionNoise.empty() && image->injectionNoise.size() != size_t(config.numSteps) * 128 * H * W)
+                throw LTXError(LTXError::invalidConfiguration, "injection noise must hold numSteps draws of the image latent's shape");
+        }
         const size_t n = size_t(128) * F * H * W;
         std::vector<float> latent = noise.empty() ? generateNoise(n, config.seed.value_or(0)) : noise;
         if (latent.size() != n) throw LTXError(LTXError::invalidConfiguration, "noise tensor has the wrong size");
@@ -244,6 +260,11 @@ class LTXPipeline {
         buildContext(emb, useCFG, ctxBits, mask);
         ltx_denoise_options opt{config.cfgScale, config.guidanceRescale, config.stgScale, config.stgBlocks.data(),
                                 int(config.stgBlocks.size()), config.geGamma};
+        if (image) {  // per-token timesteps + frame-0 slice Euler (LTXPipeline.swift:2191-2401)
+            opt.cond_latent = image->imageLatent.data();
+            opt.image_cond_noise_scale = config.imageCondNoiseScale;
+            opt.cond_noise = image->injectionNoise.empty() ? nullptr : image->injectionNoise.data();
+        }
         struct Box { GenerationProgressCallback cb; GenerationTimings* t; std::chrono::steady_clock::time_point last; } box{onProgress, &timings, t0};
         auto thunk = [](int step, int total, float sigma, void* user) {
             Box* b = static_cast<Box*>(user);

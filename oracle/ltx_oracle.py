@@ -330,7 +330,7 @@ def feed_forward(w, prefix, x):
 
 def transformer_block(w, i, x, ctx, temb, cfg, rope, bias, cross_scale=1.0, skip_attn=False, skip_ff=False,
                       first_norm_bf16=False):
-    """BasicTransformerBlock.callAsFunction (LTXTransformerBlock.swift:187-232). temb [B,1,6,D]."""
+    """BasicTransformerBlock.callAsFunction (LTXTransformerBlock.swift:187-232). temb [B,1,6,D] or [B,T,6,D]."""
     p = f"transformer_blocks.{i}."
     ada = w[p + "scale_shift_table"][None, None].astype(F32) + temb  # [B,1,6,D]
     shift_msa, scale_msa, gate_msa = ada[:, :, 0], ada[:, :, 1], ada[:, :, 2]
@@ -368,16 +368,19 @@ def mask_to_bias(mask):
 def dit_forward(w, cfg, latent, context, timesteps, mask, F, H, W, cross_scale=None, stg_blocks=(), skip_ff_blocks=(),
                 num_layers=None):
     """LTXTransformer.callAsFunction (LTXTransformer.swift:235-486).
-    latent [B,T,C] (bf16-representable f32), context [B,S,Cc] (bf16-representable), timesteps [B] sigma."""
+    latent [B,T,C] (bf16-representable f32), context [B,S,Cc] (bf16-representable), timesteps [B] sigma, or [B,T]
+    per-token sigmas (image-to-video: prepareTimestep flattens them and reshapes to [B,T,6,D], LTXTransformer.swift:105-124)."""
     D = cfg.dim
     B = latent.shape[0]
     x = bf16_round(linear(latent, w["patchify_proj.weight"], w["patchify_proj.bias"]))
-    t = np.asarray(timesteps, F32) * F32(cfg.timestep_mult)
+    ts_arr = np.asarray(timesteps, F32)
+    n_tok = 1 if ts_arr.ndim == 1 else ts_arr.shape[1]
+    t = ts_arr.reshape(-1) * F32(cfg.timestep_mult)
     e = timestep_embedding(t, 256)
     e = linear(e, w["adaln_single.emb.linear_1.weight"], w["adaln_single.emb.linear_1.bias"])
-    emb_ts = linear(silu(e), w["adaln_single.emb.linear_2.weight"], w["adaln_single.emb.linear_2.bias"])  # [B,D]
-    ada = linear(silu(emb_ts), w["adaln_single.linear.weight"], w["adaln_single.linear.bias"])  # [B,6D]
-    temb = ada.reshape(B, 1, 6, D)
+    emb_ts = linear(silu(e), w["adaln_single.emb.linear_2.weight"], w["adaln_single.emb.linear_2.bias"])  # [B*n,D]
+    ada = linear(silu(emb_ts), w["adaln_single.linear.weight"], w["adaln_single.linear.bias"])  # [B*n,6D]
+    temb = ada.reshape(B, n_tok, 6, D)
     ctx = caption_projection(w, context).reshape(B, -1, D)
     bias = mask_to_bias(mask)
     rope = rope_tables(F, H, W, D, cfg.num_heads, cfg.rope_theta, cfg.max_pos)
@@ -387,7 +390,7 @@ def dit_forward(w, cfg, latent, context, timesteps, mask, F, H, W, cross_scale=N
         x = transformer_block(w, i, x, ctx, temb, cfg, rope, bias, cs, skip_attn=(i in stg_blocks),
                               skip_ff=(i in skip_ff_blocks), first_norm_bf16=(i == 0))
     # processOutput (LTXTransformer.swift:208-224)
-    ss = w["scale_shift_table"][None, None].astype(F32) + emb_ts.reshape(B, 1, 1, D)
+    ss = w["scale_shift_table"][None, None].astype(F32) + emb_ts.reshape(B, n_tok, 1, D)
     shift, scale = ss[:, :, 0], ss[:, :, 1]
     out = layer_norm(x, cfg.norm_eps) * (F32(1) + scale) + shift
     return linear(out, w["proj_out.weight"], w["proj_out.bias"])
@@ -435,13 +438,28 @@ def euler_step(latent, velocity, sigma, sigma_next):
 
 
 def denoise(w, cfg, latent, sigmas_, context, mask, F, H, W, cfg_scale=1.0, rescale=0.0, stg_scale=0.0,
-            stg_blocks=(29,), ge_gamma=0.0, neg_context=None, neg_mask=None, num_layers=None):
-    """generateVideo's loop (LTXPipeline.swift:800-956), T2V. latent [1,C,F,H,W] f32 already scaled by sigmas[0]."""
+            stg_blocks=(29,), ge_gamma=0.0, neg_context=None, neg_mask=None, num_layers=None, cond_latent=None,
+            image_cond_noise_scale=0.0, cond_noise=None):
+    """generateVideo's loop (LTXPipeline.swift:800-956), T2V. latent [1,C,F,H,W] f32 already scaled by sigmas[0].
+    Image-to-video (denoise(...) :2191-2401 with conditioningMask / conditionedLatent): cond_latent [1,C,1,H,W] is the encoded
+    image; frame 0 is that latent (:2092-2094), optionally re-noised per step with cond_noise[step] * scale * sigma^2
+    (:2225-2229), its tokens carry timestep 0 (:2237-2252) and the Euler step skips it (:2344-2357)."""
     prev_v = None
+    i2v = cond_latent is not None
+    if i2v:
+        latent = latent.copy()
+        latent[:, :, 0:1] = cond_latent
     for step in range(len(sigmas_) - 1):
         sg, sn = float(sigmas_[step]), float(sigmas_[step + 1])
+        if i2v and image_cond_noise_scale > 0 and sg > 0 and cond_noise is not None:
+            latent[:, :, 0:1] = cond_latent + F32(image_cond_noise_scale) * cond_noise[step].astype(F32) * F32(sg * sg)
         tok = bf16_round(patchify(latent))
-        ts = np.array([sg], F32)
+        if i2v:
+            cm = np.zeros((1, F * H * W), F32)
+            cm[:, :H * W] = 1
+            ts = (F32(sg) * (F32(1) - cm)).astype(F32)  # (1, T) per-token
+        else:
+            ts = np.array([sg], F32)
 
         def fwd(c, m, **kw):
             v = dit_forward(w, cfg, tok, c, ts, m, F, H, W, num_layers=num_layers, **kw)
@@ -460,7 +478,10 @@ def denoise(w, cfg, latent, sigmas_, context, mask, F, H, W, cfg_scale=1.0, resc
         if ge_gamma > 0 and prev_v is not None:
             v = F32(ge_gamma) * (v - prev_v) + prev_v
         prev_v = v
-        latent = euler_step(latent, v, sg, sn)
+        if i2v:
+            latent = np.concatenate([latent[:, :, 0:1], euler_step(latent[:, :, 1:], v[:, :, 1:], sg, sn)], axis=2)
+        else:
+            latent = euler_step(latent, v, sg, sn)
     return latent
 
 

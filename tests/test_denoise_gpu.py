@@ -71,3 +71,64 @@ def test_denoise_single_step_bitwise_repeatable(ltx, oracle, gpu_ctx, model):
     assert np.array_equal(a, b)
     ref = oracle.denoise(w, ocfg, noise, sig, ctx, None, F, H, W)
     assert rel_l2(a, ref) <= 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# image-to-video conditioning - per-token timesteps, frame-0 slice Euler, re-noised frame 0
+# ---------------------------------------------------------------------------------------------------------------
+def test_dit_forward_per_token_timesteps(ltx, oracle, gpu_ctx, model):
+    """prepareTimestep with [B,T] sigmas (LTXTransformer.swift:105-124): frame-0 tokens at 0, the rest at sigma; a row of
+    equal per-token values must reproduce the single-timestep forward exactly (same kernels, same tables)."""
+    cfg, ocfg, w = model
+    F, H, W, S = 3, 2, 4, 24
+    T = F * H * W
+    rng = np.random.default_rng(31)
+    lat = oracle.bf16_round(rng.standard_normal((1, T, 128)).astype(np.float32))
+    ctx = oracle.bf16_round(rng.standard_normal((1, S, ocfg.caption_channels)).astype(np.float32))
+    lb, cb = ltx.f32_to_bf16_bits(lat), ltx.f32_to_bf16_bits(ctx)
+    ts = np.full((1, T), 0.6, np.float32)
+    uniform = gpu_ctx.dit_forward_tokens(lb, cb, ts, None, F, H, W)
+    single = gpu_ctx.dit_forward(lb, cb, np.array([0.6], np.float32), None, F, H, W)
+    assert np.array_equal(uniform, single)
+    ts[:, :H * W] = 0.0
+    got = gpu_ctx.dit_forward_tokens(lb, cb, ts, None, F, H, W)
+    ref = oracle.dit_forward(w, ocfg, lat, ctx, ts, None, F, H, W)
+    assert rel_l2(got, ref) <= 2e-2, rel_l2(got, ref)
+    assert rel_l2(got, single) > 5e-2  # the conditioning really changes the result
+    # three distinct values, B = 2 (CFG batch): 2 x 3 groups
+    lat2 = np.concatenate([lat, lat]); ctx2 = np.concatenate([ctx, ctx[:, ::-1]])
+    ts2 = np.stack([ts[0], np.where(np.arange(T) % 3 == 0, 0.25, 0.9).astype(np.float32)])
+    ts2[1, 0] = 0.0
+    got2 = gpu_ctx.dit_forward_tokens(ltx.f32_to_bf16_bits(lat2), ltx.f32_to_bf16_bits(ctx2), ts2, None, F, H, W)
+    ref2 = oracle.dit_forward(w, ocfg, lat2, ctx2, ts2, None, F, H, W)
+    assert rel_l2(got2, ref2) <= 2e-2
+    with pytest.raises(ltx.LTXError):  # more distinct (batch, value) pairs than the timestep path holds
+        gpu_ctx.dit_forward_tokens(lb, cb, np.linspace(0, 1, T, dtype=np.float32)[None], None, F, H, W)
+
+
+@pytest.mark.parametrize("use_cfg,noise_scale", [(False, 0.0), (False, 0.15), (True, 0.15)])
+def test_denoise_image_to_video(ltx, oracle, gpu_ctx, model, use_cfg, noise_scale):
+    """denoise(...) with conditioningMask / conditionedLatent (LTXPipeline.swift:2191-2401)."""
+    cfg, ocfg, w = model
+    F, H, W, S = 3, 4, 4, 24
+    nb = 2 if use_cfg else 1
+    noise, ctx = _inputs(oracle, ocfg, F, H, W, S, 11, nb=nb)
+    rng = np.random.default_rng(12)
+    cond = rng.standard_normal((1, 128, 1, H, W)).astype(np.float32)
+    sig = ltx.sigmas(True, 8, F * H * W) if not use_cfg else ltx.sigmas(False, 4, F * H * W)
+    cnoise = rng.standard_normal((len(sig) - 1, 128, 1, H, W)).astype(np.float32)
+    lat0 = noise * sig[0]
+    kw = dict(cond_latent=cond, image_cond_noise_scale=noise_scale, cond_noise=cnoise if noise_scale > 0 else None)
+    if use_cfg:
+        got = gpu_ctx.denoise(lat0, sig, ltx.f32_to_bf16_bits(ctx), None, F, H, W, cfg_scale=3.0, **kw)
+        ref = oracle.denoise(w, ocfg, lat0, sig, ctx[1:2], None, F, H, W, cfg_scale=3.0, neg_context=ctx[0:1], **kw)
+    else:
+        got = gpu_ctx.denoise(lat0, sig, ltx.f32_to_bf16_bits(ctx), None, F, H, W, **kw)
+        ref = oracle.denoise(w, ocfg, lat0, sig, ctx, None, F, H, W, **kw)
+    # frame 0 is never stepped: it holds the image latent, or its last re-noised value - exact either way
+    assert np.array_equal(got[:, :, 0], ref[:, :, 0])
+    if noise_scale == 0:
+        assert np.array_equal(got[:, :, 0:1], cond)
+    assert rel_l2(got[:, :, 1:], ref[:, :, 1:]) <= 3e-2, rel_l2(got[:, :, 1:], ref[:, :, 1:])
+    t2v = gpu_ctx.denoise(lat0, sig, ltx.f32_to_bf16_bits(ctx), None, F, H, W, **({"cfg_scale": 3.0} if use_cfg else {}))
+    assert rel_l2(got[:, :, 1:], t2v[:, :, 1:]) > 1e-2  # conditioning is not a no-op
