@@ -217,6 +217,26 @@ int ltx_dit_forward_tokens(ltx_ctx* ctx, const uint16_t* latent, const uint16_t*
                            const int32_t* mask, int B, int F, int H, int W, int S, float* velocity);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * VAE encoder (VideoEncoder.swift:211-312, call site encodeImage LTXPipeline.swift:1902-1932): turns the
+ * image-to-video conditioning image into the latent that ltx_denoise_options.cond_latent takes.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Replaces loadVAEEncoder (LTXPipeline.swift:1871-1885): reads the `encoder.*` tensors of the VAE file (key rules
+ * ModelDownloader.swift:1222-1283). channel_base 0 = reference (128 -> 128..2048 channels). */
+int ltx_vae_encoder_load(ltx_ctx* ctx, const char* safetensors_path, int channel_base);
+int ltx_vae_encoder_init_synthetic(ltx_ctx* ctx, int channel_base, unsigned long seed);
+int ltx_vae_encoder_unload(ltx_ctx* ctx);
+/* pixels [1][3][T][H][W] f32 (the reference feeds images scaled to [-1,1]; image loading/resizing stays with the caller) ->
+ * latent [1][128][T'][H/32][W/32] f32, T' = ltx_vae_encoder_latent_frames(T). normalize != 0 applies
+ * (latent - mean_of_means) / std_of_means with the loaded decoder's statistics (LTXPipeline.swift:1920-1927; the decoder must
+ * be loaded). HOST pointers. */
+int ltx_vae_encode(ltx_ctx* ctx, const float* pixels, int T, int H, int W, int normalize, float* latent);
+/* Same with DEVICE pointers, asynchronous on the context stream. */
+int ltx_vae_encode_dev(ltx_ctx* ctx, const float* pixels, int T, int H, int W, int normalize, float* latent);
+int ltx_vae_encoder_latent_frames(int T);
+/* mapVAEEncoderWeights (ModelDownloader.swift:1222-1283): length of the module key, 0 if the key is not an encoder tensor. */
+int ltx_map_vae_encoder_key(const char* file_key, char* out, int cap);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Text-embedding connector (VideoGemmaTextEncoderModel.encodeFromHiddenStates,
  * LTXTextEncoder.swift:574-643 - call site LTXPipeline.swift:640-700): from the 49 Gemma-3 hidden states to the
  * [B,T,3840] bf16 context + all-ones mask that ltx_denoise / ltx_dit_forward take. The language model itself is not

@@ -106,6 +106,15 @@ def map_lora_key(key):
     return _map_key(lib.ltx_map_lora_key, key)
 
 
+def map_vae_encoder_key(key):
+    """``mapVAEEncoderWeights`` (ModelDownloader.swift:1222-1283); None for non-encoder tensors."""
+    return _map_key(lib.ltx_map_vae_encoder_key, key)
+
+
+def vae_encoder_latent_frames(T):
+    return lib.ltx_vae_encoder_latent_frames(T)
+
+
 def map_text_encoder_key(key):
     """``mapTextEncoderWeights`` (ModelDownloader.swift:911-968); None = dropped."""
     return _map_key(lib.ltx_map_text_encoder_key, key)
@@ -283,6 +292,28 @@ class Context:
         self._ck(lib.ltx_op_conv3d(self._h, _ptr(x), F, H, W, Cin, _ptr(w), _ptr(bias), Cout, int(causal), _ptr(out)))
 
     # ---- two-stage glue ----
+    # ---- VAE encoder ----
+    def vae_encoder_load(self, path, channel_base=0):
+        self._ck(lib.ltx_vae_encoder_load(self._h, str(path).encode(), channel_base))
+
+    def vae_encoder_init_synthetic(self, channel_base=0, seed=66):
+        self._ck(lib.ltx_vae_encoder_init_synthetic(self._h, channel_base, seed))
+
+    def vae_encoder_unload(self):
+        self._ck(lib.ltx_vae_encoder_unload(self._h))
+
+    def vae_encode(self, pixels, normalize=False):
+        """``encodeImage`` without the image I/O: pixels [1,3,T,H,W] f32 -> latent [1,128,T',H/32,W/32] f32 (host arrays)."""
+        px = np.ascontiguousarray(pixels, dtype=np.float32)
+        _, _, T, H, W = px.shape
+        out = np.empty((1, 128, lib.ltx_vae_encoder_latent_frames(T), H // 32, W // 32), dtype=np.float32)
+        self._ck(lib.ltx_vae_encode(self._h, _ptr(px), T, H, W, int(normalize), _ptr(out)))
+        return out
+
+    def vae_encode_dev(self, pixels, latent, normalize=False):
+        _, _, T, H, W = pixels.shape
+        self._ck(lib.ltx_vae_encode_dev(self._h, _ptr(pixels), T, H, W, int(normalize), _ptr(latent)))
+
     # ---- text-embedding connector (SURVEY 8(f) item 1) ----
     def connector_load(self, path, cfg=None):
         self._ck(lib.ltx_connector_load(self._h, str(path).encode(), C.byref(cfg) if cfg is not None else None))

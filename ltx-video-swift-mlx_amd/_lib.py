@@ -116,6 +116,13 @@ SIGNATURES = {
     "ltx_connector_encode_taps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ltx_map_text_encoder_key": (_i, [C.c_char_p, C.c_char_p, _i]),
     "ltx_rope_tables_1d": (_i, [_i, _i, _f, _i, _vp, _vp]),
+    "ltx_vae_encoder_load": (_i, [_vp, C.c_char_p, _i]),
+    "ltx_vae_encoder_init_synthetic": (_i, [_vp, _i, C.c_ulong]),
+    "ltx_vae_encoder_unload": (_i, [_vp]),
+    "ltx_vae_encode": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ltx_vae_encode_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ltx_vae_encoder_latent_frames": (_i, [_i]),
+    "ltx_map_vae_encoder_key": (_i, [C.c_char_p, C.c_char_p, _i]),
     "ltx_upscaler_load": (_i, [_vp, C.c_char_p]),
     "ltx_upscaler_unload": (_i, [_vp]),
     "ltx_upscale_latent": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -15,6 +15,7 @@
 #include "pipeline.h"
 #include "upscaler.h"
 #include "vae.h"
+#include "vae_encoder.h"
 #include "runtime.h"
 
 namespace {
@@ -135,6 +136,7 @@ void ltx_ctx_destroy(ltx_ctx* ctx) {
     if (ctx->vae) vae_destroy(ctx->vae);
     if (ctx->upscaler) upscaler_destroy(ctx->upscaler);
     if (ctx->connector) connector_destroy(ctx->connector);
+    if (ctx->vae_encoder) vae_encoder_destroy(ctx->vae_encoder);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1016,4 +1018,84 @@ int ltx_rope_tables_1d(int T, int dim, float theta, int max_pos, float* cos_out,
     memcpy(cos_out, c.data(), c.size() * 4);
     memcpy(sin_out, s.data(), s.size() * 4);
     return LTX_OK;
+}
+
+
+/* ---- VAE encoder ---- */
+namespace {
+void drop_vae_encoder(ltx_ctx* ctx) {
+    if (ctx->vae_encoder) {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        vae_encoder_destroy(ctx->vae_encoder);
+        ctx->vae_encoder = nullptr;
+    }
+}
+void encode_common(ltx_ctx* ctx, const float* px_dev, int T, int H, int W, int normalize, float* lat_dev) {
+    if (!ctx->vae_encoder) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model not loaded: VAE encoder failed to load");
+    const float* mean = nullptr;
+    const float* stdv = nullptr;
+    if (normalize) {
+        if (!ctx->vae) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model not loaded: VAE decoder not loaded (needed for latent statistics)");
+        mean = ctx->vae->mean;
+        stdv = ctx->vae->std_;
+    }
+    vae_encoder_encode(ctx, ctx->vae_encoder, px_dev, T, H, W, mean, stdv, lat_dev, nullptr);
+}
+}  // namespace
+
+int ltx_vae_encoder_load(ltx_ctx* ctx, const char* path, int channel_base) {
+    if (!ctx || !path) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        drop_vae_encoder(ctx);
+        VaeEncoderModel* m = vae_encoder_create(channel_base > 0 ? channel_base : 128);
+        try {
+            vae_encoder_load_safetensors(ctx, m, path);
+        } catch (...) {
+            vae_encoder_destroy(m);
+            throw;
+        }
+        ctx->vae_encoder = m;
+    });
+}
+
+int ltx_vae_encoder_init_synthetic(ltx_ctx* ctx, int channel_base, unsigned long seed) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        drop_vae_encoder(ctx);
+        ctx->vae_encoder = vae_encoder_create(channel_base > 0 ? channel_base : 128);
+        vae_encoder_init_synthetic(ctx, ctx->vae_encoder, seed);
+    });
+}
+
+int ltx_vae_encoder_unload(ltx_ctx* ctx) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { drop_vae_encoder(ctx); });
+}
+
+int ltx_vae_encoder_latent_frames(int T) { return T < 1 ? 0 : vae_encoder_latent_frames(T); }
+
+int ltx_vae_encode_dev(ltx_ctx* ctx, const float* pixels, int T, int H, int W, int normalize, float* latent) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { encode_common(ctx, pixels, T, H, W, normalize, latent); });
+}
+
+int ltx_vae_encode(ltx_ctx* ctx, const float* pixels, int T, int H, int W, int normalize, float* latent) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        LTX_REQUIRE(pixels && latent && T >= 1 && H >= 1 && W >= 1, "ltx_vae_encode: bad arguments");
+        const size_t nb_in = (size_t)3 * T * H * W * 4;
+        const size_t nb_out = (size_t)128 * vae_encoder_latent_frames(T) * (H / 32) * (W / 32) * 4;
+        ctx->h2d[0].ensure(nb_in);
+        ctx->h2d[1].ensure(nb_out ? nb_out : 4);
+        HIP_CHECK(hipMemcpyAsync(ctx->h2d[0].p, pixels, nb_in, hipMemcpyHostToDevice, ctx->stream));
+        encode_common(ctx, ctx->h2d[0].as<float>(), T, H, W, normalize, ctx->h2d[1].as<float>());
+        HIP_CHECK(hipMemcpyAsync(latent, ctx->h2d[1].p, nb_out, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int ltx_map_vae_encoder_key(const char* file_key, char* out, int cap) {
+    std::string mk;
+    if (!file_key || !map_vae_encoder_file_key(file_key, &mk)) return 0;
+    return copy_str(mk, out, cap);
 }

@@ -115,3 +115,9 @@ void launch_register_plan(const int32_t* mask, int B, int T, int32_t* src, hipSt
 void launch_register_gather(const bf16_t* enc, const float* registers, const int32_t* src, int B, int T, int D, int R, float* x,
                             hipStream_t stream);
 void launch_fill_const_i32(int32_t* p, long n, int32_t v, hipStream_t stream);
+
+// ---- VAE encoder (VideoEncoder.swift) ----
+void launch_enc_patchify(const float* pixels, bf16_t* out, int T, int H, int W, hipStream_t stream);
+void launch_enc_s2d_residual(const float* conv, int Cc, const float* x, int Cx, float* out, int Cout, int T, int H, int W, int ft,
+                             int fh, int fw, hipStream_t stream);
+void launch_enc_finish(const float* z, long ldz, const float* mean, const float* stdv, float* out, int C, long P, hipStream_t stream);

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void vae_prepare_kernel(const float* __restric
 }
 
 // one wave per position when C <= 256*... generic: a group of G = C/4 lanes (<= 256) per position
-template <int LANES_PER_POS>
+template <int LANES_PER_POS, int NJ = 4>
 __global__ __launch_bounds__(256) void pixelnorm_silu_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift,
@@ -400,10 +400,10 @@ __global__ __launch_bounds__(256) void pixelnorm_silu_kernel(const float* __rest
     const int nchunk = C >> 2;
     const bool active = p < P;
     const float* xr = x + (active ? p : 0) * (long)C;
-    f32x4 v[4];
+    f32x4 v[NJ];
     float s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int c = sub + j * LANES_PER_POS;
         if (c < nchunk) {
             v[j] = *(const f32x4*)(xr + c * 4);
@@ -417,11 +417,14 @@ __global__ __launch_bounds__(256) void pixelnorm_silu_kernel(const float* __rest
     if (!active) return;
     bf16_t* orow = out + p * (long)C;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int c = sub + j * LANES_PER_POS;
         if (c < nchunk) {
-            const f32x4 s4 = *(const f32x4*)(scale + c * 4);
-            const f32x4 h4 = *(const f32x4*)(shift + c * 4);
+            f32x4 s4 = f32x4{1.f, 1.f, 1.f, 1.f}, h4 = f32x4{0.f, 0.f, 0.f, 0.f};  // no modulation: the VAE encoder's blocks
+            if (scale) {
+                s4 = *(const f32x4*)(scale + c * 4);
+                h4 = *(const f32x4*)(shift + c * 4);
+            }
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = silu_f(v[j][e] * inv * s4[e] + h4[e]);
@@ -699,7 +702,13 @@ void launch_clip01(float* x, long n, hipStream_t stream) {
 }
 void launch_pixelnorm_silu(const float* x, const float* scale, const float* shift, bf16_t* out, long P, int C,
                            hipStream_t stream) {
-    LTX_REQUIRE(C % 4 == 0 && C <= 1024, "pixelnorm: C=%d", C);
+    LTX_REQUIRE(C % 4 == 0 && C <= 2048, "pixelnorm: C=%d", C);
+    LTX_REQUIRE((scale == nullptr) == (shift == nullptr), "pixelnorm: scale/shift must both be set or both null");
+    if (C > 1024) {  // the encoder's 2048-channel mid block: 8 chunks per lane
+        hipLaunchKernelGGL((pixelnorm_silu_kernel<64, 8>), dim3(cdiv(P, 4)), dim3(256), 0, stream, x, scale, shift, out, P, C);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     // lanes per position: enough that each lane holds <= 4 float4 chunks, power of two, <= 64
     const int nchunk = C / 4;
     int lpp = 1;
@@ -920,5 +929,92 @@ void launch_register_gather(const bf16_t* enc, const float* registers, const int
 }
 void launch_fill_const_i32(int32_t* p, long n, int32_t v, hipStream_t stream) {
     hipLaunchKernelGGL(fill_const_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, v);
+    HIP_CHECK(hipGetLastError());
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// VAE encoder kernels (VideoEncoder.swift)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+// pixels f32 [3][T][H][W] -> bf16 channels-last [T][H/4][W/4][64]: channel = c*16 + pw*4 + ph for c < 3 (pW before pH,
+// VideoEncoder.swift:25-31), channels 48..63 zero (K-tile padding of conv_in)
+__global__ void enc_patchify_kernel(const float* __restrict__ px, bf16_t* __restrict__ out, int T, int H, int W) {
+    const long n = (long)T * (H / 4) * (W / 4) * 64;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ch = (int)(i & 63);
+    long pos = i >> 6;
+    const int w4 = (int)(pos % (W / 4));
+    pos /= (W / 4);
+    const int h4 = (int)(pos % (H / 4));
+    const int t = (int)(pos / (H / 4));
+    float v = 0.f;
+    if (ch < 48) {
+        const int c = ch >> 4, pw = (ch >> 2) & 3, ph = ch & 3;
+        v = px[(((long)c * T + t) * H + (h4 * 4 + ph)) * W + (w4 * 4 + pw)];
+    }
+    out[i] = f32_to_bf16(v);
+}
+
+// out[t2][h2][w2][co] = s2d(conv)[co] + mean_g s2d(x)[co*G + g]  (VAESpaceToDepthDownsample3d, VideoEncoder.swift:146-167)
+// s2d channel cs of a tensor with Cs source channels: source channel cs / S, sub = cs % S -> (it, ih, iw); an odd T is padded
+// in FRONT with copies of frame 0, i.e. source frame max(0, t2*ft + it - padT)
+__global__ void enc_s2d_residual_kernel(const float* __restrict__ conv, int Cc, const float* __restrict__ x, int Cx,
+                                        float* __restrict__ out, int Cout, int T, int H, int W, int ft, int fh, int fw) {
+    const int S = ft * fh * fw;
+    const int padT = (ft - T % ft) % ft;
+    const int T2 = (T + padT) / ft, H2 = H / fh, W2 = W / fw;
+    const long n = (long)T2 * H2 * W2 * Cout;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int co = (int)(i % Cout);
+    long pos = i / Cout;
+    const int w2 = (int)(pos % W2);
+    pos /= W2;
+    const int h2 = (int)(pos % H2);
+    const int t2 = (int)(pos / H2);
+    auto fetch = [&](const float* src, int C, int cs) {
+        const int c = cs / S, sub = cs - c * S;
+        const int it = sub / (fh * fw), ih = (sub / fw) % fh, iw = sub % fw;
+        int ts = t2 * ft + it - padT;
+        ts = ts < 0 ? 0 : ts;
+        return src[(((long)ts * H + (h2 * fh + ih)) * W + (w2 * fw + iw)) * C + c];
+    };
+    const int G = Cx * S / Cout;
+    float acc = 0.f;
+    for (int g = 0; g < G; ++g) acc += fetch(x, Cx, co * G + g);
+    out[i] = fetch(conv, Cc, co) + acc / (float)G;
+}
+
+// z f32 [P][ldz] (first C channels) -> out [C][P] f32 with optional (z - mean[c]) / std[c]  (LTXPipeline.swift:1920-1927)
+__global__ void enc_finish_kernel(const float* __restrict__ z, long ldz, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                  float* __restrict__ out, int C, long P) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)C * P) return;
+    const int c = (int)(i / P);
+    const long p = i - (long)c * P;
+    float v = z[p * ldz + c];
+    if (mean) v = (v - mean[c]) / stdv[c];
+    out[i] = v;
+}
+}  // namespace
+
+void launch_enc_patchify(const float* pixels, bf16_t* out, int T, int H, int W, hipStream_t stream) {
+    LTX_REQUIRE(H % 4 == 0 && W % 4 == 0, "encoder patchify: H=%d W=%d must be multiples of 4", H, W);
+    const long n = (long)T * (H / 4) * (W / 4) * 64;
+    hipLaunchKernelGGL(enc_patchify_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, pixels, out, T, H, W);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_enc_s2d_residual(const float* conv, int Cc, const float* x, int Cx, float* out, int Cout, int T, int H, int W, int ft,
+                             int fh, int fw, hipStream_t stream) {
+    LTX_REQUIRE(H % fh == 0 && W % fw == 0 && (Cx * ft * fh * fw) % Cout == 0 && Cc * ft * fh * fw == Cout, "s2d: bad shapes");
+    const int padT = (ft - T % ft) % ft;
+    const long n = (long)((T + padT) / ft) * (H / fh) * (W / fw) * Cout;
+    hipLaunchKernelGGL(enc_s2d_residual_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, conv, Cc, x, Cx, out, Cout, T, H, W, ft, fh, fw);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_enc_finish(const float* z, long ldz, const float* mean, const float* stdv, float* out, int C, long P, hipStream_t stream) {
+    hipLaunchKernelGGL(enc_finish_kernel, dim3(cdiv((long)C * P, 256)), dim3(256), 0, stream, z, ldz, mean, stdv, out, C, P);
     HIP_CHECK(hipGetLastError());
 }

@@ -41,7 +41,7 @@ struct GemmEpilogue {
 struct Conv3dGeom {
     int F = 0, H = 0, W = 0, C = 0;
     int causal = 0;
-    int pad_mode = 0;  // 0: reflect H/W + replicate T (VAE Conv3dFull); 1: zeros in every dim (MLXNN.Conv3d/Conv2d
+    int pad_mode = 0;  // 0: reflect H/W + replicate T (VAE Conv3dFull); 1: zeros in every dim (MLXNN.Conv3d/Conv2d  /* 3: zeros in H/W (zero row at index P) + replicated frames in T: the VAE encoder's CausalConv3dFull */
                        // padding=1, SpatialUpscaler.swift:78-92,139-145): out-of-range taps read the all-zero row that
                        // the caller keeps at position index F*H*W of the input tensor; 2: replicate H/W/T
     int kt = 3;        // temporal taps: 3 (3x3x3) or 1 (per-frame 3x3 conv2d)

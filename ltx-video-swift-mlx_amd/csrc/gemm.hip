@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
                 int fi = g.geom.causal ? (a_pos[i].f + dt - 2) : (a_pos[i].f + dt - 1);
                 int yi = a_pos[i].y + dy - 1, xi = a_pos[i].x + dx - 1;
                 long pos;
-                if (g.geom.pad_mode == 1) {
+                if (g.geom.pad_mode == 1 || g.geom.pad_mode == 3) {
+                    if (g.geom.pad_mode == 3) fi = clamp_idx(fi, g.geom.F);  // zeros in H/W, replicated frames in T
                     const bool ok = fi >= 0 && fi < g.geom.F && yi >= 0 && yi < g.geom.H && xi >= 0 && xi < g.geom.W;
                     pos = ok ? ((long)fi * g.geom.H + yi) * g.geom.W + xi : (long)g.geom.F * g.geom.H * g.geom.W;
                 } else {
@@ -513,7 +514,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
             int fi = g.geom.causal ? (a_pos[i].f + dt - 2) : (a_pos[i].f + dt - 1);
             int yi = a_pos[i].y + dy - 1, xi = a_pos[i].x + dx - 1;
             long pos;
-            if (g.geom.pad_mode == 1) {
+            if (g.geom.pad_mode == 1 || g.geom.pad_mode == 3) {
+                if (g.geom.pad_mode == 3) fi = clamp_idx(fi, g.geom.F);  // zeros in H/W, replicated frames in T
                 const bool ok = fi >= 0 && fi < g.geom.F && yi >= 0 && yi < g.geom.H && xi >= 0 && xi < g.geom.W;
                 pos = ok ? ((long)fi * g.geom.H + yi) * g.geom.W + xi : (long)g.geom.F * g.geom.H * g.geom.W;
             } else {

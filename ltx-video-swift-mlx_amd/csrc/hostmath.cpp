@@ -393,3 +393,33 @@ void rope_tables_1d(int T, int dim, double theta, int max_pos, std::vector<float
         }
     }
 }
+
+
+bool map_vae_encoder_file_key(const std::string& file_key, std::string* module_key) {
+    if (!starts_with(file_key, "encoder.")) return false;
+    std::string k = file_key.substr(8);
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "down_blocks." + std::to_string(i) + ".";
+        if (starts_with(k, p.c_str())) {
+            k = "down_blocks_" + std::to_string(i) + "." + k.substr(p.size());
+            break;
+        }
+    }
+    for (int i = 0; i < 4; ++i) {
+        const std::string rp = "down_blocks_" + std::to_string(i) + ".resnets.";
+        if (starts_with(k, rp.c_str())) {
+            const std::string suffix = k.substr(rp.size());
+            if (!starts_with(suffix, "resnets.")) k = rp + "resnets." + suffix;  // EncoderDownBlock.resnets -> EncoderResBlockGroup.resnets
+            break;
+        }
+    }
+    for (int i = 0; i < 4; ++i) {
+        const std::string dp = "down_blocks_" + std::to_string(i) + ".downsamplers.0.";
+        if (starts_with(k, dp.c_str())) {
+            k = "down_blocks_" + std::to_string(i) + ".downsamplers." + k.substr(dp.size());
+            break;
+        }
+    }
+    *module_key = k;
+    return true;
+}

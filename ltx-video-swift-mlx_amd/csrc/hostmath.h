@@ -54,6 +54,8 @@ bool map_transformer_file_key(const std::string& file_key, std::string* module_k
 bool map_vae_file_key(const std::string& file_key, std::string* module_key);
 // LoRA key -> module weight key (LoRALoader.swift:209-243)
 bool map_lora_key(const std::string& lora_base, std::string* module_weight_key);
+// VAE encoder tensors of the VAE file (mapVAEEncoderWeights, ModelDownloader.swift:1222-1283); false for everything else
+bool map_vae_encoder_file_key(const std::string& file_key, std::string* module_key);
 // text-embedding connector: file key -> module key of VideoGemmaTextEncoderModel
 // (ModelDownloader.swift:911-968 after the unified-file prefix strip of :1353-1399); false = dropped
 bool map_text_encoder_file_key(const std::string& file_key, std::string* module_key);

@@ -85,6 +85,7 @@ void st_to_f32(const SafeTensors& st, const StTensor& t, float* out);
 struct DiTModel;
 struct VaeModel;
 struct ConnectorModel;
+struct VaeEncoderModel;
 struct UpscalerModel;
 
 // ---- live per-kernel timing (HIP events recorded on the launch stream around each launch of a kernel family) ----
@@ -131,6 +132,7 @@ struct ltx_ctx {
     VaeModel* vae = nullptr;
     UpscalerModel* upscaler = nullptr;
     ConnectorModel* connector = nullptr;
+    VaeEncoderModel* vae_encoder = nullptr;
     // staging buffers for host-pointer entry points
     DevBuf h2d[8];
     // load report of the last *_load call (mirrors the reference's "unmatched/missing" debug logs)

@@ -1185,3 +1185,155 @@ def connector_file_keys(w, unified=True):
             fk = ("model.diffusion_model.video_embeddings_connector." if unified else "video_connector.") + s
         out[fk] = v
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SURVEY 8(f) item 3, second half: the VAE *encoder* that turns the conditioning image into the latent of frame 0.
+# Restates Models/VAE/VideoEncoder.swift (encoderPatchify :13-34, spaceToDepth :40-68, EncoderResBlock3d :74-100,
+# VAESpaceToDepthDownsample3d :124-168, VideoEncoder :211-312) and encodeImage's normalisation (LTXPipeline.swift:1902-1932).
+# `base` scales the channel ladder (reference 128 -> 128,256,512,1024,2048) so tests can run a thinner copy.
+# ---------------------------------------------------------------------------------------------------------------
+ENC_RESNETS = (4, 6, 6, 2)
+ENC_FACTORS = ((1, 2, 2), (2, 1, 1), (2, 2, 2), (2, 2, 2))
+
+
+def conv3d_causal_zero(x, weight, bias, causal=True):
+    """CausalConv3dFull with spatialPaddingMode .zeros (VideoConvolution.swift:238-347): zero pad H/W by 1; temporal pad
+    = first frame twice in front (causal) or replicate 1+1."""
+    b, c, t, h, wd = x.shape
+    o = weight.shape[0]
+    xp = np.pad(x.astype(F32), ((0, 0), (0, 0), (0, 0), (1, 1), (1, 1)))
+    if causal:
+        xp = np.concatenate([xp[:, :, :1]] * 2 + [xp], axis=2)
+    else:
+        xp = np.concatenate([xp[:, :, :1], xp, xp[:, :, -1:]], axis=2)
+    out = np.zeros((b, o, t, h, wd), F32)
+    wf = weight.astype(F32)
+    for kt in range(3):
+        for kh in range(3):
+            for kw in range(3):
+                patch = xp[:, :, kt:kt + t, kh:kh + h, kw:kw + wd].reshape(b, c, -1)
+                out += np.einsum("oc,bcn->bon", wf[:, :, kt, kh, kw], patch, optimize=True).reshape(b, o, t, h, wd)
+    if bias is not None:
+        out += bias.astype(F32).reshape(1, -1, 1, 1, 1)
+    return out
+
+
+def encoder_patchify(x):
+    """(B,3,T,H,W) -> (B,48,T,H/4,W/4); channel = c*16 + pw*4 + ph (pW before pH, VideoEncoder.swift:25-31)."""
+    b, c, t, h, w = x.shape
+    o = x.reshape(b, c, t, h // 4, 4, w // 4, 4).transpose(0, 1, 6, 4, 2, 3, 5)
+    return o.reshape(b, c * 16, t, h // 4, w // 4)
+
+
+def space_to_depth(x, factor):
+    """spaceToDepth (VideoEncoder.swift:40-68): channel = c*ft*fh*fw + (it*fh + ih)*fw + iw; odd T is padded in FRONT with
+    copies of the first frame."""
+    ft, fh, fw = factor
+    b, c, t, h, w = x.shape
+    if t % ft != 0:
+        x = np.concatenate([x[:, :, :1]] * (ft - t % ft) + [x], axis=2)
+        t = x.shape[2]
+    o = x.reshape(b, c, t // ft, ft, h // fh, fh, w // fw, fw).transpose(0, 1, 3, 5, 7, 2, 4, 6)
+    return o.reshape(b, c * ft * fh * fw, t // ft, h // fh, w // fw)
+
+
+def enc_res_block(w, p, x):
+    h = silu(pixel_norm(x))
+    h = conv3d_causal_zero(h, w[p + "conv1.conv.weight"], w[p + "conv1.conv.bias"])
+    h = silu(pixel_norm(h))
+    h = conv3d_causal_zero(h, w[p + "conv2.conv.weight"], w[p + "conv2.conv.bias"])
+    return (h + x).astype(F32)
+
+
+def enc_downsample(w, p, x, factor, c_out):
+    main = space_to_depth(conv3d_causal_zero(x, w[p + "conv.conv.weight"], w[p + "conv.conv.bias"]), factor)
+    res = space_to_depth(x, factor)
+    b, cs, t2, h2, w2 = res.shape
+    avg = res.reshape(b, c_out, cs // c_out, t2, h2, w2).mean(axis=2, dtype=np.float64).astype(F32)
+    return (main + avg).astype(F32)
+
+
+def vae_encoder_param_shapes(base=128):
+    ch = [base, base * 2, base * 4, base * 8, base * 16]
+    sh = {"conv_in.conv.weight": (ch[0], 48, 3, 3, 3), "conv_in.conv.bias": (ch[0],),
+          "conv_out.conv.weight": (129, ch[4], 3, 3, 3), "conv_out.conv.bias": (129,)}
+    for i in range(4):
+        for j in range(ENC_RESNETS[i]):
+            for cn in ("conv1", "conv2"):
+                sh[f"down_blocks_{i}.resnets.resnets.{j}.{cn}.conv.weight"] = (ch[i], ch[i], 3, 3, 3)
+                sh[f"down_blocks_{i}.resnets.resnets.{j}.{cn}.conv.bias"] = (ch[i],)
+        f = ENC_FACTORS[i]
+        co = ch[i + 1] // (f[0] * f[1] * f[2])
+        sh[f"down_blocks_{i}.downsamplers.conv.conv.weight"] = (co, ch[i], 3, 3, 3)
+        sh[f"down_blocks_{i}.downsamplers.conv.conv.bias"] = (co,)
+    for j in range(2):
+        for cn in ("conv1", "conv2"):
+            sh[f"mid_block.resnets.{j}.{cn}.conv.weight"] = (ch[4], ch[4], 3, 3, 3)
+            sh[f"mid_block.resnets.{j}.{cn}.conv.bias"] = (ch[4],)
+    return sh
+
+
+def synth_vae_encoder_weights(base=128, seed=66):
+    rng = np.random.default_rng(seed)
+    w = {}
+    for k, shp in vae_encoder_param_shapes(base).items():
+        if k.endswith(".bias"):
+            v = 0.01 * rng.standard_normal(shp)
+        else:
+            v = rng.standard_normal(shp) / math.sqrt(27 * shp[1])
+        w[k] = bf16_round(v.astype(F32))
+    return w
+
+
+def vae_encode(w, pixels, base=128, causal=True, mean=None, std=None):
+    """VideoEncoder.callAsFunction (VideoEncoder.swift:262-311) then encodeImage's (latent - mean_of_means)/std_of_means
+    (LTXPipeline.swift:1920-1927) when mean/std are given. pixels [B,3,T,H,W] -> [B,128,T',H/32,W/32]."""
+    ch = [base, base * 2, base * 4, base * 8, base * 16]
+    h = encoder_patchify(pixels.astype(F32))
+    h = conv3d_causal_zero(h, w["conv_in.conv.weight"], w["conv_in.conv.bias"], causal)
+    for i in range(4):
+        for j in range(ENC_RESNETS[i]):
+            h = enc_res_block(w, f"down_blocks_{i}.resnets.resnets.{j}.", h)
+        h = enc_downsample(w, f"down_blocks_{i}.downsamplers.", h, ENC_FACTORS[i], ch[i + 1])
+    for j in range(2):
+        h = enc_res_block(w, f"mid_block.resnets.{j}.", h)
+    h = silu(pixel_norm(h))
+    h = conv3d_causal_zero(h, w["conv_out.conv.weight"], w["conv_out.conv.bias"], causal)[:, :128]
+    if mean is not None:
+        h = (h - mean.astype(F32).reshape(1, -1, 1, 1, 1)) / std.astype(F32).reshape(1, -1, 1, 1, 1)
+    return h.astype(F32)
+
+
+def map_vae_encoder_key(key):
+    """mapVAEEncoderWeights (ModelDownloader.swift:1222-1283); None for non-encoder tensors."""
+    if not key.startswith("encoder."):
+        return None
+    k = key[len("encoder."):]
+    for i in range(4):
+        if k.startswith(f"down_blocks.{i}."):
+            k = f"down_blocks_{i}." + k[len(f"down_blocks.{i}."):]
+            break
+    for i in range(4):
+        rp = f"down_blocks_{i}.resnets."
+        if k.startswith(rp):
+            if not k[len(rp):].startswith("resnets."):
+                k = rp + "resnets." + k[len(rp):]
+            break
+    for i in range(4):
+        dp = f"down_blocks_{i}.downsamplers.0."
+        if k.startswith(dp):
+            k = f"down_blocks_{i}.downsamplers." + k[len(dp):]
+            break
+    return k
+
+
+def vae_encoder_file_keys(w):
+    out = {}
+    for k, v in w.items():
+        fk = k
+        for i in range(4):
+            fk = fk.replace(f"down_blocks_{i}.resnets.resnets.", f"down_blocks.{i}.resnets.")
+            fk = fk.replace(f"down_blocks_{i}.downsamplers.", f"down_blocks.{i}.downsamplers.0.")
+        out["encoder." + fk] = v
+    return out

@@ -321,3 +321,33 @@ def test_connector_oracle_internals(oracle):
     reg = -np.arange(4, dtype=np.float32).reshape(4, 1) - 1
     out = oracle.replace_padded_with_registers(hid, np.array([[0, 0, 0, 1, 1, 1, 1, 1]], bool), reg)
     assert out[0, :, 0].tolist() == [4, 5, 6, 7, 8, -2, -3, -4]  # 5 valid tokens first, then registers 5%4, 6%4, 7%4
+
+
+def test_vae_encoder_key_mapping_and_shapes(ltx, oracle):
+    kat = {
+        "encoder.conv_in.conv.weight": "conv_in.conv.weight",
+        "encoder.down_blocks.0.resnets.3.conv2.conv.bias": "down_blocks_0.resnets.resnets.3.conv2.conv.bias",
+        "encoder.down_blocks.2.downsamplers.0.conv.conv.weight": "down_blocks_2.downsamplers.conv.conv.weight",
+        "encoder.mid_block.resnets.1.conv1.conv.weight": "mid_block.resnets.1.conv1.conv.weight",
+        "encoder.down_blocks_1.resnets.resnets.0.conv1.conv.weight": "down_blocks_1.resnets.resnets.0.conv1.conv.weight",
+        "decoder.conv_in.conv.weight": None,
+        "latents_mean": None,
+    }
+    for k, v in kat.items():
+        assert ltx.map_vae_encoder_key(k) == v, k
+        assert oracle.map_vae_encoder_key(k) == v, k
+    sh = oracle.vae_encoder_param_shapes(128)
+    assert sh["conv_out.conv.weight"] == (129, 2048, 3, 3, 3) and sh["down_blocks_3.downsamplers.conv.conv.weight"] == (256, 1024, 3, 3, 3)
+    assert sh["down_blocks_1.downsamplers.conv.conv.weight"] == (256, 256, 3, 3, 3)
+    for fk in oracle.vae_encoder_file_keys({k: None for k in sh}):
+        assert ltx.map_vae_encoder_key(fk) in sh
+    # latent frame count: three causal temporal halvings with front padding
+    assert [ltx.vae_encoder_latent_frames(t) for t in (1, 2, 8, 9, 17, 25, 121)] == [1, 1, 1, 2, 3, 4, 16]
+    # oracle index helpers
+    x = np.arange(2 * 3 * 4 * 4, dtype=np.float32).reshape(1, 2, 3, 4, 4)
+    s = oracle.space_to_depth(x, (2, 2, 2))
+    assert s.shape == (1, 16, 2, 2, 2)
+    assert s[0, 0, 0, 0, 0] == x[0, 0, 0, 0, 0] and s[0, 4, 0, 0, 0] == x[0, 0, 0, 0, 0]  # padded front frame = frame 0 (it=0 and it=1)
+    assert s[0, 1, 1, 0, 0] == x[0, 0, 1, 0, 1] and s[0, 8 + 7, 1, 1, 1] == x[0, 1, 2, 3, 3]
+    p = oracle.encoder_patchify(np.arange(3 * 8 * 8, dtype=np.float32).reshape(1, 3, 1, 8, 8))
+    assert p.shape == (1, 48, 1, 2, 2) and p[0, 16 + 1 * 4 + 2, 0, 1, 0] == 64 + (4 + 2) * 8 + (0 + 1)  # c=1, pw=1, ph=2

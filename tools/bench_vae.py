@@ -16,8 +16,23 @@ ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--F", type=int, default=4)
 ap.add_argument("--H", type=int, default=16)
 ap.add_argument("--W", type=int, default=24)
+ap.add_argument("--encode", action="store_true", help="time the VAE encoder on one (32H x 32W) image instead (image-to-video)")
 a = ap.parse_args()
 ctx = ltx.Context(0)
+if a.encode:
+    ctx.vae_encoder_init_synthetic(0, seed=66)
+    px = torch.rand((1, 3, 1, a.H * 32, a.W * 32), dtype=torch.float32, device="cuda") * 2 - 1
+    lat = torch.empty((1, 128, 1, a.H, a.W), dtype=torch.float32, device="cuda")
+    ctx.vae_encode_dev(px, lat)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(lat).all())
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        ctx.vae_encode_dev(px, lat)
+    torch.cuda.synchronize()
+    print(f"vae encode {a.W * 32}x{a.H * 32} image: {1e3 * (time.perf_counter() - t0) / a.iters:.3f} ms")
+    ctx.close()
+    sys.exit(0)
 ctx.vae_init_synthetic(seed=77)
 lat = torch.empty((1, 128, a.F, a.H, a.W), dtype=torch.float32, device="cuda")
 ctx.op_fill_normal_f32(lat, seed=45)
