@@ -193,6 +193,17 @@ class LTXPipeline {
         return n;
     }
     void loadUpscaler(const std::string& path) { check(ltx_upscaler_load(ctx_, path.c_str())); }
+    // loadVAEEncoder / encodeImage (LTXPipeline.swift:1871-1932) without the image file I/O: pixels [1][3][1][H][W] f32 in [-1,1]
+    // -> ImageConditioning whose latent is already normalised with the decoder's statistics (loadModels first).
+    void loadVAEEncoder(const std::string& vaeWeightsPath) { check(ltx_vae_encoder_load(ctx_, vaeWeightsPath.c_str(), 0)); }
+    void unloadVAEEncoder() { check(ltx_vae_encoder_unload(ctx_)); }
+    ImageConditioning encodeImage(const std::vector<float>& pixels, int width, int height) {
+        if (pixels.size() != size_t(3) * width * height) throw LTXError(LTXError::invalidConfiguration, "image tensor must be [1][3][1][H][W]");
+        ImageConditioning c;
+        c.imageLatent.resize(size_t(128) * (height / 32) * (width / 32));
+        check(ltx_vae_encode(ctx_, pixels.data(), 1, height, width, 1, c.imageLatent.data()));
+        return c;
+    }
     // Connector part of the text encoder (VideoGemmaTextEncoderModel, LTXTextEncoder.swift:535-643; loaded in
     // loadModels, LTXPipeline.swift:420-540): reads text_embedding_projection.* / video_embeddings_connector.* from the
     // unified checkpoint or text_proj_in.* / video_connector.* from a standalone connector file.
