@@ -217,6 +217,15 @@ int ltx_dit_forward_tokens(ltx_ctx* ctx, const uint16_t* latent, const uint16_t*
                            const int32_t* mask, int B, int F, int H, int W, int S, float* velocity);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Frame export helpers (the part that is verifiable here; VideoExporter.swift:563-580). Pure host code.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* tensorToImages' pixel conversion: out = uint8(clip(x, 0, 1) * 255), f32 multiply then truncation toward zero. */
+int ltx_frames_to_u8(const float* frames, long n, uint8_t* out);
+/* Writes one (H, W, 3) uint8 frame as a PNG (8-bit RGB, stored/uncompressed deflate blocks - no external codec). The
+ * reference hands CGImages to AVAssetWriter (Apple-only); an MP4 muxer is outside this library. */
+int ltx_write_png(const char* path, const uint8_t* rgb, int width, int height);
+
+/* ------------------------------------------------------------------------------------------------------------
  * VAE encoder (VideoEncoder.swift:211-312, call site encodeImage LTXPipeline.swift:1902-1932): turns the
  * image-to-video conditioning image into the latent that ltx_denoise_options.cond_latent takes.
  * ---------------------------------------------------------------------------------------------------------- */

@@ -106,6 +106,21 @@ def map_lora_key(key):
     return _map_key(lib.ltx_map_lora_key, key)
 
 
+def frames_to_u8(frames):
+    """``VideoExporter.tensorToImages`` pixel conversion: uint8(clip(x,0,1)*255), truncating."""
+    f = np.ascontiguousarray(frames, dtype=np.float32)
+    out = np.empty(f.shape, dtype=np.uint8)
+    _check(lib.ltx_frames_to_u8(f.ctypes.data, f.size, out.ctypes.data))
+    return out
+
+
+def write_png(path, rgb):
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, c = a.shape
+    assert c == 3
+    _check(lib.ltx_write_png(str(path).encode(), a.ctypes.data, w, h))
+
+
 def map_vae_encoder_key(key):
     """``mapVAEEncoderWeights`` (ModelDownloader.swift:1222-1283); None for non-encoder tensors."""
     return _map_key(lib.ltx_map_vae_encoder_key, key)

@@ -1099,3 +1099,15 @@ int ltx_map_vae_encoder_key(const char* file_key, char* out, int cap) {
     if (!file_key || !map_vae_encoder_file_key(file_key, &mk)) return 0;
     return copy_str(mk, out, cap);
 }
+
+
+/* ---- frame export ---- */
+int ltx_frames_to_u8(const float* frames, long n, uint8_t* out) {
+    if (!frames || !out || n < 0) return LTX_ERR_INVALID_CONFIGURATION;
+    frames_to_u8(frames, n, out);
+    return LTX_OK;
+}
+
+int ltx_write_png(const char* path, const uint8_t* rgb, int width, int height) {
+    return write_png_rgb8(path, rgb, width, height) ? LTX_OK : LTX_ERR_FILE_NOT_FOUND;
+}

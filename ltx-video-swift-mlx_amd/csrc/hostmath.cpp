@@ -7,6 +7,8 @@
 #include <string.h>
 #include <stdio.h>
 
+#include <vector>
+
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -422,4 +424,91 @@ bool map_vae_encoder_file_key(const std::string& file_key, std::string* module_k
     }
     *module_key = k;
     return true;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// frame export
+// ---------------------------------------------------------------------------------------------------------------
+void frames_to_u8(const float* frames, long n, uint8_t* out) {
+    for (long i = 0; i < n; ++i) {
+        float v = frames[i];
+        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);  // MLX.clip; NaN compares false twice and converts to 0 below
+        const float s = v * 255.0f;
+        out[i] = (s == s) ? (uint8_t)s : 0;        // asType(.uint8): truncation toward zero
+    }
+}
+
+namespace {
+uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x);
+}
+void png_chunk(FILE* f, const char* type, const std::vector<uint8_t>& data) {
+    std::vector<uint8_t> hdr;
+    put_be32(hdr, (uint32_t)data.size());
+    fwrite(hdr.data(), 1, 4, f);
+    fwrite(type, 1, 4, f);
+    if (!data.empty()) fwrite(data.data(), 1, data.size(), f);
+    uint32_t crc = crc32_update(0xFFFFFFFFu, (const uint8_t*)type, 4);
+    if (!data.empty()) crc = crc32_update(crc, data.data(), data.size());
+    std::vector<uint8_t> c;
+    put_be32(c, crc ^ 0xFFFFFFFFu);
+    fwrite(c.data(), 1, 4, f);
+}
+}  // namespace
+
+bool write_png_rgb8(const char* path, const uint8_t* rgb, int width, int height) {
+    if (!path || !rgb || width < 1 || height < 1) return false;
+    FILE* f = fopen(path, "wb");
+    if (!f) return false;
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    fwrite(sig, 1, 8, f);
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, (uint32_t)width);
+    put_be32(ihdr, (uint32_t)height);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);  // 8-bit, RGB, deflate, no filter/interlace
+    png_chunk(f, "IHDR", ihdr);
+    // raw scanlines (filter byte 0) wrapped in stored deflate blocks of <= 65535 bytes, zlib header + Adler-32
+    const size_t row = (size_t)width * 3 + 1, raw_n = row * height;
+    std::vector<uint8_t> raw(raw_n);
+    for (int y = 0; y < height; ++y) {
+        raw[y * row] = 0;
+        memcpy(&raw[y * row + 1], rgb + (size_t)y * width * 3, (size_t)width * 3);
+    }
+    std::vector<uint8_t> z;
+    z.reserve(raw_n + raw_n / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t off = 0; off < raw_n;) {
+        const size_t len = raw_n - off > 65535 ? 65535 : raw_n - off;
+        z.push_back(off + len == raw_n ? 1 : 0);
+        z.push_back(len & 0xff); z.push_back(len >> 8);
+        z.push_back(~len & 0xff); z.push_back((~len >> 8) & 0xff);
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + len);
+        for (size_t i = 0; i < len; ++i) {
+            a = (a + raw[off + i]) % 65521u;
+            b = (b + a) % 65521u;
+        }
+        off += len;
+    }
+    put_be32(z, (b << 16) | a);
+    png_chunk(f, "IDAT", z);
+    png_chunk(f, "IEND", {});
+    const bool ok = ferror(f) == 0;
+    fclose(f);
+    return ok;
 }

@@ -62,3 +62,7 @@ bool map_text_encoder_file_key(const std::string& file_key, std::string* module_
 // connector RoPE: integer positions 0..T-1 on one axis, split type, f64 math (LTXTextEncoder.swift:482-497,
 // LTXRoPE.swift:375-490). cos/sin [T][dim/2] f32 (no padding slots: one axis -> dim/2 frequencies).
 void rope_tables_1d(int T, int dim, double theta, int max_pos, std::vector<float>* cos_out, std::vector<float>* sin_out);
+
+// frame export (VideoExporter.swift:563-580)
+void frames_to_u8(const float* frames, long n, uint8_t* out);
+bool write_png_rgb8(const char* path, const uint8_t* rgb, int width, int height);

@@ -35,7 +35,7 @@ struct Args {
     bool twoStage = false, distilledLora = false, enhancePrompt = false, audio = false, debug = false, profile = false,
          dryRun = false;
     // additions of this build
-    std::string embeddings, vaeWeights, upscalerWeights, distilledLoraPath;
+    std::string embeddings, vaeWeights, upscalerWeights, distilledLoraPath, pngDir;
     int vaeTile = 0, vaeOverlap = 1;
     int numLayers = 0, numHeads = 0, captionChannels = 0;  // reduced architectures for tests (0 = reference default)
 };
@@ -98,6 +98,7 @@ Args parse_generate(int argc, char** argv, int start) {
         else if (k == "--upscaler-weights") a.upscalerWeights = need(i);
         else if (k == "--distilled-lora-path") a.distilledLoraPath = need(i);
         else if (k == "--vae-tile") a.vaeTile = std::stoi(need(i));
+        else if (k == "--png-dir") a.pngDir = need(i);
         else if (k == "--vae-overlap") a.vaeOverlap = std::stoi(need(i));
         else if (k == "--num-layers") a.numLayers = std::stoi(need(i));
         else if (k == "--num-heads") a.numHeads = std::stoi(need(i));
@@ -231,6 +232,18 @@ int run_generate(const Args& a) {
     std::cout << "Generated " << r.numFrames << " frames (" << r.width << "x" << r.height << ") in " << r.generationTime << "s\n";
     std::ofstream f(a.output, std::ios::binary);
     f.write(reinterpret_cast<const char*>(r.frames.data()), std::streamsize(r.frames.size() * sizeof(float)));
+    if (!a.pngDir.empty()) {  // tensorToImages' uint8 conversion (VideoExporter.swift:563-580), one PNG per frame
+        std::vector<uint8_t> u8(r.frames.size());
+        ltx_frames_to_u8(r.frames.data(), long(r.frames.size()), u8.data());
+        const size_t fsz = size_t(r.height) * r.width * 3;
+        for (int fi = 0; fi < r.numFrames; ++fi) {
+            char name[64];
+            snprintf(name, sizeof(name), "/frame_%04d.png", fi);
+            if (ltx_write_png((a.pngDir + name).c_str(), u8.data() + fi * fsz, r.width, r.height) != 0)
+                throw LTXError(LTXError::fileNotFound, a.pngDir + name);
+        }
+        std::cout << r.numFrames << " PNG frames written to " << a.pngDir << "\n";
+    }
     std::ofstream j(a.output + ".json");
     j << "{\"frames\": " << r.numFrames << ", \"height\": " << r.height << ", \"width\": " << r.width
       << ", \"channels\": 3, \"dtype\": \"float32\", \"range\": [0, 1], \"seed\": " << r.seed << "}\n";

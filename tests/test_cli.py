@@ -64,10 +64,23 @@ def test_cli_generate_end_to_end(ltx, oracle, tmp_path):
     rc, so, se = run("generate", "test", "-w", "64", "-h", "64", "-f", "9", "--seed", "7", "-o", str(out),
                      "--ltx-weights", str(tmp_path / "dit.safetensors"), "--vae-weights", str(tmp_path / "vae.safetensors"),
                      "--embeddings", str(tmp_path / "emb.safetensors"), "--num-layers", "2", "--num-heads", "2",
-                     "--caption-channels", "128", "--profile")
+                     "--caption-channels", "128", "--profile", "--png-dir", str(tmp_path))
     assert rc == 0, se
     assert "Step 8/8" in so and "Generated 9 frames (64x64)" in so
     meta = json.loads(open(str(out) + ".json").read())
     assert meta == {"frames": 9, "height": 64, "width": 64, "channels": 3, "dtype": "float32", "range": [0, 1], "seed": 7}
     frames = np.fromfile(out, np.float32).reshape(9, 64, 64, 3)
     assert np.isfinite(frames).all() and frames.min() >= 0 and frames.max() <= 1
+    # --png-dir: one PNG per frame holding uint8(clip(x,0,1)*255) (VideoExporter.swift:563-580)
+    import struct
+    import zlib
+    raw = (tmp_path / "frame_0003.png").read_bytes()
+    pos, idat = 8, b""
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        if typ == b"IDAT":
+            idat += raw[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(64, 64 * 3 + 1)[:, 1:].reshape(64, 64, 3)
+    assert np.array_equal(px, (frames[3] * np.float32(255)).astype(np.uint8))
+    assert (tmp_path / "frame_0008.png").exists() and not (tmp_path / "frame_0009.png").exists()
