@@ -17,6 +17,8 @@
 #include <type_traits>
 
 #include "gemm.h"
+
+#include <stdlib.h>
 #include "runtime.h"
 
 namespace {
@@ -429,6 +431,10 @@ template <int N>
 LTX_DEVFN void wait_lgkm_vmcnt_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
+template <int N>
+LTX_DEVFN void wait_lgkm_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
 LTX_DEVFN void wait_lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 LTX_DEVFN void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 template <int N>
@@ -719,22 +725,24 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // v4: phased "ping-pong" kernel for the wide DiT GEMMs (fused q/k, FFN up): BMx256 output tile (BM = 192 or 256),
 // BK = 64, 8 waves as 2(M) x 4(N). The two waves that share a SIMD (wave w and w+4: wave rows 0 and 1) run half a
-// phase apart: while one is inside its MFMA cluster (priority 1) the other issues the LDS fragment reads and LDS-DMA
-// pieces for its next cluster; two workgroup barriers per phase hand the roles over. Per K-tile a wave walks its
-// WMx64 output in four quadrants (a0,b0) (a0,b1) (a1,b1) (a1,b0), so every quadrant re-uses one operand half held
-// in registers and needs 0/4/6-8/10-12 ds_read_b128 for 12-16 MFMAs.
+// phase apart: while one is inside its MFMA cluster (priority 1) the other stages LDS-DMA pieces and waits; two
+// workgroup barriers per phase hand the roles over. Per K-tile a wave walks its WMx64 output in four quadrants, each
+// re-using one operand half held in registers; the fragments of the NEXT quadrant are read from LDS inside the
+// current MFMA cluster (one ds_read per MFMA), so no LDS latency sits between the barriers.
+//   even tile: (a0,b0) (a0,b1) (a1,b1) (a1,b0)      odd tile: (a0,b1) (a0,b0) (a1,b0) (a1,b1)   [serpentine: the first
+//   quadrant of a tile needs only register sets the last quadrant of the previous tile does not use]
 // LDS: 2 slots (K-tile parity) x [A image BM rows | B image 256 rows] x 128 B, rows ordered [half][wave row/col][..]
 // so that an operand half is a contiguous row range; 16-B chunk c of LDS row r sits at chunk c ^ ((r >> 1) & 7).
 // Staging: one wave-instruction = 8 rows; unit u of an operand = LDS rows [64u, 64u+64) over the 8 waves.
-//   tile t+2 replaces tile t (same slot) one phase after the last read of the rows it overwrites:
-//     BM=256:  P2(t): A u0,u1   P3(t): B u0,u1   P4(t): B u2,u3   P1(t+1): A u2,u3
-//     BM=192:  P2(t): A u0,B u0 P3(t): B u1,u2   P4(t): B u3,A u1 P1(t+1): A u2
-//   (reads: A half 0 + B half 0 in P1, B half 1 in P2, A half 1 in P3; every phase retires its reads with
-//   lgkmcnt(0) BEFORE its first barrier, so the other wave group - which is one barrier behind - stages only rows
-//   whose reads have completed).  One counted wait per K-tile: vmcnt(6) in P4(t+1) leaves the six pieces of tile
-//   t+3 in flight and retires all of tile t+2, which is first read one phase later (P1(t+2)).
+// Hazards (wave group 1 runs one barrier behind group 0; L(p)/M(p) = the load / MFMA section of phase p):
+//   RAW: data read in M(p) must have been waited for (vmcnt) in L(p-1) or earlier by every wave.
+//   WAR: a buffer last read in M(q) may be re-staged from L(q+2) on.
+// Schedule for tile T (Bf/Bs = the B half its first / second quadrant pair needs):
+//   staged:  Bf(T) in L(P2(T-2))   Bs(T) in L(P3(T-2))   A half 0 in L(P4(T-2))   A half 1 in L(P1(T-1))
+//   read:    A half 0 + Bf(T) in M(P4(T-1))   Bs(T) in M(P1(T))   A half 1 in M(P2(T))
+//   waited:  start of L(P3(T-1)): everything but {A half 1 (T), Bf(T+1)} ; start of L(P1(T)): everything but the three
+//            groups of tile T+1 staged so far.  The weights (B, HBM-cold in the DiT) get 4-5 phases of flight.
 // ---------------------------------------------------------------------------------------------------------------
-
 template <int BM, int BN>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel_v4(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -744,6 +752,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_v4(const GemmArgs g) {
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, SLOT = A_BYTES + B_BYTES;
     constexpr int AU = BM / 64, BU = BN / 64;  // staging units (= LDS-DMA instructions per wave) per K-tile
     constexpr int HM = BM / 2, HN = BN / 2, QM = WM / 2, QN = WN / 2;
+    // LDS-DMA instructions per wave of the four staging groups
+    constexpr int G_BF = 2, G_BS = 2, G_A0 = 2, G_A1 = (BM == 256) ? 2 : 1;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -786,20 +796,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_v4(const GemmArgs g) {
                                          (__attribute__((address_space(3))) void*)(smem + slot * SLOT + A_BYTES + (8 * u + wave) * 1024),
                                          16, 0, 0);
     };
-    // the four per-phase staging groups of one K-tile, in issue order (see the header)
-    auto stage_g2 = [&](int slot, int kt) {  // issued in P2(t) for tile t+2
-        if constexpr (BM == 256) { stage_a(slot, 0, kt); stage_a(slot, 1, kt); } else { stage_a(slot, 0, kt); stage_b(slot, 0, kt); }
+    // B half h = units 2h, 2h+1. A half 0 = units 0,1 (BM=256) / 0 and the first half of 1 (BM=192: unit 1 straddles);
+    // A half 1 = units 2,3 / 2. The straddling unit is staged with half 0: its half-1 rows are free by then (last read M(P2)).
+    auto stage_bh = [&](int slot, int h, int kt) { stage_b(slot, 2 * h, kt); stage_b(slot, 2 * h + 1, kt); };
+    auto stage_a0 = [&](int slot, int kt) { stage_a(slot, 0, kt); stage_a(slot, 1, kt); };
+    auto stage_a1 = [&](int slot, int kt) {
+        stage_a(slot, 2, kt);
+        if constexpr (BM == 256) stage_a(slot, 3, kt);
     };
-    auto stage_g3 = [&](int slot, int kt) {
-        if constexpr (BM == 256) { stage_b(slot, 0, kt); stage_b(slot, 1, kt); } else { stage_b(slot, 1, kt); stage_b(slot, 2, kt); }
-    };
-    auto stage_g4 = [&](int slot, int kt) {
-        if constexpr (BM == 256) { stage_b(slot, 2, kt); stage_b(slot, 3, kt); } else { stage_b(slot, 3, kt); stage_a(slot, 1, kt); }
-    };
-    auto stage_g1 = [&](int slot, int kt) {  // issued in P1(t+1) for tile t+2
-        if constexpr (BM == 256) { stage_a(slot, 2, kt); stage_a(slot, 3, kt); } else { stage_a(slot, 2, kt); }
-    };
-    constexpr int G1 = (BM == 256) ? 2 : 1;  // pieces in group 1; groups 2..4 have two each
 
     // ---- fragment reads
     const int frow = lane & 15, fsw = (lane >> 1) & 7;
@@ -812,9 +816,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_v4(const GemmArgs g) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    s16x8 fa[MIH][2], fb0[NIH][2], fb1[NIH][2];
+    s16x8 fa0[MIH][2], fa1[MIH][2], fb0[NIH][2], fb1[NIH][2];
 
-    auto read_a = [&](int slot, int h) {
+    auto read_a = [&](int slot, int h, s16x8(&fa)[MIH][2]) {
         const char* base = smem + slot * SLOT + a_off + h * HM * ROW_BYTES;
 #pragma unroll
         for (int i = 0; i < MIH; ++i) {
@@ -830,62 +834,93 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_v4(const GemmArgs g) {
             fb[j][1] = *(const s16x8*)(base + j * 16 * ROW_BYTES + fch1);
         }
     };
-    auto cluster = [&](auto hm_tag, auto hn_tag, const s16x8(&fb)[NIH][2]) {
-        constexpr int hm = decltype(hm_tag)::value, hn = decltype(hn_tag)::value;
+    // MFMA section of one phase: quadrant (hm, hn) from the given register sets; `reads()` issues the ds_reads of the next
+    // quadrant's missing operand(s) (NR of them), interleaved one per MFMA behind the first product.
+    auto cluster = [&](auto hm_tag, auto hn_tag, const s16x8(&fa)[MIH][2], const s16x8(&fb)[NIH][2], auto nr_tag, auto&& reads) {
+        constexpr int hm = decltype(hm_tag)::value, hn = decltype(hn_tag)::value, NR = decltype(nr_tag)::value;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+        acc[hm * MIH][hn * NIH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[0][0]),
+                                                                           __builtin_bit_cast(bf16x8_t, fb[0][0]), acc[hm * MIH][hn * NIH], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        reads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < MIH; ++i)
 #pragma unroll
                 for (int j = 0; j < NIH; ++j)
-                    acc[hm * MIH + i][hn * NIH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8_t, fa[i][ks]), __builtin_bit_cast(bf16x8_t, fb[j][ks]),
-                        acc[hm * MIH + i][hn * NIH + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+                    if (ks + i + j > 0)
+                        acc[hm * MIH + i][hn * NIH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, fa[i][ks]), __builtin_bit_cast(bf16x8_t, fb[j][ks]),
+                            acc[hm * MIH + i][hn * NIH + j], 0, 0, 0);
+        constexpr int NM = 2 * MIH * NIH - 1;
+        constexpr int NI_ = NR < NM ? NR : NM;
+#pragma unroll
+        for (int q = 0; q < NI_; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one ds_read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - NI_, 0);
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
         raw_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using RA = std::integral_constant<int, 2 * MIH>;            // reads of one A half
+    using RB = std::integral_constant<int, 2 * NIH>;            // reads of one B half
+    using RAB = std::integral_constant<int, 2 * MIH + 2 * NIH>;
+    auto no_reads = [] {};
 
     const int nk = g.K / BK;  // >= 2 (launcher)
-    // prologue: tile 0 complete, tile 1 except its group 1 (issued in P1 of tile 0)
-    stage_g2(0, 0); stage_g3(0, 0); stage_g4(0, 0); stage_g1(0, 0);
-    stage_g2(1, 1); stage_g3(1, 1); stage_g4(1, 1);
-    wait_vmcnt_barrier<6>();
+    // prologue: tile 0 complete; tile 1: Bf = B half 1, Bs = B half 0, A half 0 (its A half 1 is staged in P1 of tile 0)
+    stage_bh(0, 0, 0); stage_bh(0, 1, 0); stage_a0(0, 0); stage_a1(0, 0);
+    stage_bh(1, 1, 1); stage_bh(1, 0, 1); stage_a0(1, 1);
+    wait_vmcnt_barrier<G_BF + G_BS + G_A0>();
+    read_a(0, 0, fa0);
+    read_b(0, 0, fb0);
     if (wr == 1) raw_barrier();  // wave row 1 runs one barrier behind wave row 0 from here on
 
-    // One K-tile = four phases. MODE 0: steady (tile t+2 exists); 1: tile t+1 is the last (stage only its group 1);
-    // 2: last tile (nothing to stage).
-    auto ktile = [&](int t, auto slot_tag, auto mode_tag) {
-        constexpr int S = decltype(slot_tag)::value, MODE = decltype(mode_tag)::value;
-        // P1: (a0, b0)
-        read_b(S, 0, fb0);
-        read_a(S, 0);
-        if constexpr (MODE <= 1) stage_g1(S ^ 1, t + 1);
-        wait_lgkm_barrier();
-        cluster(I0{}, I0{}, fb0);
-        // P2: (a0, b1)
-        read_b(S, 1, fb1);
-        if constexpr (MODE == 0) stage_g2(S, t + 2);
-        wait_lgkm_barrier();
-        cluster(I0{}, I1{}, fb1);
-        // P3: (a1, b1)
-        read_a(S, 1);
-        if constexpr (MODE == 0) stage_g3(S, t + 2);
-        wait_lgkm_barrier();
-        cluster(I1{}, I1{}, fb1);
-        // P4: (a1, b0); retire tile t+1 (read from P1 of the next tile on)
-        if constexpr (MODE == 0) {
-            stage_g4(S, t + 2);
-            wait_lgkm_vmcnt_barrier<6>();
+    // One K-tile = four phases; PAR = tile parity (slot, quadrant order). MODE 0: tile t+2 exists (full staging);
+    // 1: t+1 is the last tile; 2: t is the last tile.
+    auto ktile = [&](int t, auto par_tag, auto mode_tag) {
+        constexpr int S = decltype(par_tag)::value, MODE = decltype(mode_tag)::value;
+        constexpr int FH = S;      // B half of the tile's first quadrant pair (even tile: 0, odd tile: 1)
+        constexpr int SH = S ^ 1;  // B half of the second pair
+        auto& fbf = (FH == 0) ? fb0 : fb1;  // registers of Bf / Bs
+        auto& fbs = (FH == 0) ? fb1 : fb0;
+        // ---- P1: (a0, Bf); next quadrant needs Bs
+        if constexpr (MODE <= 1) {
+            wait_lgkm_vmcnt<G_BF + G_BS + G_A0>();  // A half 1 of this tile has landed (for every wave after the barrier)
+            stage_a1(S ^ 1, t + 1);
         } else {
-            wait_lgkm_vmcnt_barrier<0>();
+            wait_lgkm_vmcnt<0>();
         }
-        cluster(I1{}, I0{}, fb0);
+        raw_barrier();
+        cluster(I0{}, std::integral_constant<int, FH>{}, fa0, fbf, RB{}, [&] { read_b(S, SH, fbs); });
+        // ---- P2: (a0, Bs); next quadrant needs a1
+        if constexpr (MODE == 0) stage_bh(S, (S == 0) ? 0 : 1, t + 2);  // Bf(t+2): same parity -> same half as this tile's Bf
+        wait_lgkm_barrier();
+        cluster(I0{}, std::integral_constant<int, SH>{}, fa0, fbs, RA{}, [&] { read_a(S, 1, fa1); });
+        // ---- P3: (a1, Bs); nothing new to read for P4 = (a1, Bf)
+        if constexpr (MODE == 0) {
+            wait_lgkm_vmcnt<G_A1 + G_BF>();  // A half 0 and Bf of tile t+1 have landed
+            stage_bh(S, (S == 0) ? 1 : 0, t + 2);  // Bs(t+2)
+        } else {
+            wait_lgkm_vmcnt<0>();
+        }
+        raw_barrier();
+        cluster(I1{}, std::integral_constant<int, SH>{}, fa1, fbs, I0{}, no_reads);
+        // ---- P4: (a1, Bf); next tile's first quadrant needs a0 and ITS Bf (= the half this tile calls Bs)
+        if constexpr (MODE == 0) stage_a0(S, t + 2);
+        wait_lgkm_barrier();
+        if constexpr (MODE <= 1)
+            cluster(I1{}, std::integral_constant<int, FH>{}, fa1, fbf, RAB{}, [&] { read_a(S ^ 1, 0, fa0); read_b(S ^ 1, SH, fbs); });
+        else
+            cluster(I1{}, std::integral_constant<int, FH>{}, fa1, fbf, I0{}, no_reads);
     };
     int t = 0;
     for (; t + 3 < nk; t += 2) {
@@ -896,10 +931,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_v4(const GemmArgs g) {
     if (t + 3 == nk) {
         ktile(t, I0{}, I0{});
         ktile(t + 1, I1{}, I1{});
-        ktile(t + 2, I0{}, std::integral_constant<int, 2>{});
+        ktile(t + 2, I0{}, I2{});
     } else {
         ktile(t, I0{}, I1{});
-        ktile(t + 1, I1{}, std::integral_constant<int, 2>{});
+        ktile(t + 1, I1{}, I2{});
     }
     if (wr == 0) raw_barrier();  // re-align the two wave rows
     __syncthreads();
@@ -1085,7 +1120,8 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
         // implicit-GEMM convs: the per-tap gather arithmetic must hide under MFMAs (8-wave ring kernels interleave it;
         // the two-stage 4-wave kernel serialises it and ran the 256-channel VAE stage at 150 TFLOP/s). M is huge, so
         // tile-count quantisation does not matter; N <= 128 wants the 192x128 tile, wide N the same (B re-use).
-        launch_gemm_bf16_cfg(a, 21, stream);
+        const char* cc = getenv("LTX_CONV_CFG");  // A/B hook for tile experiments (21 = 192x128 ring, 23 = 256x128 ring)
+        launch_gemm_bf16_cfg(a, (cc && a.split_k <= 1) ? atoi(cc) : 21, stream);
         return;
     }
     int best = 0;
