@@ -128,3 +128,23 @@ def blend_tiles(chunks, overlap):
         else:
             result = torch.cat([result, nxt], 0)
     return torch.clamp((result + 1.0) / 2.0, 0.0, 1.0)
+
+
+def hip_forward_fn(ctx, context, mask, F, H, W, mask_all_ones=False):
+    """`forward_fn` for the loops above on the HIP path: patchify -> bf16 -> Context.dit_forward_dev with this branch's slice of
+    the [neg, pos] context -> unpatchify. `ctx` is an ltx Context on this rank's GPU, `context` [2,S,Cc] bf16 / `mask` [2,S] int32
+    device tensors (broadcast once with `broadcast_context`). The projected context and the cross-attention K/V of each branch
+    are cached inside the library under a per-branch version key, so only the first step pays for them."""
+    T = F * H * W
+
+    def fwd(latent, sigma, branch):
+        c = latent.shape[1]
+        tokens = latent.reshape(c, T).t().contiguous().to(torch.bfloat16).reshape(1, T, c)  # patchify (LatentUtils.swift:40-59)
+        ts = torch.full((1,), float(sigma), dtype=torch.float32, device=latent.device)
+        vel = torch.empty((1, T, c), dtype=torch.float32, device=latent.device)
+        m = None if mask is None else mask[branch:branch + 1].contiguous()
+        ctx.dit_forward_dev(tokens, context[branch:branch + 1].contiguous(), ts, m, F, H, W, vel, ctx_version=101 + branch,
+                            mask_all_ones=mask_all_ones)
+        return vel.reshape(T, c).t().reshape(1, c, F, H, W).contiguous()  # unpatchify
+
+    return fwd
