@@ -39,6 +39,13 @@ def main():
         out_lib = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         it = 0
         best = {}
+        bad = set()
+        for c in cfgs:  # a tile configuration may refuse a shape (e.g. full-tile-only kernels)
+            if c >= 0:
+                try:
+                    ctx.op_gemm(A, Bs[0], None, tile_cfg=c, **({"out_f32": out} if args.f32out else {"out_bf16": out}))
+                except Exception:
+                    bad.add(c)
         for r in range(args.rounds + 1):
             for c in cfgs:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -46,6 +53,8 @@ def main():
                 for _ in range(5):
                     B = Bs[it % nb]
                     it += 1
+                    if c in bad:
+                        continue
                     if c == -1:  # library GEMM (hipBLASLt through torch) - calibration only, never on the product path
                         torch.matmul(A, B.t(), out=out_lib)
                     elif c == -2:  # automatic tile choice
@@ -62,6 +71,9 @@ def main():
         fl = 2.0 * M * N * K
         line = f"{name:24s}"
         for c in cfgs:
+            if c in bad:
+                line += f" | c{c}:    n/a"
+                continue
             v = sorted(best[c])
             med = v[len(v) // 2]
             line += f" | c{c}: {fl / med / 1e9:6.0f}"
