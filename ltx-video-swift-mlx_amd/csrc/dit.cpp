@@ -216,6 +216,7 @@ void ensure_workspace(DiTModel* m, int B, int T, hipStream_t st) {
     m->ws_ada.ensure((size_t)8 * 6 * D * 4);
     m->ws_mod.ensure((size_t)8 * m->L * 6 * D * 4);
     m->ws_modout.ensure((size_t)8 * 2 * D * 4);
+    m->ws_splitk.ensure((size_t)8 << 22);  // 8 M floats: split-K partials of the few-tile GEMMs at small token counts
     m->ws_rows = (int)rows;
     m->ws_B = B;
     m->ws_Tpad = Tpad;
@@ -241,6 +242,8 @@ DiTModel::CtxCache* prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardA
     const int Spad = ((S + 63) / 64) * 64;
     const long rows = (long)B * S;
     hipStream_t st = ctx->stream;
+    m->ws_splitk.ensure((size_t)8 << 22);
+    const SplitWs sk{m->ws_splitk.as<float>(), (long)(m->ws_splitk.bytes / 4)};
     m->ctx_clock++;
     DiTModel::CtxCache* c = nullptr;
     if (a.ctx_version != 0)
@@ -269,11 +272,11 @@ DiTModel::CtxCache* prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardA
         e1.out_bf16 = m->ctx_tmp_h.as<bf16_t>();
         e1.ld_bf16 = D;
         e1.act = LTX_ACT_GELU_TANH;
-        gemm_linear(a.context, m->cfg.caption_channels, m->cap_l1, (int)rows, e1, st);
+        gemm_linear(a.context, m->cfg.caption_channels, m->cap_l1, (int)rows, e1, st, sk);
         GemmEpilogue e2;
         e2.out_bf16 = c->proj.as<bf16_t>();
         e2.ld_bf16 = D;
-        gemm_linear(m->ctx_tmp_h.as<bf16_t>(), D, m->cap_l2, (int)rows, e2, st);
+        gemm_linear(m->ctx_tmp_h.as<bf16_t>(), D, m->cap_l2, (int)rows, e2, st, sk);
     }
     for (int l = 0; l < L; ++l) {
         const DiTBlock& blk = m->blocks[l];
@@ -281,12 +284,12 @@ DiTModel::CtxCache* prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardA
         ek.out_f32 = m->ctx_tmp_kraw.as<float>();
         ek.ld_f32 = D;
         ek.round_bf16 = 1;  // the reference's K projection runs bf16 x bf16 -> bf16 (SURVEY R5/R11 dtype notes)
-        gemm_linear(c->proj.as<bf16_t>(), D, blk.k2, (int)rows, ek, st);
+        gemm_linear(c->proj.as<bf16_t>(), D, blk.k2, (int)rows, ek, st, sk);
         launch_qknorm_rope(m->ctx_tmp_kraw.as<float>(), D, blk.kn2, nullptr, nullptr, S,
                            c->k.as<bf16_t>() + (size_t)l * rows * D, D, (int)rows, D, m->cfg.norm_eps, st);
         for (int b = 0; b < B; ++b)
             gemm_vt(c->proj.as<bf16_t>() + (size_t)b * S * D, D, S, blk.v2,
-                    c->vt.as<bf16_t>() + ((size_t)l * B + b) * D * Spad, Spad, st);
+                    c->vt.as<bf16_t>() + ((size_t)l * B + b) * D * Spad, Spad, st, sk);
     }
     c->has_bias = (a.mask != nullptr) && !a.mask_all_ones;
     if (c->has_bias) launch_mask_to_bias(a.mask, c->bias.as<float>(), rows, st);
@@ -317,6 +320,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     DiTModel::CtxCache* cc = prepare_context(ctx, m, a);
     const int S = a.S, Spad = cc->Spad;
 
+    const SplitWs sk{m->ws_splitk.as<float>(), (long)(m->ws_splitk.bytes / 4)};
     float* x = m->ws_x.as<float>();
     bf16_t* xn = m->ws_xn.as<bf16_t>();
     bf16_t* xb = m->ws_xb.as<bf16_t>();
@@ -338,7 +342,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
         e.round_bf16 = 1;
         e.out_bf16 = xb;  // bf16 mirror (used by cross-attention when block 0 skips self-attention)
         e.ld_bf16 = D;
-        gemm_linear(a.latent, m->cfg.in_channels, m->patchify, (int)rows, e, st);
+        gemm_linear(a.latent, m->cfg.in_channels, m->patchify, (int)rows, e, st, sk);
     }
     // 2. timestep path in f32 activations x bf16 weights (LTXTimestepEmbedding.swift:62-124)
     launch_timestep_embedding(a.timesteps, m->cfg.timestep_scale_multiplier, m->ws_emb256.as<float>(), BG, 256, st);
@@ -363,10 +367,10 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             GemmEpilogue eqk;
             eqk.out_f32 = qk;
             eqk.ld_f32 = 2 * D;
-            gemm_linear(xn, D, blk.qk1, (int)rows, eqk, st);
+            gemm_linear(xn, D, blk.qk1, (int)rows, eqk, st, sk);
             launch_qknorm_rope2(qk, blk.qn1, q, qk + D, blk.kn1, k, 2 * D, D, m->rope_cos.as<float>(), m->rope_sin.as<float>(), T,
                                 (int)rows, D, eps, st);
-            for (int b = 0; b < B; ++b) gemm_vt(xn + (size_t)b * T * D, D, T, blk.v1, vt + (size_t)b * D * Tpad, Tpad, st);
+            for (int b = 0; b < B; ++b) gemm_vt(xn + (size_t)b * T * D, D, T, blk.v1, vt + (size_t)b * D * Tpad, Tpad, st, sk);
             AttnArgs at;
             at.Q = q; at.ldq = D; at.q_bstride = (long)T * D;
             at.K = k; at.ldk = D; at.k_bstride = (long)T * D;
@@ -384,7 +388,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             eo.gate_rowmap = rmap;
             eo.out_bf16 = xb;
             eo.ld_bf16 = D;
-            gemm_linear(ao, D, blk.o1, (int)rows, eo, st);
+            gemm_linear(ao, D, blk.o1, (int)rows, eo, st, sk);
         } else if (l > 0) {
             launch_cast_f32_bf16(x, xb, rows * D, st);
         }
@@ -393,7 +397,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             GemmEpilogue eq;
             eq.out_f32 = qc;
             eq.ld_f32 = D;
-            gemm_linear(xb, D, blk.q2, (int)rows, eq, st);
+            gemm_linear(xb, D, blk.q2, (int)rows, eq, st, sk);
             launch_qknorm_rope(qc, D, blk.qn2, nullptr, nullptr, T, q, D, (int)rows, D, eps, st);
             AttnArgs at;
             at.Q = q; at.ldq = D; at.q_bstride = (long)T * D;
@@ -410,7 +414,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             eo.resid = 1;
             eo.gate = nullptr;
             eo.gate_scalar = blk.cross_scale;
-            gemm_linear(ao, D, blk.o2, (int)rows, eo, st);
+            gemm_linear(ao, D, blk.o2, (int)rows, eo, st, sk);
         }
         if (!blk.skip_ff) {
             launch_norm_mod(x, D, ml + 4 * D, ml + 3 * D, mod_bs, T, xn, D, (int)rows, D, LTX_NORM_RMS, eps, 0, st, rmap);
@@ -418,7 +422,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             e1.out_bf16 = ffh;
             e1.ld_bf16 = 4 * D;
             e1.act = LTX_ACT_GELU_TANH;
-            gemm_linear(xn, D, blk.ff1, (int)rows, e1, st);
+            gemm_linear(xn, D, blk.ff1, (int)rows, e1, st, sk);
             GemmEpilogue e2;
             e2.out_f32 = x;
             e2.ld_f32 = D;
@@ -429,7 +433,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             e2.gate_rowmap = rmap;
             e2.out_bf16 = xb;
             e2.ld_bf16 = D;
-            gemm_linear(ffh, 4 * D, blk.ff2, (int)rows, e2, st);
+            gemm_linear(ffh, 4 * D, blk.ff2, (int)rows, e2, st, sk);
         } else {
             launch_cast_f32_bf16(x, xb, rows * D, st);
         }
@@ -441,6 +445,6 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
         GemmEpilogue e;
         e.out_f32 = a.velocity;
         e.ld_f32 = m->cfg.out_channels;
-        gemm_linear(xn, D, m->proj_out, (int)rows, e, st);
+        gemm_linear(xn, D, m->proj_out, (int)rows, e, st, sk);
     }
 }

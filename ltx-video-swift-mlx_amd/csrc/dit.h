@@ -74,7 +74,7 @@ struct DiTModel {
 
     // ---- activation workspace (grown on demand, never freed inside a step) ----
     DevBuf ws_x, ws_xn, ws_xb, ws_qk, ws_q, ws_k, ws_vt, ws_ao, ws_ffh, ws_qc;
-    DevBuf ws_ts, ws_emb256, ws_h1, ws_embts, ws_ada, ws_mod, ws_modout;
+    DevBuf ws_ts, ws_emb256, ws_h1, ws_embts, ws_ada, ws_mod, ws_modout, ws_splitk;
     int ws_rows = 0, ws_B = 0, ws_Tpad = 0;
 };
 

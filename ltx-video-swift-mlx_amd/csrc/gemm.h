@@ -59,8 +59,9 @@ struct GemmArgs {
     // split-K (ring kernels): grid.y = split_k workgroups share one output tile, each walks 1/split_k of the K-tiles and
     // stores its raw f32 partial tile to split_ws[z][M][N]; splitk_finish then sums the partials in a fixed order and applies
     // the epilogue (deterministic - no float atomics). Used when a launch has too few output tiles to fill the chip.
-    int split_k = 1;
+    int split_k = 1;         // 0 with a workspace: let launch_gemm_bf16 decide (dense GEMMs)
     float* split_ws = nullptr;
+    long split_ws_elems = 0;  // capacity of split_ws in floats (only read when split_k == 0)
     int group_m = 4;  // row-tiles per supertile of the workgroup order (0 = column-major tile order); see tile_coords()
 };
 

@@ -941,8 +941,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_v4(const GemmArgs g) {
     gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem);
 }
 
-// split-K finish: out = epilogue(sum_z ws[z]) for the epilogue subset the VAE convs use (bias, scalar-gated residual,
-// f32 and/or bf16 outputs); partials are summed in ascending z, so the result does not depend on scheduling.
+// split-K finish: out = epilogue(sum_z ws[z]) - every epilogue option except the depth-to-space stores; partials are summed in
+// ascending z, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int S, int M, int N, GemmEpilogue ep) {
     const long n4 = N >> 2;
     const long total = (long)M * n4;
@@ -952,6 +952,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         f32x4 v = *(const f32x4*)(ws + m * N + c);
         for (int z = 1; z < S; ++z) v += *(const f32x4*)(ws + ((long)z * M + m) * N + c);
         if (ep.bias_n) v += *(const f32x4*)(ep.bias_n + c);
+        if (ep.bias_m) {
+            const float bm = ep.bias_m[m];
+            v += f32x4{bm, bm, bm, bm};
+        }
         if (ep.act == LTX_ACT_SILU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
@@ -959,11 +963,17 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
         }
+        if (ep.round_bf16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
+        }
         if (ep.resid) {
             const float* rs = (ep.resid_src ? ep.resid_src + m * ep.ld_resid : ep.out_f32 + m * ep.ld_f32) + c;
             const f32x4 r4 = *(const f32x4*)rs;
+            f32x4 gt = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
+            if (ep.gate) gt = *(const f32x4*)(ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[m] : m / ep.rows_per_batch) * ep.gate_bstride + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = r4[e] + ep.gate_scalar * v[e];
+            for (int e = 0; e < 4; ++e) v[e] = r4[e] + gt[e] * v[e];
         }
         if (ep.out_f32) *(f32x4*)(ep.out_f32 + m * ep.ld_f32 + c) = v;
         if (ep.out_bf16) {
@@ -1001,7 +1011,7 @@ void launch_v2(const GemmArgs& a, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     if (a.split_k > 1) {
         const GemmEpilogue& e = a.ep;
-        LTX_REQUIRE(a.split_ws && a.N % 4 == 0 && !e.d2s && !e.gate && !e.gate_rowmap && !e.bias_m && !e.round_bf16, "gemm split-K: unsupported epilogue");
+        LTX_REQUIRE(a.split_ws && a.N % 4 == 0 && !e.d2s, "gemm split-K: needs a workspace, N %% 4 == 0 and no depth-to-space epilogue");
         LTX_REQUIRE(a.split_k <= a.K / BK, "gemm split-K: %d splits for %d K-tiles", a.split_k, a.K / BK);
     }
     hipLaunchKernelGGL((gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN>), dim3(tiles, a.split_k > 1 ? a.split_k : 1),
@@ -1122,6 +1132,21 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
         // tile-count quantisation does not matter; N <= 128 wants the 192x128 tile, wide N the same (B re-use).
         const char* cc = getenv("LTX_CONV_CFG");  // A/B hook for tile experiments (21 = 192x128 ring, 23 = 256x128 ring)
         launch_gemm_bf16_cfg(a, (cc && a.split_k <= 1) ? atoi(cc) : 21, stream);
+        return;
+    }
+    if (a.split_ws && a.split_k == 0) {
+        // caller-provided workspace, split count left to the launcher: few output tiles and a long reduction (the DiT at
+        // small token counts, e.g. 256x256x9 -> 128 tokens: 32 tiles of weights to stream with 256 CUs) -> split K over the idle CUs
+        GemmArgs b = a;
+        b.split_k = gemm_suggest_split_k(a.M, a.N, a.K);
+        while (b.split_k > 1 && (long)b.split_k * a.M * a.N > a.split_ws_elems) --b.split_k;
+        if (b.split_k > 1 && a.N % 4 == 0 && !a.ep.d2s) {
+            launch_gemm_bf16_cfg(b, 21, stream);
+            return;
+        }
+        b.split_k = 1;
+        b.split_ws = nullptr;
+        launch_gemm_bf16(b, stream);
         return;
     }
     int best = 0;
