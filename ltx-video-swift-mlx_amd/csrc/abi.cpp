@@ -898,7 +898,6 @@ int ltx_op_fill_normal_f32(ltx_ctx* ctx, float* p, long n, uint64_t seed, float 
     return guarded(ctx, [&] { launch_fill_normal_f32(p, n, seed, mean, stddev, 0, ctx->stream); });
 }
 
-}  // extern "C"
 
 
 /* ---- text-embedding connector ---- */
@@ -1111,3 +1110,5 @@ int ltx_frames_to_u8(const float* frames, long n, uint8_t* out) {
 int ltx_write_png(const char* path, const uint8_t* rgb, int width, int height) {
     return write_png_rgb8(path, rgb, width, height) ? LTX_OK : LTX_ERR_FILE_NOT_FOUND;
 }
+
+}  // extern "C"
