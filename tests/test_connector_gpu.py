@@ -132,3 +132,22 @@ def test_connector_feeds_the_dit(ltx, oracle, gpu_ctx, conn):
     vel = gpu_ctx.dit_forward(lat, out_bits, np.array([0.5], np.float32), om, 2, 2, 2)
     assert vel.shape == (1, 8, 128) and np.isfinite(vel).all()
     gpu_ctx.dit_unload()
+
+
+def test_connector_vs_golden_fixture(ltx, oracle, gpu_ctx, tmp_path):
+    """HIP path vs the committed golden vector (tests/golden/connector_tiny.npz: oracle output cross-checked against an
+    independent torch implementation by make_golden.py)."""
+    import os
+    from safetensors.torch import save_file
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "connector_tiny.npz"))
+    dim, heads, layers, regs, states = (int(g[k]) for k in ("dim", "heads", "layers", "registers", "states"))
+    w = oracle.synth_connector_weights(dim=dim, heads=heads, layers=layers, registers=regs, states=states, seed=int(g["seed"]))
+    path = tmp_path / "c.safetensors"
+    save_file({k: torch.from_numpy(np.ascontiguousarray(v)).to(torch.bfloat16) for k, v in oracle.connector_file_keys(w, unified=False).items()},
+              str(path))
+    gpu_ctx.connector_load(path, ltx.connector_config(dim=dim, heads=heads, layers=layers, registers=regs, states=states))
+    out_bits, om = gpu_ctx.connector_encode(bits(g["hidden"], oracle), g["mask"])
+    gpu_ctx.connector_unload()
+    got = oracle.bf16_bits_to_f32(out_bits)
+    assert om.all() and _rel(got, g["context"]) <= 2e-2 and _cos(got, g["context"]) >= 0.9995

@@ -112,3 +112,11 @@ def test_oracle_matches_golden_fixtures(oracle):
     assert np.allclose(vel, g["velocity"], rtol=1e-4, atol=1e-4)
     c = np.load(os.path.join(GOLD, "conv3d_small.npz"))
     assert np.allclose(oracle.conv3d_full(c["x"], c["w"], c["b"]), c["y"], atol=1e-4)
+    k = np.load(os.path.join(GOLD, "connector_tiny.npz"))
+    wk = oracle.synth_connector_weights(dim=int(k["dim"]), heads=int(k["heads"]), layers=int(k["layers"]), registers=int(k["registers"]),
+                                        states=int(k["states"]), seed=int(k["seed"]))
+    ctxv, om = oracle.connector_encode(wk, k["hidden"], k["mask"], heads=int(k["heads"]), layers=int(k["layers"]))
+    assert np.allclose(ctxv, k["context"], atol=1e-6) and om.all()
+    e = np.load(os.path.join(GOLD, "vae_encoder_tiny.npz"))
+    we = oracle.synth_vae_encoder_weights(base=int(e["base"]), seed=int(e["seed"]))
+    assert np.allclose(oracle.vae_encode(we, e["pixels"], base=int(e["base"])), e["latent"], rtol=1e-4, atol=1e-5)

@@ -95,3 +95,20 @@ def test_encoder_index_logic_exact(ltx, oracle, gpu_ctx):
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() <= 2.0 ** -7 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
     assert _rel(got, ref) <= 4e-3
+
+
+def test_vae_encode_vs_golden_fixture(ltx, oracle, gpu_ctx, tmp_path):
+    """HIP path vs tests/golden/vae_encoder_tiny.npz (oracle output cross-checked against an independent torch implementation)."""
+    import os
+    from safetensors.torch import save_file
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vae_encoder_tiny.npz"))
+    base = int(g["base"])
+    w = oracle.synth_vae_encoder_weights(base=base, seed=int(g["seed"]))
+    path = tmp_path / "e.safetensors"
+    save_file({k: torch.from_numpy(np.ascontiguousarray(v)).to(torch.bfloat16 if v.ndim == 5 else torch.float32)
+               for k, v in oracle.vae_encoder_file_keys(w).items()}, str(path))
+    gpu_ctx.vae_encoder_load(path, base)
+    got = gpu_ctx.vae_encode(g["pixels"])
+    gpu_ctx.vae_encoder_unload()
+    assert got.shape == g["latent"].shape and _rel(got, g["latent"]) <= 3e-2
