@@ -35,7 +35,7 @@ struct Args {
     bool twoStage = false, distilledLora = false, enhancePrompt = false, audio = false, debug = false, profile = false,
          dryRun = false;
     // additions of this build
-    std::string embeddings, vaeWeights, upscalerWeights, distilledLoraPath, pngDir;
+    std::string embeddings, vaeWeights, upscalerWeights, distilledLoraPath, pngDir, hiddenStates, connectorWeights, imageTensor;
     int vaeTile = 0, vaeOverlap = 1;
     int numLayers = 0, numHeads = 0, captionChannels = 0;  // reduced architectures for tests (0 = reference default)
 };
@@ -99,6 +99,9 @@ Args parse_generate(int argc, char** argv, int start) {
         else if (k == "--distilled-lora-path") a.distilledLoraPath = need(i);
         else if (k == "--vae-tile") a.vaeTile = std::stoi(need(i));
         else if (k == "--png-dir") a.pngDir = need(i);
+        else if (k == "--gemma-hidden-states") a.hiddenStates = need(i);
+        else if (k == "--connector-weights") a.connectorWeights = need(i);
+        else if (k == "--image-tensor") a.imageTensor = need(i);
         else if (k == "--vae-overlap") a.vaeOverlap = std::stoi(need(i));
         else if (k == "--num-layers") a.numLayers = std::stoi(need(i));
         else if (k == "--num-heads") a.numHeads = std::stoi(need(i));
@@ -178,9 +181,10 @@ int run_generate(const Args& a) {
         return 0;
     }
     if (!a.image.empty() || a.audio || a.enhancePrompt)
-        throw ValidationError("--image / --audio / --enhance-prompt are outside the MI355X hot path of this build");
-    if (a.ltxWeights.empty() || a.vaeWeights.empty() || a.embeddings.empty())
-        throw ValidationError("this build needs --ltx-weights, --vae-weights and --embeddings (no downloads, no Gemma)");
+        throw ValidationError("--image (file decoding) / --audio / --enhance-prompt are outside the MI355X hot path of this build; "
+                              "pass the image as a float tensor with --image-tensor");
+    if (a.ltxWeights.empty() || a.vaeWeights.empty() || (a.embeddings.empty() && a.hiddenStates.empty()))
+        throw ValidationError("this build needs --ltx-weights, --vae-weights and --embeddings or --gemma-hidden-states (no downloads, no Gemma)");
 
     std::cout << "Creating pipeline...\n";
     MemoryOptimizationConfig mem = MemoryOptimizationConfig::defaultConfig();
@@ -211,7 +215,42 @@ int run_generate(const Args& a) {
     cfg.seed = a.seed;
     cfg.guidanceRescale = a.guidanceRescale; cfg.crossAttentionScale = a.crossAttnScale; cfg.geGamma = a.geGamma;
     cfg.stgScale = a.stgScale; cfg.stgBlocks = stg; cfg.twoStage = a.twoStage;
-    const PrecomputedEmbeddings emb = read_embeddings(a.embeddings);
+    PrecomputedEmbeddings emb;
+    if (!a.hiddenStates.empty()) {
+        // text encoding, connector part (LTXPipeline.swift:640-700): the 49 Gemma hidden states come from a file
+        std::cout << "Encoding prompt from Gemma hidden states...\n";
+        pipeline.loadConnector(a.connectorWeights.empty() ? a.ltxWeights : a.connectorWeights);
+        long shp[8] = {0};
+        const int nd = ltx_st_info(a.hiddenStates.c_str(), "hidden_states", shp);
+        if (nd != 4) throw LTXError(LTXError::textEncodingFailed, "hidden_states must be [states][1][T][dim] in " + a.hiddenStates);
+        const int T = int(shp[2]);
+        std::vector<uint16_t> hs(size_t(shp[0]) * shp[1] * shp[2] * shp[3]);
+        ltx_st_read(a.hiddenStates.c_str(), "hidden_states", 1, hs.data(), long(hs.size()));
+        std::vector<int32_t> am(T, 1);
+        if (ltx_st_info(a.hiddenStates.c_str(), "attention_mask", shp) > 0) ltx_st_read(a.hiddenStates.c_str(), "attention_mask", 2, am.data(), T);
+        emb = pipeline.encodeFromHiddenStates(hs, am, T);
+    } else {
+        emb = read_embeddings(a.embeddings);
+    }
+    std::optional<ImageConditioning> image;
+    if (!a.imageTensor.empty()) {
+        // image-to-video: the resized image as a float tensor "pixels" [1][3][1][H][W] in [-1,1] -> VAE encoder -> frame-0 latent
+        std::cout << "Encoding conditioning image...\n";
+        long shp[8] = {0};
+        if (ltx_st_info(a.imageTensor.c_str(), "pixels", shp) != 5 || shp[3] != a.height || shp[4] != a.width)
+            throw LTXError(LTXError::invalidConfiguration, "pixels must be [1][3][1][height][width] in " + a.imageTensor);
+        std::vector<float> px(size_t(3) * a.height * a.width);
+        ltx_st_read(a.imageTensor.c_str(), "pixels", 0, px.data(), long(px.size()));
+        pipeline.loadVAEEncoder(a.vaeWeights);
+        image = pipeline.encodeImage(px, a.width, a.height);
+        pipeline.unloadVAEEncoder();
+        cfg.imageCondNoiseScale = a.imageCondNoise;
+        if (a.imageCondNoise > 0) {  // one N(0,1) draw of the image latent's shape per step (LTXPipeline.swift:2226)
+            int Fl, Hl, Wl;
+            ltx_latent_shape(a.width, a.height, a.frames, &Fl, &Hl, &Wl);
+            image->injectionNoise = generateNoise(size_t(cfg.numSteps) * 128 * Hl * Wl, a.seed.value_or(0) ^ 0x9e3779b9u);
+        }
+    }
     std::cout << "\nGenerating video...\n";
     auto progress = [](const GenerationProgress& p) {
         std::cout << "  Step " << p.currentStep + 1 << "/" << p.totalSteps << " (sigma=" << p.sigma << ")\n";
@@ -227,7 +266,7 @@ int run_generate(const Args& a) {
         r = pipeline.generateVideoTwoStage(cfg, emb, generateNoise(size_t(128) * F1 * H1 * W1, sd),
                                            generateNoise(size_t(128) * F2 * H2 * W2, sd + 0x5bd1e995u), progress);
     } else {
-        r = pipeline.generateVideo(cfg, emb, {}, progress, a.profile);
+        r = pipeline.generateVideo(cfg, emb, {}, progress, a.profile, {}, image ? &*image : nullptr);
     }
     std::cout << "Generated " << r.numFrames << " frames (" << r.width << "x" << r.height << ") in " << r.generationTime << "s\n";
     std::ofstream f(a.output, std::ios::binary);

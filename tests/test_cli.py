@@ -84,3 +84,26 @@ def test_cli_generate_end_to_end(ltx, oracle, tmp_path):
     px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(64, 64 * 3 + 1)[:, 1:].reshape(64, 64, 3)
     assert np.array_equal(px, (frames[3] * np.float32(255)).astype(np.uint8))
     assert (tmp_path / "frame_0008.png").exists() and not (tmp_path / "frame_0009.png").exists()
+
+
+@pytest.mark.gpu
+def test_cli_connector_and_image_inputs_are_validated(ltx, oracle, tmp_path):
+    """--gemma-hidden-states / --image-tensor (text-embedding connector and image-to-video inputs of this build): shape contracts
+    are checked before any model work; the full-size models behind them are covered by test_connector_gpu / test_vae_encoder_gpu."""
+    from safetensors.numpy import save_file
+
+    from test_dit_gpu import write_dit_file
+
+    ocfg = oracle.DiTConfig(num_layers=1, num_heads=2, caption_channels=128)
+    write_dit_file(oracle, oracle.synth_dit_weights(ocfg, seed=1), tmp_path / "dit.safetensors")
+    save_file({"latents_mean": np.zeros(128, np.float32), "latents_std": np.ones(128, np.float32)}, str(tmp_path / "vae.safetensors"))
+    save_file({"prompt_embeddings": np.zeros((1, 8, 128), np.float32)}, str(tmp_path / "emb.safetensors"))
+    save_file({"pixels": np.zeros((1, 3, 1, 32, 32), np.float32)}, str(tmp_path / "img.safetensors"))
+    base = ["generate", "x", "-w", "64", "-h", "64", "-f", "9", "-o", str(tmp_path / "o.raw"), "--ltx-weights", str(tmp_path / "dit.safetensors"),
+            "--vae-weights", str(tmp_path / "vae.safetensors"), "--num-layers", "1", "--num-heads", "2", "--caption-channels", "128"]
+    rc, _, err = run(*base, "--embeddings", str(tmp_path / "emb.safetensors"), "--image-tensor", str(tmp_path / "img.safetensors"))
+    assert rc != 0 and "pixels must be [1][3][1][height][width]" in err
+    rc, _, err = run(*base)  # neither embeddings nor hidden states
+    assert rc != 0 and "--embeddings or --gemma-hidden-states" in err
+    rc, _, err = run(*base, "--embeddings", str(tmp_path / "emb.safetensors"), "--image", "cat.png")
+    assert rc != 0 and "--image-tensor" in err
