@@ -14,6 +14,10 @@
 // touches LDS. The key order inside S^T's MFMA rows is permuted (bits 2<->3) when the K fragment is addressed, so
 // that the 8 accumulator registers of one k-step are 8 CONSECUTIVE keys - exactly the B-operand layout the PV
 // product needs (guide: "An accumulator tile as the next MFMA's operand").
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "attention.h"
 #include "runtime.h"
 
@@ -23,6 +27,76 @@ constexpr int KV_TILE = 64;
 constexpr int K_TILE_BYTES = KV_TILE * 256;  // [64 keys][128 d] bf16
 constexpr int V_TILE_BYTES = 128 * 128;      // [128 d][64 keys] bf16
 constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One online-softmax update for this lane's query column over a 64-key tile: scores s (register e of s[kb] is key
+// k0 + kb*32 + 16*(e>>3) + 8*h + (e&7)) -> P as the PV product's bf16 B operand, running max / sum, O rescale.
+//
+// Written for VALU instruction COUNT: on gfx950 an MFMA wave and a VALU wave on the same SIMD overlap only for transcendentals;
+// every plain VALU instruction costs ~3/4 of its 4 issue cycles even under another wave's MFMAs (tools/ubench/overlap.hip:
+// 32 MFMA = 512 ns alone, +141 ns with 96 FMAs from the other wave, +4 ns with 32 exp2). So: packed-f32 FMA / add for the
+// exponent argument and the row sum (2 values per instruction), and the 64-register O rescale is skipped whenever no lane's
+// maximum moved (alpha == 1 exactly) - the common case after the first few tiles.
+template <bool HAS_BIAS>
+LTX_DEVFN void softmax_tile(f32x16 (&s)[2], f32x16 (&o)[4], s16x8 (&pf)[4], float& m_run, float& l_run, float c, float scale,
+                            const float* biasb, int k0, int Tk, int h) {
+    if (HAS_BIAS) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int key = k0 + kb * 32 + 16 * (e >> 3) + 8 * h + (e & 7);
+                key = key < Tk ? key : Tk - 1;
+                s[kb][e] = s[kb][e] * scale + biasb[key];
+            }
+    }
+    if (k0 + KV_TILE > Tk) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = k0 + kb * 32 + 16 * (e >> 3) + 8 * h + (e & 7);
+                if (key >= Tk) s[kb][e] = -INFINITY;
+            }
+    }
+    float mloc = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, s[kb][e]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_safe) * c);
+    m_run = m_new;
+    const f32x2 c2 = {c, c};
+    const f32x2 nmc2 = {-m_safe * c, -m_safe * c};
+    f32x2 psum2 = {0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            s16x8 pk;
+#pragma unroll
+            for (int jj = 0; jj < 8; jj += 2) {
+                const f32x2 sv = {s[kb][s2 * 8 + jj], s[kb][s2 * 8 + jj + 1]};
+                const f32x2 t = __builtin_elementwise_fma(sv, c2, nmc2);
+                const f32x2 pv = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                psum2 += pv;
+                pk[jj] = (short)f32_to_bf16(pv.x);
+                pk[jj + 1] = (short)f32_to_bf16(pv.y);
+            }
+            pf[kb * 2 + s2] = pk;
+        }
+    l_run = l_run * alpha + (psum2.x + psum2.y);
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    }
+}
 
 template <bool HAS_BIAS>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
@@ -123,59 +197,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
                                                                 __builtin_bit_cast(bf16x8_t, qf[ks]), s[kb], 0, 0, 0);
             }
         }
-        // register e of s[kb] is key k0 + kb*32 + 16*(e>>3) + 8*h + (e&7) for query column r
-        if (HAS_BIAS) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    int key = k0 + kb * 32 + 16 * (e >> 3) + 8 * h + (e & 7);
-                    key = key < a.Tk ? key : a.Tk - 1;
-                    s[kb][e] = s[kb][e] * a.scale + biasb[key];
-                }
-        }
-        if (k0 + KV_TILE > a.Tk) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = k0 + kb * 32 + 16 * (e >> 3) + 8 * h + (e & 7);
-                    if (key >= a.Tk) s[kb][e] = -INFINITY;
-                }
-        }
-        float mloc = s[0][0];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, s[kb][e]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_safe) * c);
-        m_run = m_new;
-        const float mc = m_safe * c;
-        float psum = 0.f;
         s16x8 pf[4];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                float p[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    p[j] = __builtin_amdgcn_exp2f(s[kb][s2 * 8 + j] * c - mc);
-                    psum += p[j];
-                }
-                s16x8 pk;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pk[j] = (short)f32_to_bf16(p[j]);
-                pf[kb * 2 + s2] = pk;
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+        softmax_tile<HAS_BIAS>(s, o, pf, m_run, l_run, c, a.scale, biasb, k0, a.Tk, h);
 
         // O^T += Vt * P^T : four 32-row d-blocks, 4 k-steps of 16 keys
 #pragma unroll
@@ -207,6 +230,257 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong variant: 8 waves x 32 queries per workgroup, one workgroup per CU, TWO waves per SIMD that alternate roles.
+//
+// Why: with two independent waves per SIMD the kernel above takes the SUM of its MFMA time (32 x 32 cycles per 64-key tile) and
+// its softmax VALU time (~200 instructions, ~1200 cycles) per wave: measured 2.3 us per tile step with two workgroups on a CU
+// against 1.5 us with one - the two waves of a SIMD drift into the same phase (both in the MFMA block, then both in the softmax)
+// and the matrix pipe idles while both do VALU work. Here the two wave groups (waves 0-3 / 4-7, one of each per SIMD) are held
+// exactly one phase apart by the workgroup barrier: every wave runs  [softmax cluster] barrier [MFMA cluster] barrier ...,
+// group 1 enters the loop one barrier late, so while group 0 is in its MFMA cluster group 1 is in its softmax cluster and
+// vice versa. For that a wave's MFMA cluster must not depend on its own softmax of the same tile, so the loop is skewed:
+//     softmax cluster j : P(j) = softmax(S(j)), rescale O;       also issues the LDS-DMA of stage j+2
+//     MFMA cluster j    : S(j+1) = K(j+1) Q^T   and   O += Vt(j) P(j)^T
+// "stage s" = {K tile s+1, Vt tile s}: what MFMA cluster s reads. A stage is issued two steps ahead, waited for (counted vmcnt)
+// one step ahead, and read by group 0 / group 1 in consecutive barrier intervals; with 4 ring slots per operand (128 KB LDS) a
+// slot is rewritten two intervals after its last reader.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PP_Q = 256;
+constexpr int PP_SLOTS = 4;
+constexpr int PP_RA = 4;  // fragment reads in flight ahead of their MFMA (8 measured the same)
+constexpr int PP_LDS = PP_SLOTS * (K_TILE_BYTES + V_TILE_BYTES);
+
+// Phase boundaries. The barriers are inline asm that takes the phase's RESULTS as read-write operands: a plain "memory" clobber
+// orders memory operations only, and the compiler otherwise sinks most of the softmax below the barrier (seen in the ISA), which
+// puts both wave groups' VALU work into the same interval.
+#define PP_END_SOFTMAX(VM)                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(" #VM ")\n\ts_barrier"                                                                     \
+                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]),     \
+                   "+v"(l_run), "+v"(m_run)::"memory")
+#define PP_END_MFMA()                                                                                                       \
+    asm volatile("s_barrier" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(s[0]), "+v"(s[1])::"memory")
+LTX_DEVFN void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+#ifdef PP_STAMPS  // tools/ubench/attn_stamps.hip: cycle stamps at the phase boundaries of one steady-state tile step
+__device__ unsigned long long g_pp_stamps[8][8];
+#define PP_STAMP(i) \
+    if (j == 9) st_[i] = __builtin_readcyclecounter()  // kept in SGPRs until the kernel's end: a store here would join vmcnt
+#else
+#define PP_STAMP(i)
+#endif
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(512, 1) void attn_fwd_kernel_pp(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wave >> 2;
+    const int head = blockIdx.y;
+    const int b = blockIdx.z;
+    const int r = lane & 31, h = lane >> 5;
+
+    const bf16_t* Qb = a.Q + (long)b * a.q_bstride + head * 128;
+    const bf16_t* Kb = a.K + (long)b * a.k_bstride + head * 128;
+    const bf16_t* Vb = a.Vt + (long)b * a.vt_bstride + (long)head * 128 * a.ldvt;
+    const float* biasb = HAS_BIAS ? a.bias + (long)b * a.bias_bstride : nullptr;
+
+    const int qi = blockIdx.x * PP_Q + wave * 32 + r;
+    const int qrow = qi < a.Tq ? qi : a.Tq - 1;
+    s16x8 qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const s16x8*)(Qb + (long)qrow * a.ldq + ks * 16 + h * 8);
+
+    const int nt = (a.Tk + KV_TILE - 1) / KV_TILE;
+    char* const kring = smem;
+    char* const vring = smem + PP_SLOTS * K_TILE_BYTES;
+
+    // staging: a tile is 16 wave-instructions of 1 KB; wave w issues chunks w and w+8 of each operand (same swizzles as above).
+    // Buffer loads: an SGPR descriptor per operand, a 32-bit per-lane byte offset (4 loop-invariant VGPRs in all) and the tile
+    // advance as the scalar offset - no 64-bit address arithmetic in the loop. The K descriptor ends after key Tk-1, so the keys
+    // of a ragged last tile that lie beyond it read as zeros (their scores are masked to -inf below).
+    const int k_key = lane >> 4, k_pch = lane & 15;
+    const int v_row = lane >> 3, v_pch = lane & 7;
+    const __amdgpu_buffer_rsrc_t k_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((long)(a.Tk - 1) * a.ldk + 128) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)((long)128 * a.ldvt * 2), 0x00020000);
+    int koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kl = (wave + 8 * i) * 4 + k_key;
+        koff[i] = (kl * a.ldk + ((k_pch ^ (kl & 15)) << 3)) * 2;
+        const int d = (wave + 8 * i) * 8 + v_row;
+        voff[i] = (d * a.ldvt + ((v_pch ^ ((d >> 1) & 7)) << 3)) * 2;
+    }
+    auto stage_k = [&](int t) {  // K tile t (a tile index past the end reads zeros into a free slot; nobody reads them)
+        char* kbuf = kring + (t & (PP_SLOTS - 1)) * K_TILE_BYTES;
+        const int soff = t * KV_TILE * a.ldk * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(kbuf + (wave + 8 * i) * 1024), 16, koff[i], soff, 0, 0);
+    };
+    auto stage_v = [&](int t) {
+        char* vbuf = vring + (t & (PP_SLOTS - 1)) * V_TILE_BYTES;
+        const int soff = t * KV_TILE * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(vbuf + (wave + 8 * i) * 1024), 16, voff[i], soff, 0, 0);
+    };
+
+    const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+    const int k_frag_row = pr * 256;
+    const int k_sw = pr & 15;
+    const int v_frag_row = r * 128;
+    const int v_sw = (r >> 1) & 7;
+
+    f32x16 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float LOG2E = 1.4426950408889634f;
+    const float c = HAS_BIAS ? LOG2E : a.scale * LOG2E;
+
+#ifdef PP_STAMPS
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    f32x16 s[2];
+    s16x8 pf[4];
+    // One MFMA cluster: S(t_k) = K(t_k) Q^T (if QK) and O += Vt(t_v) P^T, as ONE scheduling region in which every LDS fragment
+    // read is issued RA MFMAs ahead of its consumer (read latency ~100+ cycles against 32 cycles per MFMA; without this the
+    // compiler pairs read->wait->MFMA and the cluster runs at LDS latency, 2.4x its MFMA time). Accumulators are interleaved
+    // (2 key blocks / 4 d-blocks round-robin) so consecutive MFMAs are independent.
+    // Fragment addresses. The XOR swizzle only permutes the 32-byte k-step groups of a row, so a fragment address is
+    //   base + ((kstep << 5) ^ x5)   with two loop-invariant VGPRs per operand (one v_xad_u32 per read, issued between MFMAs),
+    // and ring slots are compile-time (the tile loop is unrolled by PP_SLOTS) so slot and block offsets are instruction immediates.
+    const int kf_base = k_frag_row + ((h ^ (k_sw & 1)) << 4);
+    int kf_x5 = (k_sw >> 1) << 5;
+    const int vf_base = PP_SLOTS * K_TILE_BYTES + v_frag_row + ((h ^ (v_sw & 1)) << 4);
+    int vf_x5 = (v_sw >> 1) << 5;
+    auto mfma_cluster = [&](auto kslot_tag, auto vslot_tag, auto qk_tag, auto pv_tag) {
+        constexpr bool QK = decltype(qk_tag)::value, PV = decltype(pv_tag)::value;
+        constexpr int KS = decltype(kslot_tag)::value & (PP_SLOTS - 1), VS = decltype(vslot_tag)::value & (PP_SLOTS - 1);
+        constexpr int RA = PP_RA;
+        constexpr int NM = (QK ? 16 : 0) + (PV ? 16 : 0);
+        if constexpr (QK) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+        }
+        // keep the 12 fragment addresses from being hoisted out of the tile loop as 12 live VGPRs (the kernel sits at the 256-VGPR
+        // limit of two waves per SIMD): the compiler must treat the XOR terms as changed here
+        asm volatile("" : "+v"(kf_x5), "+v"(vf_x5));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (QK) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const s16x8 kf = *(const s16x8*)(smem + (((ks << 5) ^ kf_x5) + kf_base) + (KS * K_TILE_BYTES + kb * 32 * 256));
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]), s[kb], 0, 0, 0);
+                }
+        }
+        if constexpr (PV) {
+#pragma unroll
+            for (int kst = 0; kst < 4; ++kst)
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    const s16x8 vf = *(const s16x8*)(smem + (((kst << 5) ^ vf_x5) + vf_base) + (VS * V_TILE_BYTES + db * 32 * 128));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[kst]), o[db], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);
+#pragma unroll
+        for (int i = 0; i < NM - RA; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, RA, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using I0_ = std::integral_constant<int, 0>;
+
+    // ---- prologue: stages -1 (K0), 0 (K1, V0), 1 (K2, V1); S(0) ----
+    stage_k(0);
+    stage_k(1);
+    stage_v(0);
+    stage_k(2);
+    stage_v(1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    mfma_cluster(I0_{}, I0_{}, T_{}, F_{});
+    asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+    if (group == 1) pp_barrier();  // group 1 runs one barrier interval behind group 0 from here on
+
+    auto step = [&](int j, auto slot_tag) {
+        constexpr int SL = decltype(slot_tag)::value;  // == j & 3
+        // ================= softmax cluster j =================
+        PP_STAMP(0);
+        // stage j+2, unconditionally: a tile past the end lands in a free slot (K reads zeros past its descriptor, Vt whatever
+        // follows within its own) and is never read; that keeps the loop branch-free and the vmcnt count below constant
+        stage_k(j + 3);
+        stage_v(j + 2);
+        PP_STAMP(1);
+        const int k0 = j * KV_TILE;
+        softmax_tile<HAS_BIAS>(s, o, pf, m_run, l_run, c, a.scale, biasb, k0, a.Tk, h);
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(2);
+        // stage j+1 (issued one step ago) must have landed before anyone's MFMA cluster j+1; the 4 loads just issued may fly
+        PP_END_SOFTMAX(4);
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(3);
+
+        // ================= MFMA cluster j =================
+        __builtin_amdgcn_s_setprio(1);
+        if (j + 1 < nt)
+            mfma_cluster(std::integral_constant<int, SL + 1>{}, slot_tag, T_{}, T_{});
+        else
+            mfma_cluster(slot_tag, slot_tag, F_{}, T_{});
+        __builtin_amdgcn_s_setprio(0);
+        PP_STAMP(4);
+        PP_END_MFMA();
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(5);
+    };
+    for (int j = 0; j < nt; j += 4) {
+        step(j, std::integral_constant<int, 0>{});
+        if (j + 1 < nt) step(j + 1, std::integral_constant<int, 1>{});
+        if (j + 2 < nt) step(j + 2, std::integral_constant<int, 2>{});
+        if (j + 3 < nt) step(j + 3, std::integral_constant<int, 3>{});
+    }
+    if (group == 0) pp_barrier();  // pairs with group 1's last loop barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two stages issued past the end must not outlive the workgroup's LDS
+#ifdef PP_STAMPS
+    if (blockIdx.x == 1 && blockIdx.y == 3 && lane == 0) {
+        for (int i = 0; i < 6; ++i) g_pp_stamps[wave][i] = st_[i];
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_pp_stamps[wave][6] = hwid;
+    }
+#endif
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qi < a.Tq) {
+        bf16_t* orow = a.O + (long)b * a.o_bstride + (long)qi * a.ldo + head * 128;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 pk;
+                pk.x = pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv);
+                pk.y = pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv);
+                *(uint2*)(orow + db * 32 + g4 * 8 + h * 4) = pk;
+            }
+    }
+}
+
 }  // namespace
 
 void launch_attention(const AttnArgs& a, hipStream_t stream) {
@@ -222,10 +496,42 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
         attr_set = true;
     }
     ProfScope prof(PROF_ATTN, 4.0 * a.B * a.H * (double)a.Tq * a.Tk * 128, stream);
+    // Kernel choice by grid fill (tile-step costs measured on MI355X at T=6144: 2.3 us with two 128-query workgroups on a CU,
+    // 1.5 us with one, 2.18 us for one 256-query ping-pong workgroup): the launch lasts as long as its fullest CU.
+    //   T=1536, B=1: 384 workgroups = 128 CUs with two + 128 with one (2.3)  vs 192 ping-pong workgroups (2.18)  -> ping-pong
+    //   T=1536, B=2: 768 = one full round + one single round (2.3 + 1.5)     vs 384 = two rounds (4.36)           -> 4-wave
+    //   T=6144:      1536 = three full rounds (6.9)                          vs 768 = three rounds (6.54)         -> ping-pong
+    // The masked variant stays on the 4-wave kernel (its per-key bias loads sit in the softmax phase, measured slower).
+    // LTX_ATTN_IMPL=1 / 2 force the 4-wave / ping-pong kernel (same-process A/B runs).
+    {
+        const long wg4 = (long)((a.Tq + 127) / 128) * a.H * a.B;
+        const long rem4 = wg4 % 512;
+        const double cost4 = (double)(wg4 / 512) * 2.3 + (rem4 == 0 ? 0.0 : (rem4 <= 256 ? 1.5 : 2.3));
+        const long wgpp = (long)((a.Tq + PP_Q - 1) / PP_Q) * a.H * a.B;
+        const double costpp = (double)((wgpp + 255) / 256) * 2.18;
+        const char* impl = getenv("LTX_ATTN_IMPL");
+        const bool use_pp = (impl && impl[0] == '2') ? true : ((impl && impl[0] == '1') ? false : (!a.bias && costpp < cost4));
+        if (use_pp) {
+            static bool attr2_set = false;
+            if (!attr2_set) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_pp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_pp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
+                attr2_set = true;
+            }
+            dim3 grid_pp((a.Tq + PP_Q - 1) / PP_Q, a.H, a.B);
+            if (a.bias)
+                hipLaunchKernelGGL((attn_fwd_kernel_pp<true>), grid_pp, dim3(512), PP_LDS, stream, a);
+            else
+                hipLaunchKernelGGL((attn_fwd_kernel_pp<false>), grid_pp, dim3(512), PP_LDS, stream, a);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
     dim3 grid((a.Tq + 127) / 128, a.H, a.B);
+    const int lds = 2 * STAGE_BYTES;
     if (a.bias)
-        hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, dim3(256), lds, stream, a);
     HIP_CHECK(hipGetLastError());
 }

@@ -37,7 +37,7 @@ def main():
         fl = 4.0 * B * H * T * S * 128
         n = 3 if args.once else 20
         line = f"{name:24s}"
-        impls = ["0"]  # add "1", "2", ... here when the launcher understands LTX_ATTN_IMPL variants (A/B in one process)
+        impls = ["1", "2", "0"]  # 1 = 4-wave kernel, 2 = ping-pong kernel, 0 = the launcher's choice
         best = {i: [] for i in impls}
         for r in range(1 if args.once else args.rounds + 1):
             for impl in impls:  # interleaved rounds in one process (A/B)

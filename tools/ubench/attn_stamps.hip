@@ -1,0 +1,38 @@
+// attn_stamps.hip - cycle stamps at the phase boundaries of the ping-pong attention kernel (one steady-state tile step of one
+// workgroup, wave 0 = group 0 and wave 4 = group 1, both on SIMD 0). Build from the repo root:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DPP_STAMPS -Iinclude -Iltx-video-swift-mlx_amd/csrc -o tools/ubench/attn_stamps tools/ubench/attn_stamps.hip
+#include "../../ltx-video-swift-mlx_amd/csrc/attention.hip"
+
+// the kernel launcher's profiling hooks (runtime.cpp) are not linked into this harness
+Profiler* prof_current() { return nullptr; }
+ProfRec* Profiler::begin(int, double, hipStream_t) { return nullptr; }
+void Profiler::end(ProfRec*, hipStream_t) {}
+
+#include <stdio.h>
+#include <vector>
+
+int main() {
+    const int T = 6144, H = 32, D = 4096;
+    std::vector<bf16_t> h((size_t)T * D);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = host_f32_to_bf16((float)((i * 2654435761u >> 20) & 255) / 256.f - 0.5f);
+    bf16_t *q, *k, *vt, *o;
+    hipMalloc(&q, h.size() * 2); hipMalloc(&k, h.size() * 2); hipMalloc(&vt, h.size() * 2); hipMalloc(&o, h.size() * 2);
+    hipMemcpy(q, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(k, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(vt, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    AttnArgs a;
+    a.Q = q; a.ldq = D; a.K = k; a.ldk = D; a.Vt = vt; a.ldvt = T; a.O = o; a.ldo = D;
+    a.B = 1; a.H = H; a.Tq = T; a.Tk = T;
+    for (int it = 0; it < 3; ++it) launch_attention(a, 0);
+    hipDeviceSynchronize();
+    unsigned long long st[8][8];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pp_stamps), sizeof(st));
+    unsigned long long t0 = st[0][0];
+    printf("wave simd | t(start) stage softmax waitA  mfma  waitB | step   (cycles; t relative to wave 0)\n");
+    for (int w = 0; w < 8; ++w) {
+        const unsigned hw = (unsigned)st[w][6];
+        printf("  %d   %d   | %7lld %5llu %7llu %5llu %5llu %6llu | %5llu\n", w, (hw >> 4) & 3, (long long)(st[w][0] - t0), st[w][1] - st[w][0],
+               st[w][2] - st[w][1], st[w][3] - st[w][2], st[w][4] - st[w][3], st[w][5] - st[w][4], st[w][5] - st[w][0]);
+    }
+    return 0;
+}
