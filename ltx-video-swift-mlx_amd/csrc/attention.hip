@@ -481,6 +481,15 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_kernel_pp(const AttnArgs a) {
     }
 }
 
+
+// (Tried and removed: a one-wave-per-SIMD kernel, 48 queries per wave as three 16-query blocks of v_mfma_f32_16x16x32_bf16, 192
+// queries per workgroup = exactly 256 workgroups at 1536 tokens x 32 heads, softmax of tile t interleaved with the QK^T MFMAs
+// of tile t+1 in ONE instruction stream - tools/ubench/overlap.hip shows that in-wave interleaving hides the VALU work
+// completely (503 ns against 495 ns for the MFMAs alone) where a second wave does not. Written in HIP C++ it does not survive
+// the compiler: O (96 registers) + double-buffered S (96) + Q (48) + P (24) need the AGPR half of the register file, and the
+// allocator moves 250-300 registers between the two halves per tile step (v_accvgpr_read/write), ignores or over-serialises the
+// sched_group_barrier interleave (softmax ends up after the MFMAs) and spills 1.1-1.5 KB to scratch. The shape is right for
+// this problem size; it needs an assembly-level main loop with hand-assigned registers.)
 }  // namespace
 
 void launch_attention(const AttnArgs& a, hipStream_t stream) {
