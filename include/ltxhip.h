@@ -219,6 +219,14 @@ int ltx_dit_forward_tokens(ltx_ctx* ctx, const uint16_t* latent, const uint16_t*
 /* ------------------------------------------------------------------------------------------------------------
  * Frame export helpers (the part that is verifiable here; VideoExporter.swift:563-580). Pure host code.
  * ---------------------------------------------------------------------------------------------------------- */
+/* MLX-compatible initial noise (replaces generateNoise, LatentUtils.swift:69-83 = MLXRandom.seed(seed) then
+ * MLXRandom.normal(shape, float32)): writes the `draw_index`-th keyless normal draw after seeding (0 = the first) as n f32
+ * values. mlx-swift is not part of the reference tree: the generator is restated from MLX's published algorithm (threefry2x32-20
+ * counter hash, key split per draw, uniform -> sqrt(2)*erfinv). The hash is pinned by the Random123 known-answer vectors
+ * (ltx_threefry2x32); the bits -> normal pipeline could not be checked against an MLX run. Pure host code. */
+int ltx_mlx_random_normal(uint64_t seed, int draw_index, float* out, long n);
+void ltx_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]);
+
 /* tensorToImages' pixel conversion: out = uint8(clip(x, 0, 1) * 255), f32 multiply then truncation toward zero. */
 int ltx_frames_to_u8(const float* frames, long n, uint8_t* out);
 /* Writes one (H, W, 3) uint8 frame as a PNG (8-bit RGB, stored/uncompressed deflate blocks - no external codec). The

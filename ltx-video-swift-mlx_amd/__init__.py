@@ -106,6 +106,21 @@ def map_lora_key(key):
     return _map_key(lib.ltx_map_lora_key, key)
 
 
+def mlx_random_normal(seed, shape, draw_index=0):
+    """MLXRandom.seed(seed); MLXRandom.normal(shape) - the reference's generateNoise (LatentUtils.swift:69-83), restated."""
+    out = np.empty(shape, np.float32)
+    _check(lib.ltx_mlx_random_normal(int(seed), int(draw_index), out.ctypes.data, out.size))
+    return out
+
+
+def threefry2x32(key, ctr):
+    k = np.asarray(key, np.uint32)
+    c = np.asarray(ctr, np.uint32)
+    o = np.empty(2, np.uint32)
+    lib.ltx_threefry2x32(k.ctypes.data, c.ctypes.data, o.ctypes.data)
+    return o
+
+
 def frames_to_u8(frames):
     """``VideoExporter.tensorToImages`` pixel conversion: uint8(clip(x,0,1)*255), truncating."""
     f = np.ascontiguousarray(frames, dtype=np.float32)

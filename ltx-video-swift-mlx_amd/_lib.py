@@ -124,6 +124,8 @@ SIGNATURES = {
     "ltx_vae_encoder_latent_frames": (_i, [_i]),
     "ltx_map_vae_encoder_key": (_i, [C.c_char_p, C.c_char_p, _i]),
     "ltx_frames_to_u8": (_i, [_vp, _l, _vp]),
+    "ltx_mlx_random_normal": (_i, [_u64, _i, _vp, _l]),
+    "ltx_threefry2x32": (None, [_vp, _vp, _vp]),
     "ltx_write_png": (_i, [C.c_char_p, _vp, _i, _i]),
     "ltx_upscaler_load": (_i, [_vp, C.c_char_p]),
     "ltx_upscaler_unload": (_i, [_vp]),

@@ -1100,6 +1100,15 @@ int ltx_map_vae_encoder_key(const char* file_key, char* out, int cap) {
 }
 
 
+/* ---- MLX-compatible noise ---- */
+int ltx_mlx_random_normal(uint64_t seed, int draw_index, float* out, long n) {
+    if (!out || n < 0 || draw_index < 0) return LTX_ERR_INVALID_CONFIGURATION;
+    mlx_random_normal(seed, draw_index, n, out);
+    return LTX_OK;
+}
+
+void ltx_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]) { threefry2x32(key, ctr, out); }
+
 /* ---- frame export ---- */
 int ltx_frames_to_u8(const float* frames, long n, uint8_t* out) {
     if (!frames || !out || n < 0) return LTX_ERR_INVALID_CONFIGURATION;

@@ -1,3 +1,4 @@
+#include <cmath>
 // hostmath.cpp - see hostmath.h. Scalar arithmetic follows the reference operation by operation (Swift `Float`
 // = IEEE f32, no fused multiply-add), so floating-point contraction is disabled for this file.
 #pragma clang fp contract(off)
@@ -511,4 +512,100 @@ bool write_png_rgb8(const char* path, const uint8_t* rgb, int width, int height)
     const bool ok = ferror(f) == 0;
     fclose(f);
     return ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MLX-compatible noise (see hostmath.h). Restated from the published algorithm of mlx 0.30.x (random.cpp, threefry.cpp,
+// erf.cpp); nothing of it is in /root/reference.
+// ---------------------------------------------------------------------------------------------------------------
+void threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]) {
+    static const int rot[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+    const uint32_t ks[3] = {key[0], key[1], key[0] ^ key[1] ^ 0x1BD11BDAu};
+    uint32_t x0 = ctr[0] + ks[0], x1 = ctr[1] + ks[1];
+    for (int i = 0; i < 5; ++i) {  // 5 groups of 4 rounds = Threefry-2x32-20
+        for (int r = 0; r < 4; ++r) {
+            const int rr = rot[i & 1][r];
+            x0 += x1;
+            x1 = (x1 << rr) | (x1 >> (32 - rr));
+            x1 ^= x0;
+        }
+        x0 += ks[(i + 1) % 3];
+        x1 += ks[(i + 2) % 3] + uint32_t(i + 1);
+    }
+    out[0] = x0;
+    out[1] = x1;
+}
+
+void mlx_random_bits(const uint32_t key[2], long n_words, uint32_t* out) {
+    const long half = n_words / 2;
+    const bool even = (n_words % 2) == 0;
+    const long second = half + (even ? 0 : 1);  // where the second words of the pairs go
+    for (long i = 0; i < half; ++i) {
+        const uint32_t ctr[2] = {uint32_t(i), uint32_t(second + i)};
+        uint32_t r[2];
+        threefry2x32(key, ctr, r);
+        out[i] = r[0];
+        out[second + i] = r[1];
+    }
+    if (!even) {
+        const uint32_t ctr[2] = {uint32_t(half), 0u};
+        uint32_t r[2];
+        threefry2x32(key, ctr, r);
+        out[half] = r[0];
+    }
+}
+
+static float mlx_erfinv(float a) {  // two-branch polynomial in t = log(1 - a^2), max error 2.4 ulp
+    float t = std::fma(a, 0.0f - a, 1.0f);
+    t = std::log(t);
+    float p;
+    if (std::fabs(t) > 6.125f) {
+        p = 3.03697567e-10f;
+        p = std::fma(p, t, 2.93243101e-8f);
+        p = std::fma(p, t, 1.22150334e-6f);
+        p = std::fma(p, t, 2.84108955e-5f);
+        p = std::fma(p, t, 3.93552968e-4f);
+        p = std::fma(p, t, 3.02698812e-3f);
+        p = std::fma(p, t, 4.83185798e-3f);
+        p = std::fma(p, t, -2.64646143e-1f);
+        p = std::fma(p, t, 8.40016484e-1f);
+    } else {
+        p = 5.43877832e-9f;
+        p = std::fma(p, t, 1.43285448e-7f);
+        p = std::fma(p, t, 1.22774793e-6f);
+        p = std::fma(p, t, 1.12963626e-7f);
+        p = std::fma(p, t, -5.61530760e-5f);
+        p = std::fma(p, t, -1.47697632e-4f);
+        p = std::fma(p, t, 2.31468678e-3f);
+        p = std::fma(p, t, 1.15392581e-2f);
+        p = std::fma(p, t, -2.32015476e-1f);
+        p = std::fma(p, t, 8.86226892e-1f);
+    }
+    return a * p;
+}
+
+void mlx_random_normal(uint64_t seed, int draw_index, long n, float* out) {
+    uint32_t global[2] = {uint32_t(seed >> 32), uint32_t(seed & 0xffffffffu)};
+    uint32_t sub[2] = {0, 0};
+    for (int d = 0; d <= draw_index; ++d) {  // KeySequence::next(): split the global key in two, keep row 0, hand out row 1
+        uint32_t w[4];
+        mlx_random_bits(global, 4, w);
+        global[0] = w[0];
+        global[1] = w[1];
+        sub[0] = w[2];
+        sub[1] = w[3];
+    }
+    std::vector<uint32_t> bits((size_t)n);
+    mlx_random_bits(sub, n, bits.data());
+    const float lo = std::nextafter(-1.0f, 0.0f), hi = 1.0f;
+    const float range = hi - lo;
+    const float upper = std::nextafter(1.0f, 0.0f);
+    const float maxval = float(UINT32_MAX);
+    const float sqrt2 = float(std::sqrt(2.0));
+    for (long i = 0; i < n; ++i) {
+        float u = float(bits[(size_t)i]) / maxval;
+        u = u < upper ? u : upper;
+        u = range * u + lo;
+        out[i] = sqrt2 * mlx_erfinv(u);
+    }
 }

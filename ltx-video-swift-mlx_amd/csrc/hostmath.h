@@ -63,6 +63,18 @@ bool map_text_encoder_file_key(const std::string& file_key, std::string* module_
 // LTXRoPE.swift:375-490). cos/sin [T][dim/2] f32 (no padding slots: one axis -> dim/2 frequencies).
 void rope_tables_1d(int T, int dim, double theta, int max_pos, std::vector<float>* cos_out, std::vector<float>* sin_out);
 
+// MLX-compatible noise (R2: generateNoise = MLXRandom.seed(seed); MLXRandom.normal(shape, f32),
+// LatentUtils.swift:69-83). The arithmetic is mlx-swift 0.30.6's (absent from the reference tree), restated from its
+// published algorithm: threefry2x32-20 counter hash; key(seed) = {seed >> 32, seed & 0xffffffff}; every keyless draw first
+// splits the global key (bits of shape [2][2]: row 0 stays global, row 1 is the draw's key); bits(n words) =
+// out[i], out[i + ceil(n/2)] = hash(key, {i, i + ceil(n/2)}); uniform = min(bits / float(UINT32_MAX), nextafter(1, 0)) mapped
+// to [nextafter(-1, 0), 1); normal = sqrt(2) * erfinv(u) with the two-branch 9/10-term polynomial. The hash is pinned by the
+// Random123 known-answer vectors; the draw pipeline is NOT verified against an MLX run (none is possible here).
+void threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]);
+void mlx_random_bits(const uint32_t key[2], long n_words, uint32_t* out);
+// the `draw_index`-th keyless MLXRandom.normal(shape) call after MLXRandom.seed(seed) (0 = the first), n f32 values
+void mlx_random_normal(uint64_t seed, int draw_index, long n, float* out);
+
 // frame export (VideoExporter.swift:563-580)
 void frames_to_u8(const float* frames, long n, uint8_t* out);
 bool write_png_rgb8(const char* path, const uint8_t* rgb, int width, int height);

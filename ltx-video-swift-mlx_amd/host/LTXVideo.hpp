@@ -96,6 +96,10 @@ struct LTXVideoGenerationConfig {
     int width = 704, height = 480, numFrames = 121, numSteps = 8;
     float cfgScale = 1.0f;
     std::optional<uint64_t> seed;
+    // Which generator turns `seed` into the initial latent: false = this build's counter-based generator; true = the MLX
+    // restatement (ltx_mlx_random_normal: MLXRandom.seed(seed); MLXRandom.normal(shape), LatentUtils.swift:69-83) so that a
+    // seed reproduces the reference's noise - unverified against MLX itself, hence opt-in.
+    bool mlxCompatibleNoise = false;
     float guidanceRescale = 0.0f, crossAttentionScale = 1.0f, geGamma = 0.0f, stgScale = 0.0f;
     float imageCondNoiseScale = 0.0f;  // LTXConfig.swift:271,289
     std::vector<int> stgBlocks{29};
@@ -258,7 +262,15 @@ class LTXPipeline {
                 throw LTXError(LTXError::invalidConfiguration, "injection noise must hold numSteps draws of the image latent's shape");
         }
         const size_t n = size_t(128) * F * H * W;
-        std::vector<float> latent = noise.empty() ? generateNoise(n, config.seed.value_or(0)) : noise;
+        std::vector<float> latent = noise;
+        if (latent.empty()) {
+            if (config.mlxCompatibleNoise) {
+                latent.resize(n);
+                check(ltx_mlx_random_normal(config.seed.value_or(0), 0, latent.data(), long(n)));
+            } else {
+                latent = generateNoise(n, config.seed.value_or(0));
+            }
+        }
         if (latent.size() != n) throw LTXError(LTXError::invalidConfiguration, "noise tensor has the wrong size");
         // sigma schedule (LTXPipeline.swift:775-787); distilled ignores numSteps but the loop runs numSteps times
         float sig[128];

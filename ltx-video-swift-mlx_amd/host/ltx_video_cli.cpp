@@ -36,6 +36,7 @@ struct Args {
          dryRun = false;
     // additions of this build
     std::string embeddings, vaeWeights, upscalerWeights, distilledLoraPath, pngDir, hiddenStates, connectorWeights, imageTensor;
+    std::string noiseRng = "native";
     int vaeTile = 0, vaeOverlap = 1;
     int numLayers = 0, numHeads = 0, captionChannels = 0;  // reduced architectures for tests (0 = reference default)
 };
@@ -49,7 +50,8 @@ struct Args {
                  "  [--guidance-rescale] [--cross-attn-scale] [--ge-gamma] [--stg-scale] [--stg-blocks \"29\"]\n"
                  "  [--transformer-quant bf16|qint8|int4] [--two-stage] [--distilled-lora] [--profile] [--dry-run] [--debug]\n"
                  "  [--embeddings file] [--vae-weights file] [--upscaler-weights file] [--distilled-lora-path file]\n"
-                 "  [--vae-tile N] [--vae-overlap N]\n";
+                 "  [--vae-tile N] [--vae-overlap N] [--png-dir dir] [--gemma-hidden-states file] [--connector-weights file]\n"
+                 "  [--image-tensor file] [--noise-rng native|mlx]\n";
     std::exit(code);
 }
 
@@ -99,6 +101,7 @@ Args parse_generate(int argc, char** argv, int start) {
         else if (k == "--distilled-lora-path") a.distilledLoraPath = need(i);
         else if (k == "--vae-tile") a.vaeTile = std::stoi(need(i));
         else if (k == "--png-dir") a.pngDir = need(i);
+        else if (k == "--noise-rng") a.noiseRng = need(i);
         else if (k == "--gemma-hidden-states") a.hiddenStates = need(i);
         else if (k == "--connector-weights") a.connectorWeights = need(i);
         else if (k == "--image-tensor") a.imageTensor = need(i);
@@ -170,6 +173,7 @@ int run_generate(const Args& a) {
     const std::string effModel = a.distilledLora ? "dev" : a.model;
     const auto model = parseModel(effModel);
     if (!model) throw ValidationError("Invalid model: " + a.model + ". Use: distilled or dev");
+    if (a.noiseRng != "native" && a.noiseRng != "mlx") throw ValidationError("Invalid noise generator: " + a.noiseRng + ". Use: native or mlx");
     if (a.twoStage) {
         if (a.width % 64 != 0 || a.height % 64 != 0)
             throw ValidationError("Two-stage requires width and height divisible by 64. Got " + std::to_string(a.width) + "x" + std::to_string(a.height));
@@ -213,6 +217,7 @@ int run_generate(const Args& a) {
     cfg.numSteps = a.distilledLora ? a.steps.value_or(8) : a.steps.value_or(defaultSteps(*model));
     cfg.cfgScale = a.distilledLora ? a.guidance.value_or(1.0f) : a.guidance.value_or(defaultGuidance(*model));
     cfg.seed = a.seed;
+    cfg.mlxCompatibleNoise = a.noiseRng == "mlx";
     cfg.guidanceRescale = a.guidanceRescale; cfg.crossAttentionScale = a.crossAttnScale; cfg.geGamma = a.geGamma;
     cfg.stgScale = a.stgScale; cfg.stgBlocks = stg; cfg.twoStage = a.twoStage;
     PrecomputedEmbeddings emb;

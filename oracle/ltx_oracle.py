@@ -1337,3 +1337,76 @@ def vae_encoder_file_keys(w):
             fk = fk.replace(f"down_blocks_{i}.downsamplers.", f"down_blocks.{i}.downsamplers.0.")
         out["encoder." + fk] = v
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MLX-compatible noise (R2 generateNoise, LatentUtils.swift:69-83: MLXRandom.seed(seed) then
+# MLXRandom.normal(shape, float32)). The generator is mlx-swift 0.30.6's (Package.swift:21), which is NOT in the reference tree:
+# restated from MLX's published algorithm. Pinned: the threefry2x32-20 hash by the Random123 known-answer vectors
+# (tests/test_host_logic.py). Unpinned: the bits -> uniform -> erfinv pipeline (no MLX run is possible here).
+# ---------------------------------------------------------------------------------------------------------------------
+def threefry2x32(key, c0, c1):
+    """key: two uint32; c0, c1: uint32 arrays (counter words). Returns the two output word arrays."""
+    rot = ((13, 15, 26, 6), (17, 29, 16, 24))
+    k0, k1 = np.uint32(key[0]), np.uint32(key[1])
+    ks = (k0, k1, k0 ^ k1 ^ np.uint32(0x1BD11BDA))
+    with np.errstate(over="ignore"):
+        x0 = np.asarray(c0, np.uint32) + ks[0]
+        x1 = np.asarray(c1, np.uint32) + ks[1]
+        for i in range(5):
+            for r in rot[i & 1]:
+                x0 = x0 + x1
+                x1 = (x1 << np.uint32(r)) | (x1 >> np.uint32(32 - r))
+                x1 = x1 ^ x0
+            x0 = x0 + ks[(i + 1) % 3]
+            x1 = x1 + ks[(i + 2) % 3] + np.uint32(i + 1)
+    return x0, x1
+
+
+def mlx_random_bits(key, n):
+    """n uint32 words from one key: words i and i + ceil(n/2) come from hash(key, (i, i + ceil(n/2)))."""
+    half, odd = n // 2, n % 2
+    second = half + odd
+    out = np.empty(n, np.uint32)
+    i = np.arange(half, dtype=np.uint32)
+    a, b = threefry2x32(key, i, i + np.uint32(second))
+    out[:half] = a
+    out[second:second + half] = b
+    if odd:
+        a, _ = threefry2x32(key, np.array([half], np.uint32), np.array([0], np.uint32))
+        out[half] = a[0]
+    return out
+
+
+def mlx_erfinv(a):
+    a = np.asarray(a, np.float32)
+    f = np.float32
+    t = np.log((f(1.0) - a.astype(np.float64) * a.astype(np.float64)).astype(np.float32))  # fma(a, -a, 1): one rounding
+
+    def poly(cs):
+        p = np.full_like(t, f(cs[0]))
+        for c in cs[1:]:
+            p = (p.astype(np.float64) * t.astype(np.float64) + np.float64(f(c))).astype(np.float32)  # fma: one rounding
+        return p
+
+    big = poly((3.03697567e-10, 2.93243101e-8, 1.22150334e-6, 2.84108955e-5, 3.93552968e-4, 3.02698812e-3, 4.83185798e-3,
+                -2.64646143e-1, 8.40016484e-1))
+    small = poly((5.43877832e-9, 1.43285448e-7, 1.22774793e-6, 1.12963626e-7, -5.61530760e-5, -1.47697632e-4, 2.31468678e-3,
+                  1.15392581e-2, -2.32015476e-1, 8.86226892e-1))
+    return a * np.where(np.abs(t) > f(6.125), big, small)
+
+
+def mlx_random_normal(seed, shape, draw_index=0):
+    """The draw_index-th keyless MLXRandom.normal(shape) after MLXRandom.seed(seed)."""
+    g = (np.uint32((seed >> 32) & 0xFFFFFFFF), np.uint32(seed & 0xFFFFFFFF))
+    sub = None
+    for _ in range(draw_index + 1):
+        w = mlx_random_bits(g, 4)
+        g, sub = (w[0], w[1]), (w[2], w[3])
+    n = int(np.prod(shape))
+    f = np.float32
+    u = mlx_random_bits(sub, n).astype(np.float32) / f(4294967295.0)
+    u = np.minimum(u, np.nextafter(f(1.0), f(0.0)))
+    lo = np.nextafter(f(-1.0), f(0.0))
+    u = (f(1.0) - lo) * u + lo
+    return (f(np.sqrt(2.0)) * mlx_erfinv(u)).astype(np.float32).reshape(shape)

@@ -41,6 +41,7 @@ def test_cli_dry_run_defaults(ltx):
     (["--transformer-quant", "fp8"], "Invalid transformer quantization: fp8. Use: bf16, qint8, or int4"),
     (["-m", "turbo"], "Invalid model: turbo. Use: distilled or dev"),
     (["-w", "800", "--two-stage"], "Two-stage requires width and height divisible by 64. Got 800x512"),
+    (["--noise-rng", "philox"], "Invalid noise generator: philox. Use: native or mlx"),
 ])
 def test_cli_validation_messages(ltx, args, msg):
     rc, _, err = run("generate", "x", "--dry-run", *args)

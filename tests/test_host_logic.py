@@ -381,3 +381,29 @@ def test_frame_export_u8_and_png(ltx, tmp_path):
     assert hdr == (53, 37, 8, 2, 0, 0, 0)
     rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(37, 53 * 3 + 1)
     assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(37, 53, 3), img)
+
+
+# ---- MLX-compatible noise ----
+def test_threefry2x32_known_answers(ltx, oracle):
+    """Random123's threefry2x32-20 known-answer vectors (the same three the JAX and MLX test suites use) pin the hash."""
+    kat = [((0, 0), (0, 0), (0x6B200159, 0x99BA4EFE)),
+           ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+           ((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3), (0xC4923A9C, 0x483DF7A0))]
+    for key, ctr, want in kat:
+        assert tuple(int(v) for v in ltx.threefry2x32(key, ctr)) == want
+        a, b = oracle.threefry2x32(key, np.array([ctr[0]], np.uint32), np.array([ctr[1]], np.uint32))
+        assert (int(a[0]), int(b[0])) == want
+
+
+def test_mlx_random_normal_matches_the_restatement(ltx, oracle):
+    """Library vs oracle on the draw pipeline (bits layout for even / odd counts, key split per draw, uniform -> erfinv):
+    two restatements of the same published algorithm, NOT a check against MLX itself."""
+    for seed, shape, draw in [(42, (1, 128, 2, 8, 8), 0), (0, (7,), 0), (2**40 + 5, (3, 11), 2), (42, (1, 128, 4, 16, 24), 1)]:
+        got = ltx.mlx_random_normal(seed, shape, draw)
+        want = oracle.mlx_random_normal(seed, shape, draw)
+        assert got.shape == tuple(shape)
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7)  # libm logf vs numpy log: <= 1 ulp apart
+    x = ltx.mlx_random_normal(42, (1, 128, 4, 16, 24))
+    assert abs(float(x.mean())) < 0.01 and abs(float(x.std()) - 1.0) < 0.01 and np.isfinite(x).all()
+    assert not np.array_equal(x, ltx.mlx_random_normal(43, (1, 128, 4, 16, 24)))
+    assert not np.array_equal(x, ltx.mlx_random_normal(42, (1, 128, 4, 16, 24), 1))  # second draw after the same seed
