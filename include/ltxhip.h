@@ -150,6 +150,19 @@ int ltx_dit_forward(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* contex
 int ltx_dit_forward_dev(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* context, const float* timesteps,
                         const int32_t* mask, int mask_all_ones, int B, int F, int H, int W, int S,
                         uint64_t ctx_version, float* velocity);
+/* Sequence-parallel forward of ONE sample over sp_world ranks, one process per GPU (no counterpart in the single-device reference;
+ * SURVEY 8(e) "single video on 8 GPUs", 8(f) item 4). Rank sp_rank owns tokens [sp_rank*Tn, (sp_rank+1)*Tn) of the F*H*W grid,
+ * Tn = F*H*W / sp_world (must divide, Tn % 8 == 0): `latent` is [1][Tn][in_channels] and `velocity` [1][Tn][out_channels], that
+ * rank's rows only; context, timestep and mask are the full ones on every rank. Everything per-token is local; each block's
+ * self-attention all-gathers its K rows and V^T block through `gather`, called 2 x num_layers times per forward:
+ *   gather(user, send, recv, bytes): all-gather `bytes` from every rank into recv = [sp_world][bytes] in rank order. DEVICE pointers.
+ *   It must either enqueue the collective on the context's stream (RCCL on the stream given to ltx_ctx_set_stream) or finish it
+ *   before returning (then synchronise that stream first). Every rank must call the forward with the same arguments.
+ * DEVICE pointers, asynchronous on the context stream when `gather` is. */
+typedef void (*ltx_allgather_fn)(void* user, const void* send, void* recv, long bytes);
+int ltx_dit_forward_sp_dev(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* context, const float* timesteps,
+                           const int32_t* mask, int mask_all_ones, int F, int H, int W, int S, uint64_t ctx_version,
+                           int sp_rank, int sp_world, ltx_allgather_fn gather, void* user, float* velocity);
 /* setCrossAttentionScale (LTXTransformer.swift:497); block range inclusive, (0,-1) = all blocks. */
 int ltx_dit_set_cross_attn_scale(ltx_ctx* ctx, float scale, int first_block, int last_block);
 /* setSTGSkipFlags / clearSTGSkipFlags (LTXTransformer.swift:512-526) */

@@ -121,6 +121,9 @@ def threefry2x32(key, ctr):
     return o
 
 
+_ALLGATHER_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long)
+
+
 def frames_to_u8(frames):
     """``VideoExporter.tensorToImages`` pixel conversion: uint8(clip(x,0,1)*255), truncating."""
     f = np.ascontiguousarray(frames, dtype=np.float32)
@@ -270,6 +273,20 @@ class Context:
         S = context.shape[1]
         self._ck(lib.ltx_dit_forward_dev(self._h, _ptr(latent), _ptr(context), _ptr(timesteps), _ptr(mask),
                                          int(mask_all_ones), B, F, H, W, S, ctx_version, _ptr(velocity)))
+
+    def dit_forward_sp_dev(self, latent, context, timesteps, mask, F, H, W, velocity, sp_rank, sp_world, gather, ctx_version=0,
+                           mask_all_ones=False):
+        """Sequence-parallel forward: `latent` [1,Tn,C] / `velocity` [1,Tn,C] hold this rank's token slice; `gather(send_ptr,
+        recv_ptr, nbytes)` all-gathers device memory over the ranks (see dist.sp_allgather_fn). Device tensors."""
+        S = context.shape[1]
+
+        def _cb(_user, send, recv, nbytes):
+            gather(send, recv, nbytes)
+
+        cb = _ALLGATHER_FN(_cb)  # kept alive for the duration of the call
+        self._ck(lib.ltx_dit_forward_sp_dev(self._h, _ptr(latent), _ptr(context), _ptr(timesteps), _ptr(mask), int(mask_all_ones),
+                                            F, H, W, S, ctx_version, sp_rank, sp_world, C.cast(cb, C.c_void_p), None,
+                                            _ptr(velocity)))
 
     def dit_set_cross_attn_scale(self, scale, first=0, last=-1):
         self._ck(lib.ltx_dit_set_cross_attn_scale(self._h, scale, first, last))

@@ -97,6 +97,7 @@ SIGNATURES = {
     "ltx_dit_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ltx_dit_forward_tokens": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ltx_dit_forward_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _vp]),
+    "ltx_dit_forward_sp_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u64, _i, _i, _vp, _vp, _vp]),
     "ltx_dit_set_cross_attn_scale": (_i, [_vp, _f, _i, _i]),
     "ltx_dit_set_stg": (_i, [_vp, _ip, _i, _i, _i]),
     "ltx_dit_clear_stg": (_i, [_vp]),

@@ -365,6 +365,30 @@ int ltx_dit_forward_dev(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* co
     });
 }
 
+int ltx_dit_forward_sp_dev(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* context, const float* timesteps,
+                           const int32_t* mask, int mask_all_ones, int F, int H, int W, int S, uint64_t ctx_version,
+                           int sp_rank, int sp_world, ltx_allgather_fn gather, void* user, float* velocity) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        DiTModel* m = need_dit(ctx);
+        LTX_REQUIRE(sp_world >= 1 && (sp_world == 1 || gather), "ltx_dit_forward_sp_dev: %d ranks need a gather callback", sp_world);
+        DiTForwardArgs a;
+        a.latent = latent;
+        a.context = context;
+        a.timesteps = timesteps;
+        a.mask = mask;
+        a.mask_all_ones = mask_all_ones;
+        a.B = 1; a.F = F; a.H = H; a.W = W; a.S = S;
+        a.ctx_version = ctx_version;
+        a.velocity = velocity;
+        a.sp_rank = sp_rank;
+        a.sp_world = sp_world;
+        a.sp_gather = gather;
+        a.sp_user = user;
+        dit_forward(ctx, m, a);
+    });
+}
+
 int ltx_dit_forward(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* context, const float* timesteps,
                     const int32_t* mask, int B, int F, int H, int W, int S, float* velocity) {
     if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;

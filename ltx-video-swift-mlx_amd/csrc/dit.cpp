@@ -304,7 +304,13 @@ DiTModel::CtxCache* prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardA
 
 void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     const int D = m->D, L = m->L, B = a.B;
-    const int T = a.F * a.H * a.W;
+    const int Tfull = a.F * a.H * a.W;
+    const int NW = a.sp_world < 1 ? 1 : a.sp_world;
+    LTX_REQUIRE(NW == 1 || (a.sp_gather && B == 1 && a.sp_rank >= 0 && a.sp_rank < NW && Tfull % NW == 0 && (Tfull / NW) % 8 == 0),
+                "dit_forward: sequence parallelism needs a gather callback, batch 1 and F*H*W = %d divisible by %d ranks into multiples of 8",
+                Tfull, NW);
+    const int T = Tfull / NW;            // rows this rank evaluates
+    const int tok0 = a.sp_rank * T;      // first global token of this rank (NW == 1: 0)
     LTX_REQUIRE(B >= 1 && B <= 8 && T >= 1 && a.S >= 1, "dit_forward: bad shapes B=%d T=%d S=%d", B, T, a.S);
     const int G = a.n_groups < 1 ? 1 : a.n_groups;
     const int BG = B * G;  // rows of the timestep path / modulation tables
@@ -333,6 +339,19 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     float* qc = m->ws_qc.as<float>();
     float* mod = m->ws_mod.as<float>();
     const float eps = m->cfg.norm_eps;
+    // RoPE rows of this rank's tokens (the table is [F*H*W][D/2] in global token order)
+    const float* rope_c = m->rope_cos.as<float>() + (long)tok0 * (D >> 1);
+    const float* rope_s = m->rope_sin.as<float>() + (long)tok0 * (D >> 1);
+    const int TfullPad = ((Tfull + 63) / 64) * 64;
+    bf16_t* k_full = k;
+    bf16_t* vt_full = vt;
+    if (NW > 1) {
+        m->ws_sp_k.ensure((size_t)Tfull * D * 2);
+        if (m->ws_sp_vt.ensure((size_t)D * TfullPad * 2)) HIP_CHECK(hipMemsetAsync(m->ws_sp_vt.p, 0, m->ws_sp_vt.bytes, st));
+        m->ws_sp_vtg.ensure((size_t)NW * D * T * 2);
+        k_full = m->ws_sp_k.as<bf16_t>();
+        vt_full = m->ws_sp_vt.as<bf16_t>();
+    }
 
     // 1. patchify_proj: bf16 x bf16 -> bf16 in the reference; the residual stream starts as that bf16 value
     {
@@ -368,15 +387,28 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             eqk.out_f32 = qk;
             eqk.ld_f32 = 2 * D;
             gemm_linear(xn, D, blk.qk1, (int)rows, eqk, st, sk);
-            launch_qknorm_rope2(qk, blk.qn1, q, qk + D, blk.kn1, k, 2 * D, D, m->rope_cos.as<float>(), m->rope_sin.as<float>(), T,
-                                (int)rows, D, eps, st);
-            for (int b = 0; b < B; ++b) gemm_vt(xn + (size_t)b * T * D, D, T, blk.v1, vt + (size_t)b * D * Tpad, Tpad, st, sk);
+            launch_qknorm_rope2(qk, blk.qn1, q, qk + D, blk.kn1, k, 2 * D, D, rope_c, rope_s, T, (int)rows, D, eps, st);
             AttnArgs at;
+            if (NW == 1) {
+                for (int b = 0; b < B; ++b) gemm_vt(xn + (size_t)b * T * D, D, T, blk.v1, vt + (size_t)b * D * Tpad, Tpad, st, sk);
+                at.Vt = vt; at.ldvt = Tpad; at.vt_bstride = (long)D * Tpad;
+                at.K = k; at.k_bstride = (long)T * D;
+                at.Tk = T;
+            } else {
+                // keys / values of every rank's tokens: K rows gather straight into global token order; V^T blocks [D][T] of
+                // the ranks are interleaved into [D][Tfull] after the gather
+                gemm_vt(xn, D, T, blk.v1, vt, T, st, sk);  // V^T of the local tokens, dense [D][T]
+                a.sp_gather(a.sp_user, k, k_full, (long)T * D * 2);
+                a.sp_gather(a.sp_user, vt, m->ws_sp_vtg.p, (long)D * T * 2);
+                launch_sp_vt_interleave(m->ws_sp_vtg.as<bf16_t>(), vt_full, NW, D, T, TfullPad, st);
+                at.Vt = vt_full; at.ldvt = TfullPad; at.vt_bstride = (long)D * TfullPad;
+                at.K = k_full; at.k_bstride = (long)Tfull * D;
+                at.Tk = Tfull;
+            }
             at.Q = q; at.ldq = D; at.q_bstride = (long)T * D;
-            at.K = k; at.ldk = D; at.k_bstride = (long)T * D;
-            at.Vt = vt; at.ldvt = Tpad; at.vt_bstride = (long)D * Tpad;
+            at.ldk = D;
             at.O = ao; at.ldo = D; at.o_bstride = (long)T * D;
-            at.B = B; at.H = m->cfg.num_heads; at.Tq = T; at.Tk = T;
+            at.B = B; at.H = m->cfg.num_heads; at.Tq = T;
             launch_attention(at, st);
             GemmEpilogue eo;
             eo.out_f32 = x;

@@ -74,6 +74,7 @@ struct DiTModel {
 
     // ---- activation workspace (grown on demand, never freed inside a step) ----
     DevBuf ws_x, ws_xn, ws_xb, ws_qk, ws_q, ws_k, ws_vt, ws_ao, ws_ffh, ws_qc;
+    DevBuf ws_sp_k, ws_sp_vt, ws_sp_vtg;  // sequence-parallel: gathered K [T][D], V^T [D][Tpad], V^T gather staging
     DevBuf ws_ts, ws_emb256, ws_h1, ws_embts, ws_ada, ws_mod, ws_modout, ws_splitk;
     int ws_rows = 0, ws_B = 0, ws_Tpad = 0;
 };
@@ -98,6 +99,13 @@ struct DiTForwardArgs {
     int B = 1, F = 0, H = 0, W = 0, S = 0;
     uint64_t ctx_version = 0;         // 0 = recompute context every call; else cache key
     float* velocity = nullptr;        // device [B][T][out_channels] f32
+    // Sequence parallelism over sp_world ranks (single sample on several GPUs): this rank owns tokens
+    // [sp_rank*Tn, (sp_rank+1)*Tn), Tn = F*H*W / sp_world, and `latent`, `row_map`, `velocity` hold only those Tn rows. Every
+    // per-token operation is local; self-attention all-gathers K and V^T of each layer through `sp_gather`, which must
+    // enqueue on the context's stream (or synchronise) an all-gather of `bytes` per rank: recv = [sp_world][bytes], rank order.
+    int sp_rank = 0, sp_world = 1;
+    void (*sp_gather)(void* user, const void* send, void* recv, long bytes) = nullptr;
+    void* sp_user = nullptr;
 };
 void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a);
 

@@ -25,6 +25,9 @@ void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const f
 void launch_qknorm_rope(const float* x, long ldx, const float* w, const float* cosT, const float* sinT, int T,
                         bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t stream);
 
+// sequence-parallel self-attention: gathered V^T blocks [N][D][Tn] -> one V^T [D][ld] with rank r's keys at columns r*Tn ..
+void launch_sp_vt_interleave(const bf16_t* gathered, bf16_t* vt, int N, int D, int Tn, long ld, hipStream_t stream);
+
 void launch_cast_f32_bf16(const float* x, bf16_t* out, long n, hipStream_t stream);
 void launch_cast_bf16_f32(const bf16_t* x, float* out, long n, hipStream_t stream);
 

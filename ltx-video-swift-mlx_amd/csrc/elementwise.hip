@@ -599,6 +599,28 @@ void launch_mask_to_bias(const int32_t* mask, float* bias, long n, hipStream_t s
     hipLaunchKernelGGL(mask_to_bias_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, mask, bias, n);
     HIP_CHECK(hipGetLastError());
 }
+// [N][D][Tn] -> [D][ld]: one 16-byte piece (8 keys) per thread, rows stay contiguous on both sides
+__global__ __launch_bounds__(256) void sp_vt_interleave_kernel(const bf16_t* __restrict__ g, bf16_t* __restrict__ vt, int N, int D,
+                                                               int Tn, long ld) {
+    const int per_row = Tn >> 3;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)N * D * per_row;
+    if (i >= total) return;
+    const int c = (int)(i % per_row);
+    const long rd = i / per_row;
+    const int d = (int)(rd % D);
+    const int r = (int)(rd / D);
+    const uint4 v = *(const uint4*)(g + ((long)r * D + d) * Tn + c * 8);
+    *(uint4*)(vt + (long)d * ld + (long)r * Tn + c * 8) = v;
+}
+
+void launch_sp_vt_interleave(const bf16_t* gathered, bf16_t* vt, int N, int D, int Tn, long ld, hipStream_t stream) {
+    LTX_REQUIRE(Tn % 8 == 0 && ld % 8 == 0, "sp_vt_interleave: Tn=%d ld=%ld must be multiples of 8", Tn, ld);
+    const long total = (long)N * D * (Tn >> 3);
+    hipLaunchKernelGGL(sp_vt_interleave_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, gathered, vt, N, D, Tn, ld);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_patchify_bf16(const float* latent, bf16_t* tokens, int B, int C, int T, hipStream_t stream) {
     hipLaunchKernelGGL(patchify_bf16_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, stream, latent, tokens, C, T);
     HIP_CHECK(hipGetLastError());

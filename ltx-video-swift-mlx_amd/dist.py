@@ -8,6 +8,10 @@ box, "gloo" in CPU tests). The reference is single-device; this is new design (D
   one xGMI hop) rather than a ring.
 * VAE temporal tiles (config 5): tiles are independent decoder calls -> round-robin over ranks, gathered to rank 0
   and blended there in tile order (the blend is order-dependent, VideoDecoder.swift:561-592).
+* one sample on several GPUs (sequence parallelism): tokens are split into equal contiguous slices; all
+  per-token work (projections, norms, FFN, cross-attention against the replicated text keys) is local, each block's self-attention
+  all-gathers its K rows and V^T block (2 collectives per block, (T/N)*4096*2 B each per rank), and one all-gather of the velocity
+  slices per step lets every rank run the scheduler redundantly. `hip_forward_fn_sp`.
 
 `forward_fn(tokens_bf16_f32, branch, step)` abstracts the DiT forward so the same loop runs on the HIP path
 (Context.dit_forward_dev) and, in CPU tests, on a stand-in; the arithmetic around it (CFG, rescale, Euler) is done with
@@ -128,6 +132,79 @@ def blend_tiles(chunks, overlap):
         else:
             result = torch.cat([result, nxt], 0)
     return torch.clamp((result + 1.0) / 2.0, 0.0, 1.0)
+
+
+class _DevMem:
+    """Zero-copy view of raw device memory for torch (CUDA array interface)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def sp_allgather_fn(device, group=None):
+    """The `gather(send_ptr, recv_ptr, nbytes)` callback of Context.dit_forward_sp_dev over torch.distributed.
+
+    backend nccl (= RCCL): the all-gather is enqueued behind the library's kernels - the context runs on torch's current stream and
+    ProcessGroupNCCL orders its own stream after / before it with events, no host synchronisation. backend gloo (tests): device ->
+    host, all_gather on the CPU, host -> device, synchronising the stream on both sides."""
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+
+    def gather(send_ptr, recv_ptr, nbytes):
+        send = torch.as_tensor(_DevMem(send_ptr, nbytes), device=device)
+        recv = torch.as_tensor(_DevMem(recv_ptr, nbytes * world), device=device)
+        if backend == "gloo":
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, send.cpu(), group=group)  # .cpu() synchronises the current stream
+            recv.copy_(torch.cat(parts).to(device))
+            torch.cuda.current_stream(device).synchronize()
+        else:
+            dist.all_gather_into_tensor(recv, send, group=group)
+
+    return gather
+
+
+def sp_token_slice(T, rank=None, world=None):
+    """Token range [t0, t1) of a rank: contiguous, equal, in global token order (token t = (f*H + h)*W + w)."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    assert T % world == 0 and (T // world) % 8 == 0, f"{T} tokens do not split into {world} equal multiples of 8"
+    n = T // world
+    return rank * n, (rank + 1) * n
+
+
+def sp_gather_velocity(vel_local, group=None):
+    """[Tn, C] f32 slice of every rank -> [T, C] in global token order on every rank (one all-gather per denoise step)."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo" and vel_local.is_cuda:
+        parts = [torch.empty(vel_local.shape, dtype=vel_local.dtype) for _ in range(world)]
+        dist.all_gather(parts, vel_local.cpu(), group=group)
+        return torch.cat(parts).to(vel_local.device)
+    full = torch.empty((world * vel_local.shape[0],) + tuple(vel_local.shape[1:]), dtype=vel_local.dtype, device=vel_local.device)
+    dist.all_gather_into_tensor(full, vel_local.contiguous(), group=group)
+    return full
+
+
+def hip_forward_fn_sp(ctx, context, mask, F, H, W, mask_all_ones=False, group=None):
+    """`forward_fn` for ONE sample sharded by tokens over all ranks of `group`: every rank keeps the full latent (786 KB at
+    768x512x25), evaluates the DiT on its token slice (K / V^T all-gathered inside each block's self-attention), and one final
+    all-gather of the [Tn,128] f32 velocity slices gives every rank the full velocity, so the scheduler arithmetic around it runs
+    redundantly and ranks stay bit-identical without another collective. `context` [1,S,Cc] bf16, `mask` [1,S] int32 or None."""
+    T = F * H * W
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    t0, t1 = sp_token_slice(T, rank, world)
+    gather = sp_allgather_fn(context.device, group)
+
+    def fwd(latent, sigma, branch=0):
+        c = latent.shape[1]
+        tokens = latent.reshape(c, T).t()[t0:t1].contiguous().to(torch.bfloat16).reshape(1, t1 - t0, c)
+        ts = torch.full((1,), float(sigma), dtype=torch.float32, device=latent.device)
+        vel = torch.empty((1, t1 - t0, c), dtype=torch.float32, device=latent.device)
+        ctx.dit_forward_sp_dev(tokens, context, ts, mask, F, H, W, vel, rank, world, gather, ctx_version=201 + branch,
+                               mask_all_ones=mask_all_ones)
+        return sp_gather_velocity(vel[0], group).t().reshape(1, c, F, H, W).contiguous()
+
+    return fwd
 
 
 def hip_forward_fn(ctx, context, mask, F, H, W, mask_all_ones=False):

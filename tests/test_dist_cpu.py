@@ -53,7 +53,13 @@ def _worker(rank, world, port, q):
     ok_tiles = True
     if rank == 0:
         ok_tiles = torch.equal(d.blend_tiles(gathered, 1), d.blend_tiles(tiles, 1))
-    q.put((rank, torch.equal(out, ref), float(ctx.sum()), bool(ok_tiles), out.numpy().tobytes()))
+    # sequence parallelism: token slices of one sample, velocity slices gathered back in global token order
+    T, C = 48, 8
+    t0, t1 = d.sp_token_slice(T)
+    tok = torch.randn(T, C, generator=torch.Generator().manual_seed(5))
+    per_token = lambda x: torch.tanh(x) * 3.0 + x.flip(-1)  # any row-wise map
+    ok_sp = torch.equal(d.sp_gather_velocity(per_token(tok[t0:t1])), per_token(tok)) and (t0, t1) == (rank * 24, rank * 24 + 24)
+    q.put((rank, torch.equal(out, ref), float(ctx.sum()), bool(ok_tiles) and bool(ok_sp), out.numpy().tobytes()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,3 +88,7 @@ def test_tile_sharding_plan():
     assert d.shard_tiles(4, 0, 8) == [0] and d.shard_tiles(4, 5, 8) == []
     assert sorted(sum((d.shard_tiles(5, r, 2) for r in range(2)), [])) == [0, 1, 2, 3, 4]
     assert [d.cfg_branch_for_rank(r) for r in range(4)] == [0, 1, 0, 1]
+    # sequence-parallel token slices: equal, contiguous, multiples of 8 (1536 tokens over 8 ranks = 192 each)
+    assert [d.sp_token_slice(1536, r, 8) for r in (0, 7)] == [(0, 192), (1344, 1536)]
+    with pytest.raises(AssertionError):
+        d.sp_token_slice(1536, 0, 5)
