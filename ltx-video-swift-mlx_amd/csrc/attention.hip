@@ -490,6 +490,190 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_kernel_pp(const AttnArgs a) {
 // allocator moves 250-300 registers between the two halves per tile step (v_accvgpr_read/write), ignores or over-serialises the
 // sched_group_barrier interleave (softmax ends up after the MFMAs) and spills 1.1-1.5 KB to scratch. The shape is right for
 // this problem size; it needs an assembly-level main loop with hand-assigned registers.)
+
+// ---------------------------------------------------------------------------------------------------------------
+// 48 queries per wave, one wave per SIMD (192 queries per workgroup): layout reference in plain HIP C++.
+// The shape that fits 1536 tokens x 32 heads exactly (256 workgroups, every SIMD loaded alike), on v_mfma_f32_16x16x32_bf16:
+// A/B lane (r = lane&15, g = lane>>4) holds k = 8g..8g+7 of row/col r; C lane (c = lane&15, g) holds rows 4g..4g+3 of col c.
+// MFMA row rho of key block kb reads tile key 32*(kb>>1) + 4*(kb&1) + 8*(rho>>2) + (rho&3), so a lane's 4+4 accumulators of
+// blocks (2i, 2i+1) are the 8 consecutive keys 32i + 8g .. +7 = the B operand of the PV product's k-step i. K rows are
+// XOR-swizzled by rho (bits {3,4,0,1} of the key), Vt rows by (d>>1)&7. This version leaves scheduling and register assignment
+// to the compiler (which parks half the state in AGPRs and moves it back and forth): it exists to pin the layout with the
+// parity tests; the fast path is the assembly main loop generated from the same layout (attention_w48_asm.inc).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int W48_Q = 192;
+constexpr int W48_SLOTS = 4;
+constexpr int W48_LDS = W48_SLOTS * STAGE_BYTES;
+
+struct W48Lane {  // per-lane constants shared by the C++ and the assembly kernel
+    int koff[4], voff[4];  // buffer-load byte offsets of this lane's 16-byte pieces of a K / Vt tile (pieces w, w+4, w+8, w+12)
+    int kaddr[4], vaddr[2];  // LDS byte address of the K fragment for k-step ks / the Vt fragment for k-step i (slot 0, block 0)
+};
+LTX_DEVFN W48Lane w48_lane(int lane, int wave, long ldk, long ldvt) {
+    W48Lane L;
+    const int c16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = (wave + 4 * i) * 4 + (lane >> 4);
+        const int sw = (((key >> 3) & 3) << 2) | (key & 3);
+        L.koff[i] = (key * (int)ldk + (((lane & 15) ^ sw) << 3)) * 2;
+        const int d = (wave + 4 * i) * 8 + (lane >> 3);
+        L.voff[i] = (d * (int)ldvt + (((lane & 7) ^ ((d >> 1) & 7)) << 3)) * 2;
+    }
+    const int kf_base = (8 * (c16 >> 2) + (c16 & 3)) * 256 + ((g ^ (c16 & 3)) << 4);
+    const int kf_x6 = (c16 & 12) << 4;
+    const int vf_base = K_TILE_BYTES + c16 * 128 + ((g ^ ((c16 >> 1) & 3)) << 4);
+    const int vf_x6 = ((c16 >> 1) & 4) << 4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) L.kaddr[ks] = ((ks << 6) ^ kf_x6) + kf_base;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) L.vaddr[i] = ((i << 6) ^ vf_x6) + vf_base;
+    return L;
+}
+constexpr int w48_kblock_off(int kb) { return (32 * (kb >> 1) + 4 * (kb & 1)) * 256; }  // LDS offset of key block kb's row 0
+constexpr int w48_vblock_off(int db) { return db * 16 * 128; }
+
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_ref(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const bf16_t* Qb = a.Q + (long)b * a.q_bstride + head * 128;
+    const bf16_t* Kb = a.K + (long)b * a.k_bstride + head * 128;
+    const bf16_t* Vb = a.Vt + (long)b * a.vt_bstride + (long)head * 128 * a.ldvt;
+    const int q0 = blockIdx.x * W48_Q + wave * 48;
+    const int nt = a.Tk / KV_TILE;
+    const W48Lane L = w48_lane(lane, wave, a.ldk, a.ldvt);
+    s16x8 qf[3][4];
+    for (int qb = 0; qb < 3; ++qb)
+        for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *(const s16x8*)(Qb + (long)(q0 + 16 * qb + c16) * a.ldq + ks * 32 + g * 8);
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((long)(a.Tk - 1) * a.ldk + 128) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)((long)128 * a.ldvt * 2), 0x00020000);
+    f32x4 o[8][3];
+    for (int db = 0; db < 8; ++db)
+        for (int qb = 0; qb < 3; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[3] = {-INFINITY, -INFINITY, -INFINITY}, l_run[3] = {0.f, 0.f, 0.f};
+    const float c = a.scale * 1.4426950408889634f;
+    for (int t = 0; t < nt; ++t) {  // single-buffered, fully synchronous: a layout check, not a fast kernel
+        __syncthreads();
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(smem + (wave + 4 * i) * 1024), 16, L.koff[i], t * KV_TILE * (int)a.ldk * 2, 0, 0);
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(smem + K_TILE_BYTES + (wave + 4 * i) * 1024), 16, L.voff[i], t * KV_TILE * 2, 0, 0);
+        __syncthreads();
+        f32x4 s[4][3];
+        for (int kb = 0; kb < 4; ++kb)
+            for (int qb = 0; qb < 3; ++qb) s[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < 4; ++kb)
+            for (int ks = 0; ks < 4; ++ks) {
+                const s16x8 kf = *(const s16x8*)(smem + L.kaddr[ks] + w48_kblock_off(kb));
+                for (int qb = 0; qb < 3; ++qb)
+                    s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[qb][ks]), s[kb][qb], 0, 0, 0);
+            }
+        s16x8 pf[3][2];
+        for (int qb = 0; qb < 3; ++qb) {
+            float mloc = s[0][qb][0];
+            for (int kb = 0; kb < 4; ++kb)
+                for (int j = 0; j < 4; ++j) mloc = fmaxf(mloc, s[kb][qb][j]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run[qb], mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+            m_run[qb] = m_new;
+            float psum = 0.f;
+            for (int i = 0; i < 2; ++i) {
+                s16x8 pk;
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int j = 0; j < 4; ++j) {
+                        const float p = __builtin_amdgcn_exp2f(s[2 * i + hh][qb][j] * c - m_new * c);
+                        psum += p;
+                        pk[4 * hh + j] = (short)f32_to_bf16(p);
+                    }
+                pf[qb][i] = pk;
+            }
+            l_run[qb] = l_run[qb] * alpha + psum;
+            for (int db = 0; db < 8; ++db) o[db][qb] *= alpha;
+        }
+        for (int db = 0; db < 8; ++db)
+            for (int i = 0; i < 2; ++i) {
+                const s16x8 vf = *(const s16x8*)(smem + L.vaddr[i] + w48_vblock_off(db));
+                for (int qb = 0; qb < 3; ++qb)
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[qb][i]), o[db][qb], 0, 0, 0);
+            }
+    }
+    for (int qb = 0; qb < 3; ++qb) {
+        float l = l_run[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        bf16_t* orow = a.O + (long)b * a.o_bstride + (long)(q0 + 16 * qb + c16) * a.ldo + head * 128;
+        for (int db = 0; db < 8; ++db) {
+            uint2 pk;
+            pk.x = pack_bf16x2(o[db][qb][0] * inv, o[db][qb][1] * inv);
+            pk.y = pack_bf16x2(o[db][qb][2] * inv, o[db][qb][3] * inv);
+            *(uint2*)(orow + db * 16 + g * 4) = pk;
+        }
+    }
+}
+
+
+#ifdef W48_STAMPS
+__device__ unsigned long long g_w48_stamps[8][8];
+#endif
+// The same kernel with the main loop in assembly (generated by tools/gen_attn_w48.py from the layout above; register map and
+// schedule in that script's header). C++ only prepares the per-lane offsets and the uniform operands.
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const bf16_t* Qb = a.Q + (long)b * a.q_bstride + head * 128;
+    const bf16_t* Kb = a.K + (long)b * a.k_bstride + head * 128;
+    const bf16_t* Vb = a.Vt + (long)b * a.vt_bstride + (long)head * 128 * a.ldvt;
+    bf16_t* Ob = a.O + (long)b * a.o_bstride + head * 128;
+    const int q0 = blockIdx.x * W48_Q + wave * 48;
+    const W48Lane L = w48_lane(lane, wave, a.ldk, a.ldvt);
+    int qo[3], oo[3];
+#pragma unroll
+    for (int qb = 0; qb < 3; ++qb) {
+        qo[qb] = ((q0 + 16 * qb + c16) * (int)a.ldq + g * 8) * 2;
+        oo[qb] = ((q0 + 16 * qb + c16) * (int)a.ldo + g * 4) * 2;
+    }
+    const uint32_t kblo = (uint32_t)(uintptr_t)Kb, kbhi = (uint32_t)((uintptr_t)Kb >> 32);
+    const uint32_t vblo = (uint32_t)(uintptr_t)Vb, vbhi = (uint32_t)((uintptr_t)Vb >> 32);
+    const uint32_t krec = (uint32_t)(((long)(a.Tk - 1) * a.ldk + 128) * 2), vrec = (uint32_t)((long)128 * a.ldvt * 2);
+    const uint32_t ktb = (uint32_t)(KV_TILE * a.ldk * 2);
+    const uint32_t nt4 = (uint32_t)(a.Tk / (4 * KV_TILE));
+    const float c = a.scale * 1.4426950408889634f;
+    const uint32_t wlds = (uint32_t)wave * 1024u;
+    const float tauc = 8.0f / c;  // rescale threshold in score units: a score more than 2^8 (after the scale) above the reference
+#ifdef W48_STAMPS  // tools/ubench/attn_stamps.hip: per-wave s_memtime stamps of one tile step -> g_w48_stamps[wave][5]
+    unsigned long long* dbg = (blockIdx.x == 1 && blockIdx.y == 3) ? &g_w48_stamps[wave][0] : &g_w48_stamps[4 + (wave & 3)][0];
+#endif
+    asm volatile(
+#ifdef W48_STAMPS
+#include "attention_w48_asm_stamps.inc"
+#else
+#include "attention_w48_asm.inc"
+#endif
+        :
+        : [qbase] "s"(Qb), [obase] "s"(Ob), [kblo] "s"(kblo), [kbhi] "s"(kbhi), [vblo] "s"(vblo), [vbhi] "s"(vbhi), [krec] "s"(krec),
+          [vrec] "s"(vrec), [ktb] "s"(ktb), [nt4] "s"(nt4), [c] "s"(c), [tauc] "s"(tauc), [wlds] "s"(wlds), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]),
+          [qo2] "v"(qo[2]), [oo0] "v"(oo[0]), [oo1] "v"(oo[1]), [oo2] "v"(oo[2]), [ko0] "v"(L.koff[0]), [ko1] "v"(L.koff[1]),
+          [ko2] "v"(L.koff[2]), [ko3] "v"(L.koff[3]), [vo0] "v"(L.voff[0]), [vo1] "v"(L.voff[1]), [vo2] "v"(L.voff[2]),
+          [vo3] "v"(L.voff[3]), [ka0] "v"(L.kaddr[0]), [ka1] "v"(L.kaddr[1]), [ka2] "v"(L.kaddr[2]), [ka3] "v"(L.kaddr[3]),
+          [va0] "v"(L.vaddr[0]), [va1] "v"(L.vaddr[1])
+#ifdef W48_STAMPS
+          , [dbg] "s"(dbg)
+#endif
+        :
+#include "attention_w48_clobbers.inc"
+    );
+    (void)smem;
+}
+
 }  // namespace
 
 void launch_attention(const AttnArgs& a, hipStream_t stream) {
@@ -505,13 +689,16 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
         attr_set = true;
     }
     ProfScope prof(PROF_ATTN, 4.0 * a.B * a.H * (double)a.Tq * a.Tk * 128, stream);
-    // Kernel choice by grid fill (tile-step costs measured on MI355X at T=6144: 2.3 us with two 128-query workgroups on a CU,
-    // 1.5 us with one, 2.18 us for one 256-query ping-pong workgroup): the launch lasts as long as its fullest CU.
-    //   T=1536, B=1: 384 workgroups = 128 CUs with two + 128 with one (2.3)  vs 192 ping-pong workgroups (2.18)  -> ping-pong
-    //   T=1536, B=2: 768 = one full round + one single round (2.3 + 1.5)     vs 384 = two rounds (4.36)           -> 4-wave
-    //   T=6144:      1536 = three full rounds (6.9)                          vs 768 = three rounds (6.54)         -> ping-pong
-    // The masked variant stays on the 4-wave kernel (its per-key bias loads sit in the softmax phase, measured slower).
-    // LTX_ATTN_IMPL=1 / 2 force the 4-wave / ping-pong kernel (same-process A/B runs).
+    // Kernel choice by grid fill. Tile-step costs measured on MI355X at T=6144: 2.3 us with two 128-query workgroups on a CU,
+    // 1.5 us with one; 2.18 us for one 256-query ping-pong workgroup; 1.45 us for one 192-query workgroup of the 48-query
+    // assembly kernel. The launch lasts as long as its fullest CU:
+    //   T=1536, B=1: 384 4-wave workgroups (2.3) | 192 ping-pong (2.18) | 256 x 192-query (1.45)     -> assembly (46 vs 57 / 63 us)
+    //   T=1536, B=2: 768 (2.3 + 1.5)             | 384 (4.36)           | 512 (2.9)                   -> assembly (86 vs 113 / 100 us)
+    //   T=6144:      1536 (6.9)                  | 768 (6.54)           | 1024 (5.8)                  -> assembly (532 vs 625 / 643 us)
+    // The assembly kernel takes unmasked launches with Tq % 192 == 0 and Tk % 256 == 0 (the DiT's self- and cross-attention at
+    // every BASELINE configuration); masked launches stay on the 4-wave kernel (its per-key bias loads sit in the softmax phase
+    // of the ping-pong kernel, measured slower). LTX_ATTN_IMPL=1 / 2 / 4 force the 4-wave / ping-pong / assembly kernel, 3 the
+    // plain-HIP layout reference of the assembly kernel (same-process A/B runs).
     {
         const long wg4 = (long)((a.Tq + 127) / 128) * a.H * a.B;
         const long rem4 = wg4 % 512;
@@ -519,7 +706,35 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
         const long wgpp = (long)((a.Tq + PP_Q - 1) / PP_Q) * a.H * a.B;
         const double costpp = (double)((wgpp + 255) / 256) * 2.18;
         const char* impl = getenv("LTX_ATTN_IMPL");
-        const bool use_pp = (impl && impl[0] == '2') ? true : ((impl && impl[0] == '1') ? false : (!a.bias && costpp < cost4));
+        const bool forced = impl && impl[0] >= '1' && impl[0] <= '4';
+        bool use_pp = forced ? impl[0] == '2' : (!a.bias && costpp < cost4);
+        // the 48-query kernels cover unmasked launches whose query count is a multiple of 192 and key count a multiple of 256
+        const bool w48_ok = !a.bias && a.Tq % W48_Q == 0 && a.Tk % (4 * KV_TILE) == 0;
+        if (impl && impl[0] == '3') {
+            LTX_REQUIRE(w48_ok, "attention: LTX_ATTN_IMPL=3 needs Tq %% 192 == 0, Tk %% 256 == 0 and no mask (Tq=%d Tk=%d)", a.Tq, a.Tk);
+            static bool attr3_set = false;
+            if (!attr3_set) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_ref, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
+                attr3_set = true;
+            }
+            hipLaunchKernelGGL(attn_fwd_kernel_w48_ref, dim3(a.Tq / W48_Q, a.H, a.B), dim3(256), W48_LDS, stream, a);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+        const long wg48 = (long)(a.Tq / W48_Q) * a.H * a.B;
+        const double cost48 = (double)((wg48 + 255) / 256) * 1.45;
+        const bool use_asm = forced ? impl[0] == '4' : (w48_ok && cost48 < cost4 && cost48 < costpp);
+        if (use_asm) {
+            LTX_REQUIRE(w48_ok, "attention: LTX_ATTN_IMPL=4 needs Tq %% 192 == 0, Tk %% 256 == 0 and no mask (Tq=%d Tk=%d)", a.Tq, a.Tk);
+            static bool attr4_set = false;
+            if (!attr4_set) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
+                attr4_set = true;
+            }
+            hipLaunchKernelGGL(attn_fwd_kernel_w48_asm, dim3(a.Tq / W48_Q, a.H, a.B), dim3(256), W48_LDS, stream, a);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         if (use_pp) {
             static bool attr2_set = false;
             if (!attr2_set) {

@@ -211,6 +211,101 @@ def test_attention_late_maximum(gpu_ctx):
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-2
 
 
+@pytest.fixture
+def attn_impl(monkeypatch):
+    """Force one attention kernel through the launcher's A/B switch (LTX_ATTN_IMPL: 1 = 4-wave, 2 = ping-pong, 3 = plain-HIP layout
+    reference of the 48-query kernel, 4 = its assembly main loop; unset = the launcher's grid-fill choice)."""
+    def force(impl):
+        if impl is None:
+            monkeypatch.delenv("LTX_ATTN_IMPL", raising=False)
+        else:
+            monkeypatch.setenv("LTX_ATTN_IMPL", str(impl))
+    return force
+
+
+def _attn_inputs(rng, B, H, Tq, Tk, q=None, k=None, v=None):
+    D = H * 128
+    q = rng.standard_normal((B, Tq, D)).astype(np.float32) if q is None else q
+    k = rng.standard_normal((B, Tk, D)).astype(np.float32) if k is None else k
+    v = rng.standard_normal((B, Tk, D)).astype(np.float32) if v is None else v
+    qd, kd, vd = dev_bf16(q), dev_bf16(k), dev_bf16(v)
+    ldvt = ((Tk + 63) // 64) * 64
+    vt = torch.zeros((B, D, ldvt), device="cuda", dtype=torch.bfloat16)
+    vt[:, :, :Tk] = vd.transpose(1, 2)
+    return qd, kd, vd, vt
+
+
+@pytest.mark.parametrize("impl", [1, 2, 3, 4, None])
+@pytest.mark.parametrize("B,H,Tq,Tk", [(1, 2, 192, 256), (2, 3, 384, 512), (1, 4, 1536, 1024), (1, 1, 576, 1536)])
+def test_attention_every_kernel_vs_f32(gpu_ctx, attn_impl, impl, B, H, Tq, Tk):
+    """Shapes every kernel takes (Tq % 192 == 0, Tk % 256 == 0, no mask): each of them against the f32 reference, same bounds as
+    test_attention_vs_f32. The assembly kernel normalises P by a reference maximum that is raised only when a score exceeds it by
+    2^8 - a different rounding of the bf16 P than the running-maximum kernels, not a different result."""
+    attn_impl(impl)
+    rng = np.random.default_rng(B * 7 + H + Tq + Tk)
+    qd, kd, vd, vt = _attn_inputs(rng, B, H, Tq, Tk)
+    o = torch.empty((B, Tq, H * 128), device="cuda", dtype=torch.bfloat16)
+    scale = 1.0 / math.sqrt(128.0)
+    gpu_ctx.op_attention(qd, kd, vt, None, H, o, scale)
+    torch.cuda.synchronize()
+    ref = _attn_ref(qd.float().cpu(), kd.float().cpu(), vd.float().cpu(), H, None, scale).numpy()
+    got = as_f32(o)
+    assert np.abs(got - ref).max() <= 2e-2
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-2
+
+
+@pytest.mark.parametrize("impl", [1, 2, 4])
+def test_attention_reference_maximum_stress(gpu_ctx, attn_impl, impl):
+    """The assembly kernel's rare path under stress, the other kernels beside it: key magnitudes grow with the key index (the
+    maximum moves in every tile, by more than the 2^8 threshold several times), every third query has flat scores (its reference
+    settles in the first tile and must never be rescaled wrongly), and one query block sees a single huge late key (delta)."""
+    attn_impl(impl)
+    B, H, Tq, Tk = 1, 2, 384, 768
+    D = H * 128
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((B, Tq, D)).astype(np.float32)
+    k = rng.standard_normal((B, Tk, D)).astype(np.float32)
+    k *= np.linspace(0.2, 6.0, Tk).astype(np.float32)[None, :, None]
+    q[:, ::3] *= 0.05
+    k[0, 700] = 0.0
+    k[0, 700, :128] = q[0, 17, :128] * 4.0  # head 0, query 17: one dominant key in the last tiles
+    qd, kd, vd, vt = _attn_inputs(rng, B, H, Tq, Tk, q=q, k=k)
+    o = torch.empty((B, Tq, D), device="cuda", dtype=torch.bfloat16)
+    scale = 1.0 / math.sqrt(128.0)
+    gpu_ctx.op_attention(qd, kd, vt, None, H, o, scale)
+    torch.cuda.synchronize()
+    ref = _attn_ref(qd.float().cpu(), kd.float().cpu(), vd.float().cpu(), H, None, scale).numpy()
+    got = as_f32(o)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 3e-2
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-2
+
+
+@pytest.mark.parametrize("impl", [3, 4])
+def test_attention_integer_layout_48_query_kernels(gpu_ctx, attn_impl, impl):
+    """Delta softmax pins the 16x16x32 key permutation, both swizzles and the O store of the 48-query kernels: O must equal the
+    selected key's V row exactly (integer V, bf16-exact)."""
+    attn_impl(impl)
+    B, H, Tq, Tk = 1, 2, 192, 512
+    D = H * 128
+    rng = np.random.default_rng(0)
+    sel = rng.integers(0, Tk, (H, Tq))
+    q = np.zeros((B, Tq, D), np.float32)
+    k = np.zeros((B, Tk, D), np.float32)
+    codes = rng.choice([-1.0, 1.0], (H, Tk, 128)).astype(np.float32)
+    for h in range(H):
+        k[0, :, h * 128:(h + 1) * 128] = codes[h]
+        q[0, :, h * 128:(h + 1) * 128] = codes[h][sel[h]] * 8.0
+    v = rng.integers(-8, 9, (B, Tk, D)).astype(np.float32)
+    qd, kd, vd, vt = _attn_inputs(rng, B, H, Tq, Tk, q=q, k=k, v=v)
+    o = torch.empty((B, Tq, D), device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_attention(qd, kd, vt, None, H, o, 1.0 / math.sqrt(128.0))
+    torch.cuda.synchronize()
+    got = as_f32(o)
+    for h in range(H):
+        assert np.abs(got[0, :, h * 128:(h + 1) * 128] - v[0, sel[h], h * 128:(h + 1) * 128]).max() <= 1e-2
+
+
 def test_attention_integer_layout(gpu_ctx):
     """One-hot style check that pins the key permutation / Vt layout exactly: with q.k = big for exactly one key per
     query, softmax is a delta and O must equal that key's V row (bf16-exact)."""

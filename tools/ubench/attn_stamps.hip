@@ -1,6 +1,6 @@
 // attn_stamps.hip - cycle stamps at the phase boundaries of the ping-pong attention kernel (one steady-state tile step of one
 // workgroup, wave 0 = group 0 and wave 4 = group 1, both on SIMD 0). Build from the repo root:
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DPP_STAMPS -Iinclude -Iltx-video-swift-mlx_amd/csrc -o tools/ubench/attn_stamps tools/ubench/attn_stamps.hip
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DPP_STAMPS (ping-pong kernel) or -DW48_STAMPS (48-query assembly kernel) -Iinclude -Iltx-video-swift-mlx_amd/csrc -o tools/ubench/attn_stamps tools/ubench/attn_stamps.hip
 #include "../../ltx-video-swift-mlx_amd/csrc/attention.hip"
 
 // the kernel launcher's profiling hooks (runtime.cpp) are not linked into this harness
@@ -9,6 +9,7 @@ ProfRec* Profiler::begin(int, double, hipStream_t) { return nullptr; }
 void Profiler::end(ProfRec*, hipStream_t) {}
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 int main() {
@@ -23,6 +24,22 @@ int main() {
     AttnArgs a;
     a.Q = q; a.ldq = D; a.K = k; a.ldk = D; a.Vt = vt; a.ldvt = T; a.O = o; a.ldo = D;
     a.B = 1; a.H = H; a.Tq = T; a.Tk = T;
+#ifdef W48_STAMPS
+    setenv("LTX_ATTN_IMPL", "4", 1);
+    for (int it = 0; it < 3; ++it) launch_attention(a, 0);
+    hipDeviceSynchronize();
+    {
+        unsigned long long st[8][8];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_w48_stamps), sizeof(st));
+        printf("48-query assembly kernel, one tile step (ring slot 0 of the last loop iteration), cycles:\n");
+        printf("wave | maxima (6 MFMA)  reference check  exp+pack (42 MFMA) + PV + DMA  vmcnt+barrier | step\n");
+        for (int w = 0; w < 4; ++w)
+            printf("  %d  | %8llu %16llu %14llu %16llu       | %llu\n", w, st[w][1] - st[w][0], st[w][2] - st[w][1], st[w][3] - st[w][2],
+                   st[w][4] - st[w][3], st[w][4] - st[w][0]);
+        return 0;
+    }
+#endif
+#ifdef PP_STAMPS
     for (int it = 0; it < 3; ++it) launch_attention(a, 0);
     hipDeviceSynchronize();
     unsigned long long st[8][8];
@@ -34,5 +51,6 @@ int main() {
         printf("  %d   %d   | %7lld %5llu %7llu %5llu %5llu %6llu | %5llu\n", w, (hw >> 4) & 3, (long long)(st[w][0] - t0), st[w][1] - st[w][0],
                st[w][2] - st[w][1], st[w][3] - st[w][2], st[w][4] - st[w][3], st[w][5] - st[w][4], st[w][5] - st[w][0]);
     }
+#endif
     return 0;
 }
