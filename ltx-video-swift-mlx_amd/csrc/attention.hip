@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     const uint32_t nt4 = (uint32_t)(a.Tk / (4 * KV_TILE));
     const float c = a.scale * 1.4426950408889634f;
     const uint32_t wlds = (uint32_t)wave * 1024u;
-    const float tauc = 8.0f / c;  // rescale threshold in score units: a score more than 2^8 (after the scale) above the reference
+    const float tau = 8.0f / c;  // raw-score threshold: the reference maximum of a query is raised only when exp2((s - ref)*c) > 2^8
 #ifdef W48_STAMPS  // tools/ubench/attn_stamps.hip: per-wave s_memtime stamps of one tile step -> g_w48_stamps[wave][5]
     unsigned long long* dbg = (blockIdx.x == 1 && blockIdx.y == 3) ? &g_w48_stamps[wave][0] : &g_w48_stamps[4 + (wave & 3)][0];
 #endif
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
 #endif
         :
         : [qbase] "s"(Qb), [obase] "s"(Ob), [kblo] "s"(kblo), [kbhi] "s"(kbhi), [vblo] "s"(vblo), [vbhi] "s"(vbhi), [krec] "s"(krec),
-          [vrec] "s"(vrec), [ktb] "s"(ktb), [nt4] "s"(nt4), [c] "s"(c), [tauc] "s"(tauc), [wlds] "s"(wlds), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]),
+          [vrec] "s"(vrec), [ktb] "s"(ktb), [nt4] "s"(nt4), [c] "s"(c), [tau] "s"(tau), [wlds] "s"(wlds), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]),
           [qo2] "v"(qo[2]), [oo0] "v"(oo[0]), [oo1] "v"(oo[1]), [oo2] "v"(oo[2]), [ko0] "v"(L.koff[0]), [ko1] "v"(L.koff[1]),
           [ko2] "v"(L.koff[2]), [ko3] "v"(L.koff[3]), [vo0] "v"(L.voff[0]), [vo1] "v"(L.voff[1]), [vo2] "v"(L.voff[2]),
           [vo3] "v"(L.voff[3]), [ka0] "v"(L.kaddr[0]), [ka1] "v"(L.kaddr[1]), [ka2] "v"(L.kaddr[2]), [ka3] "v"(L.kaddr[3]),
@@ -690,11 +690,11 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
     }
     ProfScope prof(PROF_ATTN, 4.0 * a.B * a.H * (double)a.Tq * a.Tk * 128, stream);
     // Kernel choice by grid fill. Tile-step costs measured on MI355X at T=6144: 2.3 us with two 128-query workgroups on a CU,
-    // 1.5 us with one; 2.18 us for one 256-query ping-pong workgroup; 1.45 us for one 192-query workgroup of the 48-query
+    // 1.5 us with one; 2.18 us for one 256-query ping-pong workgroup; 1.25 us for one 192-query workgroup of the 48-query
     // assembly kernel. The launch lasts as long as its fullest CU:
-    //   T=1536, B=1: 384 4-wave workgroups (2.3) | 192 ping-pong (2.18) | 256 x 192-query (1.45)     -> assembly (46 vs 57 / 63 us)
-    //   T=1536, B=2: 768 (2.3 + 1.5)             | 384 (4.36)           | 512 (2.9)                   -> assembly (86 vs 113 / 100 us)
-    //   T=6144:      1536 (6.9)                  | 768 (6.54)           | 1024 (5.8)                  -> assembly (532 vs 625 / 643 us)
+    //   T=1536, B=1: 384 4-wave workgroups (2.3) | 192 ping-pong (2.18) | 256 x 192-query (1.25)     -> assembly (42 vs 59 / 65 us)
+    //   T=1536, B=2: 768 (2.3 + 1.5)             | 384 (4.36)           | 512 (2.5)                   -> assembly (82 vs 114 / 100 us)
+    //   T=6144:      1536 (6.9)                  | 768 (6.54)           | 1024 (5.0)                  -> assembly (491 vs 641 / 658 us)
     // The assembly kernel takes unmasked launches with Tq % 192 == 0 and Tk % 256 == 0 (the DiT's self- and cross-attention at
     // every BASELINE configuration); masked launches stay on the 4-wave kernel (its per-key bias loads sit in the softmax phase
     // of the ping-pong kernel, measured slower). LTX_ATTN_IMPL=1 / 2 / 4 force the 4-wave / ping-pong / assembly kernel, 3 the
@@ -722,7 +722,7 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
             return;
         }
         const long wg48 = (long)(a.Tq / W48_Q) * a.H * a.B;
-        const double cost48 = (double)((wg48 + 255) / 256) * 1.45;
+        const double cost48 = (double)((wg48 + 255) / 256) * 1.25;
         const bool use_asm = forced ? impl[0] == '4' : (w48_ok && cost48 < cost4 && cost48 < costpp);
         if (use_asm) {
             LTX_REQUIRE(w48_ok, "attention: LTX_ATTN_IMPL=4 needs Tq %% 192 == 0, Tk %% 256 == 0 and no mask (Tq=%d Tk=%d)", a.Tq, a.Tk);

@@ -12,18 +12,26 @@ Register map (per wave):
   v[48:95]    S buffer A   s[kb][qb] (4 each)    s[36:39]  K buffer descriptor      s[40:43] Vt buffer descriptor
   v[96:143]   S buffer B                         s44 / s45 K / Vt scalar offset of the next tile to stage
   v[144:167]  P fragments  pf[qb][i]             s46       loop counter (groups of 4 tiles)
-  v[168:183]  fragment ring (4 x 4)              s[48:53]  compare masks of the rescale test
-  v[184:207]  softmax temporaries (8 per query block)
-  v[208:219]  m_ref[3], m_thr[3], -m_ref*c [3], l[3]   v[220:225] fragment addresses + 64 KB (ring slots 2, 3)
+  v[168:183]  fragment ring (4 x 4)              s[48:53]  compare masks of the reference check
+  v[184:186]  per-lane maxima, v[187:194] rare-path temporaries, v195 floor, v[196:199] bf16 ones
+  v[200:211]  -(reference max) per query block (x4: accumulator init of K.Q^T)        a[96:107] row sums l[qb]
+  v[212:217]  fragment addresses + 64 KB (ring slots 2, 3)
 Operands (compiler-assigned): see the asm statement in attention.hip.
 """
 import os
 
-QF, SA, SB, PF, RING, TMP = 0, 48, 96, 144, 168, 184
-MREF, MTHR, NMC, LRUN, HI = 208, 211, 214, 217, 220   # per query block: reference max, rescale threshold, -m_ref*c, row-sum partial
-TAU = 8.0  # rescale only when a score exceeds the reference maximum by more than 2^TAU (after the scale): P stays <= 256
+QF, SA, SB, PF, RING = 0, 48, 96, 144, 168
+MAXR = 184        # v184..186: this lane's maximum of each query block's scores (phase 1)
+RT = 187          # v187..194: temporaries of the rare path and the prologue / epilogue
+FLOOR = 195       # lower bound of the reference raise: -inf until the first tile set the reference, 0 afterwards
+ONES = 196        # v[196:199]: bf16 ones, the A operand that makes the PV product also produce the row sums
+NMCT = (200, 204, 208)  # per query block: -(reference maximum) in all four registers = accumulator init of the QK product
+HI = 212          # v[212:217] fragment addresses + 64 KB (ring slots 2, 3)
+NV = 220          # v0..v219 are assigned here; the compiler places the operands above
+LACC = 96         # a[96:107]: row sums l[qb] (every register of a tuple holds the same value)
+TAU = 8.0         # raise the reference only when a score exceeds it by more than 2^TAU: P stays <= 256
 STAGE = 32768
-RA = 3  # fragment reads in flight ahead of their MFMAs
+RA = 3  # fragment reads in flight ahead of their MFMAs (ring of 4 fragment registers)
 
 
 def vr(base, n=4):
@@ -45,6 +53,9 @@ def kblock_off(kb):
 
 def vblock_off(db):
     return db * 16 * 128
+
+
+ABL = set(os.environ.get("W48_ABLATE", "").split(","))  # timing experiments only (wrong results): nodma, noexp, nords, ra6
 
 
 class Gen:
@@ -72,7 +83,8 @@ class Gen:
 
     # ---- MFMA streams: list of groups, each group = [pre-instructions..., 3 MFMAs] per fragment ----
     def qk_stream(self, sbuf, slot):
-        """S(next) = K Q^T from ring slot `slot` into S buffer `sbuf`. Returns a list of (kind, text)."""
+        """S(next) = K Q^T from ring slot `slot` into S buffer `sbuf`. Returns a list of (kind, text); the first RA entries are
+        the fragment reads issued ahead."""
         out = []
         frags = [(kb, ks) for kb in range(4) for ks in range(4)]
         issued = 0
@@ -83,7 +95,7 @@ class Gen:
             out.append(("wait", f"s_waitcnt lgkmcnt({issued - f - 1})"))
             for qb in range(3):
                 d = vr(s_reg(sbuf, kb, qb))
-                c = "0" if ks == 0 else d
+                c = vr(NMCT[qb]) if ks == 0 else d   # scores arrive as q.k - m_ref: the accumulators start at -m_ref
                 out.append(("mfma", f"v_mfma_f32_16x16x32_bf16 {d}, {vr(RING + 4 * (f % 4))}, {vr(QF + (qb * 4 + ks) * 4)}, {c}"))
             if f + RA < 16:
                 out.append(("ds", self.k_read((f + RA) % 4, slot, *frags[f + RA])))
@@ -92,7 +104,7 @@ class Gen:
 
     def pv_stream(self, slot):
         out = []
-        frags = [(db, i) for db in range(8) for i in range(2)]
+        frags = [(db, i) for i in range(2) for db in range(8)]  # k-step 0 of every d-block first: it only needs pf[.][0]
         issued = 0
         for f in range(RA):
             out.append(("ds", self.v_read(f % 4, slot, *frags[f])))
@@ -105,19 +117,26 @@ class Gen:
             if f + RA < 16:
                 out.append(("ds", self.v_read((f + RA) % 4, slot, *frags[f + RA])))
                 issued += 1
+            if db == 7:  # end of a k-step: the same P against a block of ones = this k-step's row sums
+                for qb in range(3):
+                    a = f"a[{LACC + 4 * qb}:{LACC + 4 * qb + 3}]"
+                    out.append(("mfma", f"v_mfma_f32_16x16x32_bf16 {a}, {vr(ONES)}, {vr(PF + (qb * 2 + i) * 4)}, {a}"))
         return out
 
     # ---- softmax of one S buffer (in place) ----
-    # The O rescale costs 288 instructions for a wave's 96 accumulator registers (AGPR -> VGPR -> multiply -> AGPR), and with 48
-    # queries per wave SOME query's maximum moves in nearly every tile. So the running maximum is replaced by a REFERENCE maximum
-    # m_ref per query that is only raised when a score exceeds it by more than TAU (in exp2 units): P = exp2(s*c - m_ref*c) then
-    # stays <= 2^TAU, l accumulates against the same reference, and the common path needs no alpha, no cross-lane reduction and
-    # no rescale. The rare path (always taken on the first tile, m_ref = -inf) updates every query to its true running maximum.
+    # Scores arrive from the QK MFMAs already as s' = q.k - m_ref (raw score units relative to a REFERENCE maximum per query: the
+    # accumulators start at -m_ref; the products stay exact, the scale c = scale*log2(e) is one v_mul before the exp). Pre-scaling Q
+    # by c would save those 48 multiplies per tile but rounds q*c to bf16 a second time: 2-4 % error in P once |s*c| reaches ~30
+    # (seen in test_attention_reference_maximum_stress) - not taken. The O rescale costs ~300 instructions for a wave's 96
+    # accumulator registers (AGPR -> VGPR -> multiply -> AGPR), and with 48 queries per wave SOME query's maximum moves in nearly
+    # every tile; so the reference is only raised when a score exceeds it by more than 2^TAU (after the scale): P = exp2(s'*c)
+    # <= 2^TAU, l (a row of ones in the PV product) accumulates against the same reference, and the common path is 24 v_max3 + 3
+    # compares, 48 v_mul, 48 v_exp and 24 v_cvt_pk per tile - no row-sum adds, no cross-lane reduction, no rescale.
     def sm_max(self, sbuf):
         """Phase 1: per-lane maximum of each query block's 16 scores and the wave-wide 'exceeds threshold' masks."""
         lists = []
         for qb in range(3):
-            t = TMP + 8 * qb
+            t = MAXR + qb
             vals = [s_reg(sbuf, kb, qb, j) for kb in range(4) for j in range(4)]
             out = [f"v_max3_f32 v{t}, v{vals[0]}, v{vals[1]}, v{vals[2]}"]
             k = 3
@@ -128,41 +147,32 @@ class Gen:
                 else:
                     out.append(f"v_max_f32 v{t}, v{t}, v{vals[k]}")
                     k += 1
-            out.append(f"v_cmp_gt_f32_e64 s[{48 + 2 * qb}:{49 + 2 * qb}], v{t}, v{MTHR + qb}")
+            out.append(f"v_cmp_gt_f32_e64 s[{48 + 2 * qb}:{49 + 2 * qb}], v{t}, %[tau]")   # 8.0 is not an inline constant
             lists.append(out)
         return [x[k] for k in range(len(lists[0])) for x in lists]
 
-    def sm_exp(self, sbuf):
-        """Phase 2: P = exp2(s*c - m_ref*c), row-sum partials, bf16 pack into the PV product's B operand."""
+    def sm_exp(self, sbuf, half):
+        """Phase 2 for key blocks 2*half, 2*half+1 (= k-step `half` of the PV product): P = exp2(s' * c), bf16 pack into pf[qb][half]."""
         lists = []
         for qb in range(3):
-            t = TMP + 8 * qb
-            vals = [s_reg(sbuf, kb, qb, j) for kb in range(4) for j in range(4)]
+            tup = [s_reg(sbuf, 2 * half + hh, qb) for hh in range(2)]
             out = []
-            for v in vals:
-                out.append(f"v_fma_f32 v{v}, v{v}, %[c], v{NMC + qb}")
-            for v in vals:
-                out.append(f"v_exp_f32 v{v}, v{v}")
-            tup = [s_reg(sbuf, kb, qb) for kb in range(4)]
-            out.append(f"v_pk_add_f32 v[{t + 4}:{t + 5}], v[{tup[0]}:{tup[0] + 1}], v[{tup[0] + 2}:{tup[0] + 3}]")
-            for b in tup[1:]:
-                out.append(f"v_pk_add_f32 v[{t + 4}:{t + 5}], v[{t + 4}:{t + 5}], v[{b}:{b + 1}]")
-                out.append(f"v_pk_add_f32 v[{t + 4}:{t + 5}], v[{t + 4}:{t + 5}], v[{b + 2}:{b + 3}]")
-            out.append(f"v_add_f32 v{t + 4}, v{t + 4}, v{t + 5}")
-            out.append(f"v_add_f32 v{LRUN + qb}, v{LRUN + qb}, v{t + 4}")
-            # k-step i = key blocks 2i (low 4 values) and 2i+1 (high 4)
-            for i in range(2):
-                p = PF + (qb * 2 + i) * 4
-                for hh in range(2):
-                    b = s_reg(sbuf, 2 * i + hh, qb)
-                    out.append(f"v_cvt_pk_bf16_f32 v{p + 2 * hh}, v{b}, v{b + 1}")
-                    out.append(f"v_cvt_pk_bf16_f32 v{p + 2 * hh + 1}, v{b + 2}, v{b + 3}")
+            for b in tup:
+                for j in range(4):
+                    out.append(f"v_mul_f32 v{b + j}, %[c], v{b + j}")
+            for b in tup:
+                for j in range(4):
+                    out.append(f"v_exp_f32 v{b + j}, v{b + j}")
+            p = PF + (qb * 2 + half) * 4
+            for hh, b in enumerate(tup):
+                out.append(f"v_cvt_pk_bf16_f32 v{p + 2 * hh}, v{b}, v{b + 1}")
+                out.append(f"v_cvt_pk_bf16_f32 v{p + 2 * hh + 1}, v{b + 2}, v{b + 3}")
             lists.append(out)
         return [x[k] for k in range(len(lists[0])) for x in lists]
 
-    def sm_check_and_rare_path(self, label):
-        """After phase 1: if any lane saw a score above its threshold, raise every query's reference to its running maximum and
-        rescale l and O accordingly (v{TMP+8qb} holds the lane's maximum of this tile)."""
+    def sm_check_and_rare_path(self, label, sbuf):
+        """After phase 1 on `sbuf`: if any lane saw a score above the threshold, raise every query's reference to its running
+        maximum: delta = max(row maximum, floor) in shifted units; S' -= delta, accumulator init -= delta, O and l *= 2^-delta."""
         e = self.e
         e("s_nop 3")
         e("s_or_b64 s[48:49], s[48:49], s[50:51]")
@@ -170,34 +180,35 @@ class Gen:
         e("s_cmp_lg_u64 s[48:49], 0")
         e(f"s_cbranch_scc0 {label}f")
         for qb in range(3):
-            t = TMP + 8 * qb
+            t = MAXR + qb
             for swap in ("v_permlane16_swap_b32", "v_permlane32_swap_b32"):  # maximum over the four lanes of a query
-                e(f"v_mov_b32 v{t + 1}, v{t}")
+                e(f"v_mov_b32 v{RT}, v{t}")
                 e("s_nop 1")
-                e(f"{swap} v{t}, v{t + 1}")
+                e(f"{swap} v{t}, v{RT}")
                 e("s_nop 1")
-                e(f"v_max_f32 v{t}, v{t}, v{t + 1}")
-            e(f"v_max_f32 v{t + 2}, v{MREF + qb}, v{t}")            # new reference = running maximum
-            e(f"v_sub_f32 v{t + 3}, v{MREF + qb}, v{t + 2}")        # <= 0, -inf on the first tile
-            e(f"v_mul_f32 v{t + 3}, %[c], v{t + 3}")
-            e(f"v_exp_f32 v{t + 3}, v{t + 3}")                        # alpha
-            e(f"v_mov_b32 v{MREF + qb}, v{t + 2}")
-            e(f"v_add_f32 v{MTHR + qb}, %[tauc], v{t + 2}")          # threshold = reference + TAU / c
-            e(f"v_mul_f32 v{NMC + qb}, %[c], v{t + 2}")
-            e(f"v_sub_f32 v{NMC + qb}, 0, v{NMC + qb}")              # -m_ref * c
-            e(f"v_mul_f32 v{LRUN + qb}, v{LRUN + qb}, v{t + 3}")
+                e(f"v_max_f32 v{t}, v{t}, v{RT}")
+            e(f"v_max_f32 v{RT + 1}, v{t}, v{FLOOR}")             # delta
+            e(f"v_mul_f32 v{RT + 2}, %[c], v{RT + 1}")
+            e(f"v_sub_f32 v{RT + 2}, 0, v{RT + 2}")
+            e(f"v_exp_f32 v{RT + 2}, v{RT + 2}")                   # alpha = 2^(-delta*c)
+            for j in range(4):
+                e(f"v_sub_f32 v{NMCT[qb] + j}, v{NMCT[qb] + j}, v{RT + 1}")
+            for kb in range(4):
+                for j in range(4):
+                    r = s_reg(sbuf, kb, qb, j)
+                    e(f"v_sub_f32 v{r}, v{r}, v{RT + 1}")
             e("s_nop 7")
             e("s_nop 7")
-            for db in range(8):
-                a = o_reg(db, qb)
+            for a in [o_reg(db, qb) for db in range(8)] + [LACC + 4 * qb]:
                 for j in range(4):
-                    e(f"v_accvgpr_read_b32 v{t + 4 + j}, a{a + j}")
+                    e(f"v_accvgpr_read_b32 v{RT + 4 + j}, a{a + j}")
                 e("s_nop 1")
                 for j in range(4):
-                    e(f"v_mul_f32 v{t + 4 + j}, v{t + 4 + j}, v{t + 3}")
+                    e(f"v_mul_f32 v{RT + 4 + j}, v{RT + 4 + j}, v{RT + 2}")
                 e("s_nop 1")
                 for j in range(4):
-                    e(f"v_accvgpr_write_b32 a{a + j}, v{t + 4 + j}")
+                    e(f"v_accvgpr_write_b32 a{a + j}, v{RT + 4 + j}")
+        e(f"v_mov_b32 v{FLOOR}, 0")
         e("s_nop 7")
         e(f"{label}:")
 
@@ -205,6 +216,8 @@ class Gen:
         """Emit (part of) an MFMA stream with `per_mfma` instructions of `valu` after every MFMA; leftovers at the end."""
         vi = 0
         for kind, text in stream:
+            if "nords" in ABL and kind in ("ds", "wait"):
+                continue
             self.e(text)
             if kind == "mfma":
                 for _ in range(per_mfma):
@@ -214,6 +227,25 @@ class Gen:
         while vi < len(valu):
             self.e(valu[vi])
             vi += 1
+
+    def spread(self, stream, groups, over):
+        """Emit an MFMA stream with the instruction groups spread evenly behind its first `over` MFMAs (leftovers at the end)."""
+        gi, nm = 0, 0
+        for kind, text in stream:
+            if "nords" in ABL and kind in ("ds", "wait"):
+                continue
+            self.e(text)
+            if kind == "mfma":
+                nm += 1
+                want = (len(groups) * nm + over - 1) // over if nm <= over else len(groups)
+                while gi < min(want, len(groups)):
+                    for ins in groups[gi]:
+                        self.e(ins)
+                    gi += 1
+        while gi < len(groups):
+            for ins in groups[gi]:
+                self.e(ins)
+            gi += 1
 
     @staticmethod
     def split_stream(stream, n_mfma):
@@ -245,29 +277,37 @@ class Gen:
         self.e(f"; ---------------- tile step, ring slot {slot} ----------------")
         st = self.stamp if slot == 0 else (lambda i: None)
         st(0)
-        # part A: S(t+1) from slot+1; in the gaps first the per-lane maxima of S(t) + the (rarely taken) reference update,
-        # then the exponentials, row sums and the bf16 pack
+        # Entry state: S(t) in `cur`, already checked against the reference maxima (end of the previous step / prologue).
+        # part A : S(t+1) = K Q^T (48 MFMAs) with P(t) = exp2(S(t)*c - m_ref*c), row sums and the bf16 pack in the gaps, two VALU
+        #          instructions per MFMA (what a 4-pass MFMA hides, tools/ubench/valu_slots.hip)
+        # part B1: O += Vt P, k-step 0 of every d-block (24 MFMAs) with the rest of that VALU work (key blocks 2, 3 -> pf[.][1])
+        # part B2: k-step 1 (24 MFMAs) with the per-lane maxima of S(t+1) and the LDS-DMA of tile t+3 in the gaps
+        # then the reference check for S(t+1) (rare path: rescale O and l), counted vmcnt, barrier
+        va = [] if "noexp" in ABL else self.sm_exp(cur, 0)   # -> pf[.][0], needed by part B1
+        vb = [] if "noexp" in ABL else self.sm_exp(cur, 1)   # -> pf[.][1], needed by part B2
         qk = self.qk_stream(nxt, (slot + 1) & 3)
-        head, tail = self.split_stream(qk, 6)
-        self.interleave(head, self.sm_max(cur), 5)
-        st(1)
-        self.sm_check_and_rare_path(f"{uid}")
-        st(2)
-        self.interleave(tail, self.sm_exp(cur), 4)
-        # part B: O += Vt P with the LDS-DMA of tile t+3 in the gaps
-        dma = self.stage((slot + 3) & 3)
-        stream = self.pv_stream(slot)
-        nm = 0
-        for kind, text in stream:
+        for kind, text in qk[:RA]:
             self.e(text)
-            if kind == "mfma":
-                nm += 1
-                if nm % 6 == 3 and dma:
-                    for ins in dma.pop(0):
-                        self.e(ins)
-        for grp in dma:
-            for ins in grp:
-                self.e(ins)
+        npre = min(6, len(va))
+        for ins in va[:npre]:  # independent of the reads just issued: covers part of their latency
+            self.e(ins)
+        self.spread(qk[RA:], [[x] for x in va[npre:]], 44)
+        st(1)
+        pv = self.pv_stream(slot)
+        head, tail = self.split_stream(pv, 24)
+        self.spread(head, [[x] for x in vb], 22)
+        st(2)
+        dma = [] if "nodma" in ABL else self.stage((slot + 3) & 3)
+        mx = self.sm_max(nxt)
+        work = []  # B2 filler: alternate maxima instructions and DMA groups
+        while mx or dma:
+            for _ in range(4):
+                if mx:
+                    work.append([mx.pop(0)])
+            if dma:
+                work.append(dma.pop(0))
+        self.spread(tail, work, 26)
+        self.sm_check_and_rare_path(f"{uid}", nxt)
         self.advance_stage_offsets()
         st(3)
         self.e("s_waitcnt vmcnt(8)")
@@ -296,13 +336,14 @@ class Gen:
         for qb in range(3):
             for ks in range(4):
                 e(f"global_load_dwordx4 {vr(QF + (qb * 4 + ks) * 4)}, %[qo{qb}], %[qbase] offset:{ks * 64}")
-        for i in range(96):
+        for i in range(LACC + 12):
             e(f"v_accvgpr_write_b32 a{i}, 0")
         for qb in range(3):
-            e(f"v_mov_b32 v{MREF + qb}, 0xff800000")
-            e(f"v_mov_b32 v{MTHR + qb}, 0xff800000")
-            e(f"v_mov_b32 v{NMC + qb}, 0")
-            e(f"v_mov_b32 v{LRUN + qb}, 0")
+            for j in range(4):
+                e(f"v_mov_b32 v{NMCT[qb] + j}, 0")
+        e(f"v_mov_b32 v{FLOOR}, 0xff800000")
+        for j in range(4):
+            e(f"v_mov_b32 v{ONES + j}, 0x3f803f80")
         e("; ---- tiles 0, 1, 2 ----")
         for t in range(3):
             for grp in self.stage(t):
@@ -315,6 +356,9 @@ class Gen:
             e(text)
         e("s_nop 7")
         e("s_nop 7")
+        for ins in self.sm_max(SA):
+            e(ins)
+        self.sm_check_and_rare_path("9", SA)
         e("10:")
         self.step(0, SA, SB, 11)
         self.step(1, SB, SA, 12)
@@ -328,33 +372,27 @@ class Gen:
         e("s_nop 7")
         e("s_nop 7")
         for qb in range(3):
-            t = TMP + 8 * qb
-            e(f"v_mov_b32 v{t}, v{LRUN + qb}")
-            for swap in ("v_permlane16_swap_b32", "v_permlane32_swap_b32"):
-                e(f"v_mov_b32 v{t + 1}, v{t}")
-                e("s_nop 1")
-                e(f"{swap} v{t}, v{t + 1}")
-                e("s_nop 1")
-                e(f"v_add_f32 v{t}, v{t}, v{t + 1}")
-            e(f"v_rcp_f32 v{t}, v{t}")
+            e(f"v_accvgpr_read_b32 v{RT}, a{LACC + 4 * qb}")
+            e("s_nop 1")
+            e(f"v_rcp_f32 v{RT}, v{RT}")
             e("s_nop 1")
             for db in range(8):
                 a = o_reg(db, qb)
                 for j in range(4):
-                    e(f"v_accvgpr_read_b32 v{t + 2 + j}, a{a + j}")
+                    e(f"v_accvgpr_read_b32 v{RT + 1 + j}, a{a + j}")
                 e("s_nop 1")
                 for j in range(4):
-                    e(f"v_mul_f32 v{t + 2 + j}, v{t + 2 + j}, v{t}")
-                e(f"v_cvt_pk_bf16_f32 v{t + 6}, v{t + 2}, v{t + 3}")
-                e(f"v_cvt_pk_bf16_f32 v{t + 7}, v{t + 4}, v{t + 5}")
-                e(f"global_store_dwordx2 %[oo{qb}], v[{t + 6}:{t + 7}], %[obase] offset:{db * 32}")
+                    e(f"v_mul_f32 v{RT + 1 + j}, v{RT + 1 + j}, v{RT}")
+                e(f"v_cvt_pk_bf16_f32 v{RT + 5}, v{RT + 1}, v{RT + 2}")   # v[192:193]: 64-bit aligned store data
+                e(f"v_cvt_pk_bf16_f32 v{RT + 6}, v{RT + 3}, v{RT + 4}")
+                e(f"global_store_dwordx2 %[oo{qb}], v[{RT + 5}:{RT + 6}], %[obase] offset:{db * 32}")
         e("s_waitcnt vmcnt(0)")
         if self.stamps:  # lane 0 of every wave writes its 5 stamps: dbg[wave][5] u64
             for i in range(10):
-                e(f"v_mov_b32 v{TMP + i}, s{54 + i}")
-            e(f"v_mov_b32 v{TMP + 10}, 0")
+                e(f"v_mov_b32 v{PF + i}, s{54 + i}")
+            e(f"v_mov_b32 v{PF + 10}, 0")
             for i in range(5):
-                e(f"global_store_dwordx2 v{TMP + 10}, v[{TMP + 2 * i}:{TMP + 2 * i + 1}], %[dbg] offset:{i * 8}")
+                e(f"global_store_dwordx2 v{PF + 10}, v[{PF + 2 * i}:{PF + 2 * i + 1}], %[dbg] offset:{i * 8}")
             e("s_waitcnt vmcnt(0)")
         return self.lines
 
@@ -370,7 +408,7 @@ def main():
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. gfx950 assembly body of attn_fwd_kernel_w48_asm (attention.hip).\n")
         for ln in lines:
             f.write('"' + ln.replace('"', '\\"') + '\\n\\t"\n')
-    clob = [f"v{i}" for i in range(230)] + [f"a{i}" for i in range(96)] + [f"s{i}" for i in range(36, 64)] + ["m0", "vcc", "scc", "memory"]
+    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(LACC + 12)] + [f"s{i}" for i in range(36, 64)] + ["m0", "vcc", "scc", "memory"]
     with open(os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", "attention_w48_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. Registers the assembly body assigns by hand.\n")
         for i in range(0, len(clob), 12):

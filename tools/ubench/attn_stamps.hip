@@ -32,7 +32,7 @@ int main() {
         unsigned long long st[8][8];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(g_w48_stamps), sizeof(st));
         printf("48-query assembly kernel, one tile step (ring slot 0 of the last loop iteration), cycles:\n");
-        printf("wave | maxima (6 MFMA)  reference check  exp+pack (42 MFMA) + PV + DMA  vmcnt+barrier | step\n");
+        printf("wave | A: QK+exp/pack  B1: PV k-step 0 + pack  B2: PV k-step 1 + maxima + DMA + check  vmcnt+barrier | step\n");
         for (int w = 0; w < 4; ++w)
             printf("  %d  | %8llu %16llu %14llu %16llu       | %llu\n", w, st[w][1] - st[w][0], st[w][2] - st[w][1], st[w][3] - st[w][2],
                    st[w][4] - st[w][3], st[w][4] - st[w][0]);
