@@ -67,9 +67,11 @@ LTX_DEVFN void tile_coords(const GemmArgs& g, int bid, int tiles_m, int BN_, int
 }
 
 // ---- epilogue: per-wave LDS transpose (16 rows at a time), then 16-B row-contiguous global accesses ----
-template <int BM, int BN, int WGM = 2, int WGN = 2>
-LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const GemmArgs& g, int m0, int n0, int wr, int wc,
-                             int lane, int wave, char* smem) {
+// `get(mi_c, slab)` hands over the 16-row slab mi of this wave's accumulators (f32x4 slab[NI]) - an array copy for the kernels
+// that accumulate in VGPRs, an AGPR read-out for the assembly kernel (whose 192 accumulator registers must never be live in
+// VGPRs all at once next to this function's prefetch buffers).
+template <int BM, int BN, int WGM = 2, int WGN = 2, class Get>
+LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, int wr, int wc, int lane, int wave, char* smem) {
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
     float* scr = (float*)(smem + wave * (16 * WN * 4));
     constexpr int LPR = WN / 4;    // lanes per output row
@@ -111,10 +113,12 @@ LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const G
             constexpr int mi = decltype(mi_c)::value;
             constexpr int buf = mi & 1;
             if constexpr (mi + 1 < MI) prefetch(std::integral_constant<int, mi + 1>{}, std::integral_constant<int, (mi + 1) & 1>{});
+            f32x4 slab[NI];
+            get(mi_c, slab);
             static_for<0, NI>([&](auto ni_c) {
                 constexpr int ni = decltype(ni_c)::value;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = acc[mi][ni][r];
+                for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = slab[ni][r];
             });
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -144,7 +148,11 @@ LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const G
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = rs[buf][it][e] + gt[buf][it][e] * v[e];
                 }
+#ifdef EPI_NO_STORE  // tools/ubench/gemm_stamps.hip timing experiment
+                if (gm < 0) {
+#else
                 if (gm < g.M) {
+#endif
                     if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn_w + c4) = v;
                     if (ep.out_bf16) {
                         uint2 pk;
@@ -159,10 +167,12 @@ LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const G
     }
     static_for<0, MI>([&](auto mi_c) {
         constexpr int mi = decltype(mi_c)::value;
+        f32x4 slab[NI];
+        get(mi_c, slab);
         static_for<0, NI>([&](auto ni_c) {
             constexpr int ni = decltype(ni_c)::value;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = acc[mi][ni][r];
+            for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = slab[ni][r];
         });
 #pragma unroll
         for (int it = 0; it < (16 * LPR) / 64; ++it) {
@@ -268,6 +278,19 @@ LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const G
             }
         }
     });
+}
+
+template <int BM, int BN, int WGM = 2, int WGN = 2>
+LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const GemmArgs& g, int m0, int n0, int wr, int wc,
+                             int lane, int wave, char* smem) {
+    constexpr int NI = BN / WGN / 16;
+    gemm_epilogue_with<BM, BN, WGM, WGN>(
+        [&](auto mi_c, f32x4(&slab)[NI]) {
+            constexpr int mi = decltype(mi_c)::value;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) slab[ni] = acc[mi][ni];
+        },
+        g, m0, n0, wr, wc, lane, wave, smem);
 }
 
 template <int BM, int BN, bool CONV>
@@ -999,6 +1022,131 @@ void launch_one(const GemmArgs& a, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One wave per SIMD, assembly main loop (generated by tools/gen_gemm_asm.py; schedule and register map in that script's header).
+// Workgroup tile 192 x 256, four waves as 2 x 2 (96 x 128 per wave), dense A.B^T only, M % 192 == 0, N % 256 == 0, K % 64 == 0.
+// C++ prepares the per-lane offsets / LDS addresses (the ring kernel's LDS image) and runs the shared epilogue on the accumulators
+// the assembly leaves in a[0:191].
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef GEMM_ASM_STAMPS
+__device__ unsigned long long g_gemm_stamps[5][8];
+#endif
+__global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_asm(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 192, BN = 256, WGM = 2, WGN = 2, NW = 4;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
+    constexpr int A_BYTES = BM * ROW_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int tiles_m = g.M / BM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(g, bid, tiles_m, BN, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    // piece i of this wave = rows (wave + 4 i) * 8 .. +7 of the tile: the per-lane part of its address (row inside the piece, swizzled
+    // 16-byte column) does not depend on i ((row >> 1) & 7 is the same for rows 32 apart), the i part is a scalar offset
+    const int srow = lane >> 3, pch = lane & 7;
+    const int row0 = wave * 8 + srow;
+    const int ao = (row0 * (int)g.lda + ((pch ^ ((row0 >> 1) & 7)) << 3)) * 2;
+    const int bo = (row0 * (int)g.ldb + ((pch ^ ((row0 >> 1) & 7)) << 3)) * 2;
+    const uint32_t sa = (uint32_t)(32 * g.lda * 2), sb = (uint32_t)(32 * g.ldb * 2);
+    const bf16_t* At = g.A + (long)m0 * g.lda;
+    const bf16_t* Bt = g.B + (long)n0 * g.ldb;
+    const uint32_t alo = (uint32_t)(uintptr_t)At, ahi = (uint32_t)((uintptr_t)At >> 32);
+    const uint32_t blo = (uint32_t)(uintptr_t)Bt, bhi = (uint32_t)((uintptr_t)Bt >> 32);
+    const uint32_t arec = (uint32_t)(((long)(BM - 1) * g.lda + g.K) * 2), brec = (uint32_t)(((long)(BN - 1) * g.ldb + g.K) * 2);
+    const uint32_t nk = (uint32_t)(g.K / BK);
+    const int wb = wave * 1024 + lane * 16;
+    const int frow = lane & 15, fsw = (lane >> 1) & 7;
+    const int foff0 = frow * ROW_BYTES + ((((lane >> 4) + 0) ^ fsw) << 4);
+    const int foff1 = frow * ROW_BYTES + ((((lane >> 4) + 4) ^ fsw) << 4);
+    const int a_wave_off = (wr * WM) * ROW_BYTES, b_wave_off = A_BYTES + (wc * WN) * ROW_BYTES;
+    const int fa0 = a_wave_off + foff0, fa1 = a_wave_off + foff1, fb0 = b_wave_off + foff0, fb1 = b_wave_off + foff1;
+#ifdef GEMM_ASM_STAMPS  // tools/ubench/gemm_stamps.hip
+    unsigned long long* dbg = (blockIdx.x == 7) ? &g_gemm_stamps[wave][0] : &g_gemm_stamps[4][0];
+    const unsigned long long t_before = __builtin_readcyclecounter();
+#endif
+    asm volatile(
+#ifdef GEMM_ASM_STAMPS
+#include "gemm_asm_192x256_stamps.inc"
+#else
+#include "gemm_asm_192x256.inc"
+#endif
+        :
+        : [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk),
+          [sa] "s"(sa), [sb] "s"(sb), [ao] "v"(ao), [bo] "v"(bo), [wb] "v"(wb), [fa0] "v"(fa0), [fa1] "v"(fa1), [fb0] "v"(fb0),
+          [fb1] "v"(fb1)
+#ifdef GEMM_ASM_STAMPS
+          , [dbg] "s"(dbg)
+#endif
+        :
+#include "gemm_asm_192x256_clobbers.inc"
+    );
+#ifdef GEMM_ASM_STAMPS
+    const unsigned long long t_after = __builtin_readcyclecounter();
+#endif
+    __syncthreads();  // every wave is done with the K-tile slots before the epilogue scratch reuses them
+    // Epilogue: 32 rows x 128 columns at a time through 16 KB of LDS scratch per wave (assembly dump, see the generator), then a
+    // rolled loop over row pairs: one 16-byte column group per lane, two rows per iteration.
+    float* scr = (float*)(smem + wave * (32 * WN * 4));
+    // LDS byte address of this lane's first scratch element (the dynamic LDS of this kernel starts at 0, as the main loop assumes)
+    const unsigned scr_lane = (unsigned)(wave * (32 * WN * 4) + ((((lane >> 4) * 4) * WN + (lane & 15)) * 4));
+    const GemmEpilogue& ep = g.ep;
+    const int gn = n0 + wc * WN + (lane & 31) * 4;
+    const f32x4 bias = ep.bias_n ? *(const f32x4*)(ep.bias_n + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* rbase = ep.resid_src ? ep.resid_src : ep.out_f32;
+    const long rld = ep.resid_src ? ep.ld_resid : ep.ld_f32;
+    static_for<0, 3>([&](auto grp_c) {
+        constexpr int grp = decltype(grp_c)::value;
+#include "gemm_asm_192x256_dump.inc"
+#pragma unroll 2
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 2 + (lane >> 5);
+            const int gm = m0 + wr * WM + grp * 32 + row;
+            f32x4 v = *(const f32x4*)(scr + row * WN + (lane & 31) * 4);
+            v += bias;
+            if (ep.bias_m) {
+                const float bm = ep.bias_m[gm];
+                v += f32x4{bm, bm, bm, bm};
+            }
+            if (ep.act == LTX_ACT_GELU_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+            } else if (ep.act == LTX_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+            }
+            if (ep.round_bf16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
+            }
+            if (ep.resid) {
+                const f32x4 rs = *(const f32x4*)(rbase + (long)gm * rld + gn);
+                f32x4 gt = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
+                if (ep.gate) gt = *(const f32x4*)(ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[gm] : gm / ep.rows_per_batch) * ep.gate_bstride + gn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
+            }
+            if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn) = v;
+            if (ep.out_bf16) {
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn) = pk;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the scratch is rewritten by the next dump
+    });
+#ifdef GEMM_ASM_STAMPS
+    if (blockIdx.x == 7 && lane == 0) {
+        g_gemm_stamps[wave][6] = t_after - t_before;
+        g_gemm_stamps[wave][7] = __builtin_readcyclecounter() - t_after;
+    }
+#endif
+}
+
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2>
 void launch_v2(const GemmArgs& a, hipStream_t stream) {
     constexpr int smem = NSTAGE * (BM + BN) * ROW_BYTES;
@@ -1070,6 +1218,22 @@ void validate(const GemmArgs& a) {
 
 }  // namespace
 
+static bool gemm_asm_takes(const GemmArgs& a) {
+    return !a.conv && a.split_k <= 1 && a.M % 192 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 64 && !a.ep.d2s;
+}
+static void launch_asm(const GemmArgs& a, hipStream_t stream) {
+    LTX_REQUIRE(gemm_asm_takes(a), "gemm: the assembly kernel needs a dense A.B^T with M %% 192 == 0, N %% 256 == 0, K %% 64 == 0 (M=%d N=%d K=%d)",
+                a.M, a.N, a.K);
+    constexpr int smem = 2 * (192 + 256) * ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_asm, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_kernel_asm, dim3((a.M / 192) * (a.N / 256)), dim3(256), smem, stream, a);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     validate(a);
     LTX_REQUIRE(a.split_k <= 1 || (cfg >= 20 && cfg < 30), "gemm: split-K needs a ring kernel (tile cfg %d)", cfg);
@@ -1096,6 +1260,7 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 22: { GemmArgs b = a; b.group_m = 0; launch_v2<192, 128, 4, false, 4, 2>(b, stream); break; }  // A/B: column-major order
             case 23: launch_v2<256, 128, 3, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
+            case 71: launch_asm(a, stream); break;           // one wave per SIMD, assembly main loop, 192x256
             case 41: launch_v4<192, 256>(a, stream); break;  // ping-pong, 8 waves (2x4), per-wave 96x64
             case 42: launch_v4<256, 256>(a, stream); break;  // ping-pong, per-wave 128x64
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
@@ -1148,6 +1313,21 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
         b.split_ws = nullptr;
         launch_gemm_bf16(b, stream);
         return;
+    }
+    // The assembly kernel (tile_cfg 71: 192 x 256 tile, one wave per SIMD, generated main loop) is NOT in the default choice.
+    // Measured on MI355X, HBM-cold weights, random data, same process (tools/bench_gemm.py --cold --cfgs=-1,21,1,71), TFLOP/s:
+    // 1536x16384x4096 1057 vs 1009 (two-stage) / 987 (ring); 6144x4096x4096 1069 vs 1053 / 1015; 1536x8192x4096 895 vs 930 (ring);
+    // but inside the DiT step (same-box A/B of bench.py) routing the FFN's first GEMM to it costs 0.3 ms per step (41.6 vs 41.3).
+    // Its loop runs 2380 cycles per K-tile against 1730 of MFMA issue (14 buffer loads + 14 ds_write_b128 per wave and tile are
+    // not free) and its epilogue (10 us for 50 MB of output, every workgroup at the same time) is exposed once per launch.
+    // LTX_GEMM_ASM=1 opts in for launches that fill the chip at least twice with 192x256 tiles (A/B runs).
+    static const bool asm_on = getenv("LTX_GEMM_ASM") && getenv("LTX_GEMM_ASM")[0] == '1';
+    if (asm_on && gemm_asm_takes(a)) {
+        const long tiles_asm = (long)(a.M / 192) * (a.N / 256);
+        if (tiles_asm >= 512 && tiles_asm % 256 == 0 && a.K <= 8192) {
+            launch_gemm_bf16_cfg(a, 71, stream);
+            return;
+        }
     }
     int best = 0;
     double be = -1;

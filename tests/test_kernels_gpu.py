@@ -61,6 +61,45 @@ def test_gemm_split_k_integer_exact(gpu_ctx, M, N, K, S, cfg):
     assert np.array_equal(as_f32(outb), torch.from_numpy(ref).to(torch.bfloat16).float().numpy())
 
 
+@pytest.mark.parametrize("M,N,K,reps", [(192, 256, 64, 1), (192, 256, 128, 1), (384, 512, 448, 1), (192, 768, 7 * 64, 1), (576, 256, 13 * 64, 2),
+                                        (1536, 2048, 4096, 4), (768, 4096, 1024, 3)])
+def test_gemm_assembly_kernel_integer_exact(gpu_ctx, M, N, K, reps):
+    """One-wave-per-SIMD kernel with the assembly main loop (tile 192x256, three register sets, six-tile loop body left after
+    any tile): bit-exact on integer data for 1, 2, 7, 13 and 64 K-tiles - every exit point of the loop body and both LDS slots -
+    with bias, an f32 and a bf16 output through its own epilogue; the large shapes are repeated with fresh operands to screen the
+    register-set / LDS-slot rotation for races (a stale or early-read tile shows as a wrong integer)."""
+    for r in range(reps):
+        rng = np.random.default_rng(M + N + K + 71 + 1000 * r)
+        A = rng.integers(-3, 4, (M, K)).astype(np.float32)
+        B = rng.integers(-3, 4, (N, K)).astype(np.float32)
+        bias = rng.integers(-5, 6, (N,)).astype(np.float32)
+        out = torch.empty((M, N), device="cuda")
+        outb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+        gpu_ctx.op_gemm(dev_bf16(A), dev_bf16(B), dev_f32(bias), tile_cfg=71, out_f32=out, out_bf16=outb)
+        torch.cuda.synchronize()
+        ref = A @ B.T + bias
+        got = as_f32(out)
+        assert np.array_equal(got, ref), f"rep {r}: {np.count_nonzero(got != ref)} wrong, max diff {np.abs(got - ref).max()}"
+        assert np.array_equal(as_f32(outb), torch.from_numpy(ref).to(torch.bfloat16).float().numpy())
+
+
+def test_gemm_assembly_kernel_epilogue_matches_ring_kernel(gpu_ctx, ltx):
+    """GELU-tanh + bias + bf16 output (the FFN's first GEMM) and the refusal of shapes the assembly kernel does not take."""
+    rng = np.random.default_rng(9)
+    M, N, K = 384, 512, 256
+    A = dev_bf16(rng.standard_normal((M, K)))
+    B = dev_bf16(rng.standard_normal((N, K)) * 0.1)
+    bias = dev_f32(rng.standard_normal((N,)))
+    o1 = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    o2 = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_gemm(A, B, bias, act=1, tile_cfg=21, out_bf16=o1)
+    gpu_ctx.op_gemm(A, B, bias, act=1, tile_cfg=71, out_bf16=o2)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)  # same products, same f32 accumulation order per K-tile, same epilogue arithmetic
+    with pytest.raises(ltx.LTXError):
+        gpu_ctx.op_gemm(A[:100], B, bias, tile_cfg=71, out_bf16=o2[:100])
+
+
 @pytest.mark.parametrize("cfg", [41, 42])
 @pytest.mark.parametrize("M,N,K,reps", [(192, 256, 128, 1), (256, 256, 192, 1), (100, 60, 320, 1), (500, 700, 256, 2),
                                         (777, 1000, 448, 2), (1536, 1024, 4096, 6), (1536, 2048, 1024, 6), (3000, 768, 2112, 3)])

@@ -285,6 +285,10 @@ class Gen:
         # then the reference check for S(t+1) (rare path: rescale O and l), counted vmcnt, barrier
         va = [] if "noexp" in ABL else self.sm_exp(cur, 0)   # -> pf[.][0], needed by part B1
         vb = [] if "noexp" in ABL else self.sm_exp(cur, 1)   # -> pf[.][1], needed by part B2
+        # balance: part A has 48 MFMAs, part B1 24 - the multiplies of the second half move up into part A
+        mul_b = [x for x in vb if x.startswith("v_mul_f32")]
+        vb = [x for x in vb if not x.startswith("v_mul_f32")]
+        va = va + mul_b
         qk = self.qk_stream(nxt, (slot + 1) & 3)
         for kind, text in qk[:RA]:
             self.e(text)
