@@ -635,17 +635,29 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     bf16_t* Ob = a.O + (long)b * a.o_bstride + head * 128;
     const int q0 = blockIdx.x * W48_Q + wave * 48;
     const W48Lane L = w48_lane(lane, wave, a.ldk, a.ldvt);
+    // any Tq / Tk: query rows past Tq read row Tq-1 and their stores fall outside the O descriptor; key rows past Tk read zeros
+    // through the K descriptor and are masked to -inf in the last tile (tmask: bit kb*4+j = this lane's key (kb, j) is invalid)
     int qo[3], oo[3];
 #pragma unroll
     for (int qb = 0; qb < 3; ++qb) {
-        qo[qb] = ((q0 + 16 * qb + c16) * (int)a.ldq + g * 8) * 2;
-        oo[qb] = ((q0 + 16 * qb + c16) * (int)a.ldo + g * 4) * 2;
+        const int qi = q0 + 16 * qb + c16;
+        qo[qb] = ((qi < a.Tq ? qi : a.Tq - 1) * (int)a.ldq + g * 8) * 2;
+        oo[qb] = (qi * (int)a.ldo + g * 4) * 2;
     }
+    const uint32_t nt = (uint32_t)((a.Tk + KV_TILE - 1) / KV_TILE);
+    const uint32_t rag = (uint32_t)__builtin_amdgcn_readfirstlane((a.Tk % KV_TILE) != 0 ? 1 : 0);
+    uint32_t tmask = 0;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((int)(nt - 1) * KV_TILE + 32 * (kb >> 1) + 4 * (kb & 1) + 8 * g + j >= a.Tk) tmask |= 1u << (kb * 4 + j);
+    const uint32_t oblo = (uint32_t)(uintptr_t)Ob, obhi = (uint32_t)((uintptr_t)Ob >> 32);
+    const uint32_t orec = (uint32_t)(((long)(a.Tq - 1) * a.ldo + 128) * 2);
     const uint32_t kblo = (uint32_t)(uintptr_t)Kb, kbhi = (uint32_t)((uintptr_t)Kb >> 32);
     const uint32_t vblo = (uint32_t)(uintptr_t)Vb, vbhi = (uint32_t)((uintptr_t)Vb >> 32);
     const uint32_t krec = (uint32_t)(((long)(a.Tk - 1) * a.ldk + 128) * 2), vrec = (uint32_t)((long)128 * a.ldvt * 2);
     const uint32_t ktb = (uint32_t)(KV_TILE * a.ldk * 2);
-    const uint32_t nt4 = (uint32_t)(a.Tk / (4 * KV_TILE));
     const float c = a.scale * 1.4426950408889634f;
     const uint32_t wlds = (uint32_t)wave * 1024u;
     const float tau = 8.0f / c;  // raw-score threshold: the reference maximum of a query is raised only when exp2((s - ref)*c) > 2^8
@@ -659,8 +671,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
 #include "attention_w48_asm.inc"
 #endif
         :
-        : [qbase] "s"(Qb), [obase] "s"(Ob), [kblo] "s"(kblo), [kbhi] "s"(kbhi), [vblo] "s"(vblo), [vbhi] "s"(vbhi), [krec] "s"(krec),
-          [vrec] "s"(vrec), [ktb] "s"(ktb), [nt4] "s"(nt4), [c] "s"(c), [tau] "s"(tau), [wlds] "s"(wlds), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]),
+        : [qbase] "s"(Qb), [oblo] "s"(oblo), [obhi] "s"(obhi), [orec] "s"(orec), [rag] "s"(rag), [tmask] "v"(tmask), [kblo] "s"(kblo), [kbhi] "s"(kbhi), [vblo] "s"(vblo), [vbhi] "s"(vbhi), [krec] "s"(krec),
+          [vrec] "s"(vrec), [ktb] "s"(ktb), [nt] "s"(nt), [c] "s"(c), [tau] "s"(tau), [wlds] "s"(wlds), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]),
           [qo2] "v"(qo[2]), [oo0] "v"(oo[0]), [oo1] "v"(oo[1]), [oo2] "v"(oo[2]), [ko0] "v"(L.koff[0]), [ko1] "v"(L.koff[1]),
           [ko2] "v"(L.koff[2]), [ko3] "v"(L.koff[3]), [vo0] "v"(L.voff[0]), [vo1] "v"(L.voff[1]), [vo2] "v"(L.voff[2]),
           [vo3] "v"(L.voff[3]), [ka0] "v"(L.kaddr[0]), [ka1] "v"(L.kaddr[1]), [ka2] "v"(L.kaddr[2]), [ka3] "v"(L.kaddr[3]),
@@ -721,17 +733,18 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
             HIP_CHECK(hipGetLastError());
             return;
         }
-        const long wg48 = (long)(a.Tq / W48_Q) * a.H * a.B;
+        const long wg48 = (long)((a.Tq + W48_Q - 1) / W48_Q) * a.H * a.B;
         const double cost48 = (double)((wg48 + 255) / 256) * 1.25;
-        const bool use_asm = forced ? impl[0] == '4' : (w48_ok && cost48 < cost4 && cost48 < costpp);
+        const bool asm_ok = !a.bias;  // any Tq, Tk (ragged tails handled in the kernel); masked launches stay on the 4-wave kernel
+        const bool use_asm = forced ? impl[0] == '4' : (asm_ok && cost48 < cost4 && cost48 < costpp);
         if (use_asm) {
-            LTX_REQUIRE(w48_ok, "attention: LTX_ATTN_IMPL=4 needs Tq %% 192 == 0, Tk %% 256 == 0 and no mask (Tq=%d Tk=%d)", a.Tq, a.Tk);
+            LTX_REQUIRE(asm_ok, "attention: LTX_ATTN_IMPL=4 takes unmasked launches only (Tq=%d Tk=%d)", a.Tq, a.Tk);
             static bool attr4_set = false;
             if (!attr4_set) {
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
                 attr4_set = true;
             }
-            hipLaunchKernelGGL(attn_fwd_kernel_w48_asm, dim3(a.Tq / W48_Q, a.H, a.B), dim3(256), W48_LDS, stream, a);
+            hipLaunchKernelGGL(attn_fwd_kernel_w48_asm, dim3((a.Tq + W48_Q - 1) / W48_Q, a.H, a.B), dim3(256), W48_LDS, stream, a);
             HIP_CHECK(hipGetLastError());
             return;
         }

@@ -293,6 +293,34 @@ def test_attention_every_kernel_vs_f32(gpu_ctx, attn_impl, impl, B, H, Tq, Tk):
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-2
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk", [(1, 2, 128, 128), (2, 2, 105, 77), (1, 1, 32, 64), (1, 1, 1, 3), (1, 2, 193, 33), (2, 1, 191, 1000),
+                                       (1, 2, 1024, 1024), (1, 1, 500, 321), (1, 3, 384, 640), (1, 1, 200, 65), (1, 1, 50, 255)])
+def test_attention_assembly_kernel_any_shape(gpu_ctx, attn_impl, B, H, Tq, Tk):
+    """The assembly kernel on sizes that are NOT multiples of its 192-query / 64-key tiles: query rows past Tq must not be stored
+    (guard band checked), keys past Tk must not contribute (1, 2, 3 and 5 ... 16 key tiles: every exit point of the unrolled loop,
+    a single ragged tile, a ragged last tile after full ones)."""
+    attn_impl(4)
+    rng = np.random.default_rng(B * 5 + H + Tq * 3 + Tk)
+    qd, kd, vd, vt = _attn_inputs(rng, B, H, Tq, Tk)
+    D = H * 128
+    obuf = torch.full((B, Tq + 8, D), 7.0, device="cuda", dtype=torch.bfloat16)  # 8 guard rows after the last batch element only
+    o = obuf[:, :Tq]
+    scale = 1.0 / math.sqrt(128.0)
+    if B == 1:
+        gpu_ctx.op_attention(qd, kd, vt, None, H, o, scale)
+    else:
+        o = torch.empty((B, Tq, D), device="cuda", dtype=torch.bfloat16)
+        gpu_ctx.op_attention(qd, kd, vt, None, H, o, scale)
+    torch.cuda.synchronize()
+    ref = _attn_ref(qd.float().cpu(), kd.float().cpu(), vd.float().cpu(), H, None, scale).numpy()
+    got = as_f32(o)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-2
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-2
+    if B == 1:
+        assert (as_f32(obuf[:, Tq:]) == 7.0).all(), "rows past Tq were written"
+
+
 @pytest.mark.parametrize("impl", [1, 2, 4])
 def test_attention_reference_maximum_stress(gpu_ctx, attn_impl, impl):
     """The assembly kernel's rare path under stress, the other kernels beside it: key magnitudes grow with the key index (the

@@ -15,7 +15,7 @@ Register map (per wave):
   v[168:183]  fragment ring (4 x 4)              s[48:53]  compare masks of the reference check
   v[184:186]  per-lane maxima, v[187:194] rare-path temporaries, v195 floor, v[196:199] bf16 ones
   v[200:211]  -(reference max) per query block (x4: accumulator init of K.Q^T)        a[96:107] row sums l[qb]
-  v[212:217]  fragment addresses + 64 KB (ring slots 2, 3)
+  v[212:217]  fragment addresses + 64 KB (ring slots 2, 3)                              s[60:63] O buffer descriptor
 Operands (compiler-assigned): see the asm statement in attention.hip.
 """
 import os
@@ -66,7 +66,7 @@ class Gen:
     def stamp(self, i):
         """--stamps build only: s_memtime into s[54+2i : 55+2i] (written out at the end of the kernel)."""
         if self.stamps:
-            self.e(f"s_memtime s[{54 + 2 * i}:{55 + 2 * i}]")
+            self.e(f"s_memtime s[{64 + 2 * i}:{65 + 2 * i}]")
             self.e("s_waitcnt lgkmcnt(0)")
 
     def e(self, s):
@@ -169,6 +169,27 @@ class Gen:
                 out.append(f"v_cvt_pk_bf16_f32 v{p + 2 * hh + 1}, v{b + 2}, v{b + 3}")
             lists.append(out)
         return [x[k] for k in range(len(lists[0])) for x in lists]
+
+    def tail_mask(self, label, sbuf, count):
+        """If exactly `count` tiles remain after... (s46 == count) and the key count is ragged: the tile in `sbuf` is the last one -
+        its keys at or beyond Tk (zero rows from the K descriptor) get a score of -inf. %[tmask] bit kb*4+j = that key is invalid."""
+        e = self.e
+        e(f"s_cmp_eq_u32 s46, {count}")
+        e(f"s_cbranch_scc0 {label}f")
+        e("s_cmp_eq_u32 %[rag], 0")
+        e(f"s_cbranch_scc1 {label}f")
+        e("s_nop 7")
+        e("s_nop 7")
+        e(f"v_mov_b32 v{RT + 1}, 0xff800000")
+        for kb in range(4):
+            for j in range(4):
+                e(f"v_and_b32 v{RT}, {1 << (kb * 4 + j)}, %[tmask]")
+                e(f"v_cmp_ne_u32_e64 s[48:49], 0, v{RT}")
+                e("s_nop 1")
+                for qb in range(3):
+                    r = s_reg(sbuf, kb, qb, j)
+                    e(f"v_cndmask_b32_e64 v{r}, v{r}, v{RT + 1}, s[48:49]")
+        e(f"{label}:")
 
     def sm_check_and_rare_path(self, label, sbuf):
         """After phase 1 on `sbuf`: if any lane saw a score above the threshold, raise every query's reference to its running
@@ -296,6 +317,7 @@ class Gen:
         for ins in va[:npre]:  # independent of the reads just issued: covers part of their latency
             self.e(ins)
         self.spread(qk[RA:], [[x] for x in va[npre:]], 44)
+        self.tail_mask(f"{uid + 10}", nxt, 2)   # S(t+1) is the last, ragged tile
         st(1)
         pv = self.pv_stream(slot)
         head, tail = self.split_stream(pv, 24)
@@ -311,6 +333,11 @@ class Gen:
             if dma:
                 work.append(dma.pop(0))
         self.spread(tail, work, 26)
+        # tile t was the last one: leave before the reference check of a tile that does not exist (its zero scores could raise the
+        # reference of a row whose real scores are all far below zero, scaling O and l to nothing)
+        self.e("s_sub_u32 s46, s46, 1")
+        self.e("s_cmp_eq_u32 s46, 0")
+        self.e("s_cbranch_scc1 30f")
         self.sm_check_and_rare_path(f"{uid}", nxt)
         self.advance_stage_offsets()
         st(3)
@@ -331,7 +358,11 @@ class Gen:
         e("s_mov_b32 s43, 0x00020000")
         e("s_mov_b32 s44, 0")
         e("s_mov_b32 s45, 0")
-        e("s_mov_b32 s46, %[nt4]")
+        e("s_mov_b32 s46, %[nt]")        # tiles left (including the one whose S is current)
+        e("s_mov_b32 s60, %[oblo]")
+        e("s_mov_b32 s61, %[obhi]")
+        e("s_mov_b32 s62, %[orec]")      # rows at or beyond Tq fall outside the descriptor: their stores are dropped
+        e("s_mov_b32 s63, 0x00020000")
         for ks in range(4):
             e(f"v_add_u32 v{HI + ks}, 0x10000, %[ka{ks}]")
         for i in range(2):
@@ -360,6 +391,7 @@ class Gen:
             e(text)
         e("s_nop 7")
         e("s_nop 7")
+        self.tail_mask("8", SA, 1)       # a single, ragged tile
         for ins in self.sm_max(SA):
             e(ins)
         self.sm_check_and_rare_path("9", SA)
@@ -368,9 +400,8 @@ class Gen:
         self.step(1, SB, SA, 12)
         self.step(2, SA, SB, 13)
         self.step(3, SB, SA, 14)
-        e("s_sub_u32 s46, s46, 1")
-        e("s_cmp_lg_u32 s46, 0")
-        e("s_cbranch_scc1 10b")
+        e("s_branch 10b")
+        e("30:")
         e("; ---- epilogue ----")
         e("s_waitcnt vmcnt(0)")
         e("s_nop 7")
@@ -389,11 +420,11 @@ class Gen:
                     e(f"v_mul_f32 v{RT + 1 + j}, v{RT + 1 + j}, v{RT}")
                 e(f"v_cvt_pk_bf16_f32 v{RT + 5}, v{RT + 1}, v{RT + 2}")   # v[192:193]: 64-bit aligned store data
                 e(f"v_cvt_pk_bf16_f32 v{RT + 6}, v{RT + 3}, v{RT + 4}")
-                e(f"global_store_dwordx2 %[oo{qb}], v[{RT + 5}:{RT + 6}], %[obase] offset:{db * 32}")
+                e(f"buffer_store_dwordx2 v[{RT + 5}:{RT + 6}], %[oo{qb}], s[60:63], 0 offen offset:{db * 32}")
         e("s_waitcnt vmcnt(0)")
         if self.stamps:  # lane 0 of every wave writes its 5 stamps: dbg[wave][5] u64
             for i in range(10):
-                e(f"v_mov_b32 v{PF + i}, s{54 + i}")
+                e(f"v_mov_b32 v{PF + i}, s{64 + i}")
             e(f"v_mov_b32 v{PF + 10}, 0")
             for i in range(5):
                 e(f"global_store_dwordx2 v{PF + 10}, v[{PF + 2 * i}:{PF + 2 * i + 1}], %[dbg] offset:{i * 8}")
@@ -412,7 +443,7 @@ def main():
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. gfx950 assembly body of attn_fwd_kernel_w48_asm (attention.hip).\n")
         for ln in lines:
             f.write('"' + ln.replace('"', '\\"') + '\\n\\t"\n')
-    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(LACC + 12)] + [f"s{i}" for i in range(36, 64)] + ["m0", "vcc", "scc", "memory"]
+    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(LACC + 12)] + [f"s{i}" for i in range(36, 76)] + ["m0", "vcc", "scc", "memory"]
     with open(os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", "attention_w48_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. Registers the assembly body assigns by hand.\n")
         for i in range(0, len(clob), 12):
