@@ -623,6 +623,7 @@ __device__ unsigned long long g_w48_stamps[8][8];
 #endif
 // The same kernel with the main loop in assembly (generated by tools/gen_attn_w48.py from the layout above; register map and
 // schedule in that script's header). C++ only prepares the per-lane offsets and the uniform operands.
+template <bool HAS_BIAS>
 __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -661,28 +662,48 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     const float c = a.scale * 1.4426950408889634f;
     const uint32_t wlds = (uint32_t)wave * 1024u;
     const float tau = 8.0f / c;  // raw-score threshold: the reference maximum of a query is raised only when exp2((s - ref)*c) > 2^8
+    // masked variant: the bias vector of this batch element goes to LDS once (16 KB after the ring, Tk <= 4096); a lane's 16 values
+    // of a tile sit at ba + 256 * tile
+    const float* biasb = HAS_BIAS ? a.bias + (long)b * a.bias_bstride : nullptr;
+    const uint32_t bilo = (uint32_t)(uintptr_t)biasb, bihi = (uint32_t)((uintptr_t)biasb >> 32), birec = (uint32_t)(a.Tk * 4);
+    const float isc = 1.0f / a.scale;
+    const int bvo = lane * 16;
+    const int ba = W48_LDS + g * 32;
 #ifdef W48_STAMPS  // tools/ubench/attn_stamps.hip: per-wave s_memtime stamps of one tile step -> g_w48_stamps[wave][5]
     unsigned long long* dbg = (blockIdx.x == 1 && blockIdx.y == 3) ? &g_w48_stamps[wave][0] : &g_w48_stamps[4 + (wave & 3)][0];
 #endif
-    asm volatile(
+#define W48_OPERANDS                                                                                                                  \
+    [qbase] "s"(Qb), [oblo] "s"(oblo), [obhi] "s"(obhi), [orec] "s"(orec), [rag] "s"(rag), [tmask] "v"(tmask), [kblo] "s"(kblo),         \
+        [kbhi] "s"(kbhi), [vblo] "s"(vblo), [vbhi] "s"(vbhi), [krec] "s"(krec), [vrec] "s"(vrec), [ktb] "s"(ktb), [nt] "s"(nt),          \
+        [c] "s"(c), [tau] "s"(tau), [wlds] "s"(wlds), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]), [qo2] "v"(qo[2]), [oo0] "v"(oo[0]),             \
+        [oo1] "v"(oo[1]), [oo2] "v"(oo[2]), [ko0] "v"(L.koff[0]), [ko1] "v"(L.koff[1]), [ko2] "v"(L.koff[2]), [ko3] "v"(L.koff[3]),       \
+        [vo0] "v"(L.voff[0]), [vo1] "v"(L.voff[1]), [vo2] "v"(L.voff[2]), [vo3] "v"(L.voff[3]), [ka0] "v"(L.kaddr[0]),                  \
+        [ka1] "v"(L.kaddr[1]), [ka2] "v"(L.kaddr[2]), [ka3] "v"(L.kaddr[3]), [va0] "v"(L.vaddr[0]), [va1] "v"(L.vaddr[1])
+    if constexpr (HAS_BIAS) {
+        asm volatile(
+#include "attention_w48_asm_bias.inc"
+            :
+            : W48_OPERANDS, [bilo] "s"(bilo), [bihi] "s"(bihi), [birec] "s"(birec), [isc] "s"(isc), [bvo] "v"(bvo), [ba] "v"(ba)
+            :
+#include "attention_w48_bias_clobbers.inc"
+        );
+    } else {
+        asm volatile(
 #ifdef W48_STAMPS
 #include "attention_w48_asm_stamps.inc"
 #else
 #include "attention_w48_asm.inc"
 #endif
-        :
-        : [qbase] "s"(Qb), [oblo] "s"(oblo), [obhi] "s"(obhi), [orec] "s"(orec), [rag] "s"(rag), [tmask] "v"(tmask), [kblo] "s"(kblo), [kbhi] "s"(kbhi), [vblo] "s"(vblo), [vbhi] "s"(vbhi), [krec] "s"(krec),
-          [vrec] "s"(vrec), [ktb] "s"(ktb), [nt] "s"(nt), [c] "s"(c), [tau] "s"(tau), [wlds] "s"(wlds), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]),
-          [qo2] "v"(qo[2]), [oo0] "v"(oo[0]), [oo1] "v"(oo[1]), [oo2] "v"(oo[2]), [ko0] "v"(L.koff[0]), [ko1] "v"(L.koff[1]),
-          [ko2] "v"(L.koff[2]), [ko3] "v"(L.koff[3]), [vo0] "v"(L.voff[0]), [vo1] "v"(L.voff[1]), [vo2] "v"(L.voff[2]),
-          [vo3] "v"(L.voff[3]), [ka0] "v"(L.kaddr[0]), [ka1] "v"(L.kaddr[1]), [ka2] "v"(L.kaddr[2]), [ka3] "v"(L.kaddr[3]),
-          [va0] "v"(L.vaddr[0]), [va1] "v"(L.vaddr[1])
+            :
+            : W48_OPERANDS
 #ifdef W48_STAMPS
-          , [dbg] "s"(dbg)
+              , [dbg] "s"(dbg)
 #endif
-        :
+            :
 #include "attention_w48_clobbers.inc"
-    );
+        );
+    }
+#undef W48_OPERANDS
     (void)smem;
 }
 
@@ -735,16 +756,21 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
         }
         const long wg48 = (long)((a.Tq + W48_Q - 1) / W48_Q) * a.H * a.B;
         const double cost48 = (double)((wg48 + 255) / 256) * 1.25;
-        const bool asm_ok = !a.bias;  // any Tq, Tk (ragged tails handled in the kernel); masked launches stay on the 4-wave kernel
+        const bool asm_ok = !a.bias || a.Tk <= 4096;  // any Tq, Tk (ragged tails in the kernel); masked: the bias vector must fit 16 KB of LDS
         const bool use_asm = forced ? impl[0] == '4' : (asm_ok && cost48 < cost4 && cost48 < costpp);
         if (use_asm) {
-            LTX_REQUIRE(asm_ok, "attention: LTX_ATTN_IMPL=4 takes unmasked launches only (Tq=%d Tk=%d)", a.Tq, a.Tk);
+            LTX_REQUIRE(asm_ok, "attention: LTX_ATTN_IMPL=4 takes masked launches up to 4096 keys only (Tq=%d Tk=%d)", a.Tq, a.Tk);
             static bool attr4_set = false;
             if (!attr4_set) {
-                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS + 16384));
                 attr4_set = true;
             }
-            hipLaunchKernelGGL(attn_fwd_kernel_w48_asm, dim3((a.Tq + W48_Q - 1) / W48_Q, a.H, a.B), dim3(256), W48_LDS, stream, a);
+            const dim3 grid4((a.Tq + W48_Q - 1) / W48_Q, a.H, a.B);
+            if (a.bias)
+                hipLaunchKernelGGL(attn_fwd_kernel_w48_asm<true>, grid4, dim3(256), W48_LDS + 16384, stream, a);
+            else
+                hipLaunchKernelGGL(attn_fwd_kernel_w48_asm<false>, grid4, dim3(256), W48_LDS, stream, a);
             HIP_CHECK(hipGetLastError());
             return;
         }

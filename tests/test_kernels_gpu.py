@@ -321,6 +321,54 @@ def test_attention_assembly_kernel_any_shape(gpu_ctx, attn_impl, B, H, Tq, Tk):
         assert (as_f32(obuf[:, Tq:]) == 7.0).all(), "rows past Tq were written"
 
 
+@pytest.mark.parametrize("impl", [1, 4])
+@pytest.mark.parametrize("B,H,Tq,Tk,all_masked", [(1, 2, 192, 256, False), (2, 2, 105, 77, False), (1, 3, 300, 1024, False), (1, 1, 384, 97, False),
+                                                  (2, 1, 1536, 1024, True), (1, 1, 1, 3, False), (1, 2, 200, 4096, False)])
+def test_attention_masked_every_kernel(gpu_ctx, attn_impl, impl, B, H, Tq, Tk, all_masked):
+    """Additive key mask ((1-m) * -10000, LTXTransformer.swift:141-156) on the 4-wave kernel and on the masked assembly variant (bias
+    vector in LDS, added to the scores in raw units before the reference maximum is taken). all_masked: batch element 0 has EVERY
+    key masked - the CFG null-mask case: softmax(s - 10000) = softmax(s) must come out, not 0/0."""
+    attn_impl(impl)
+    rng = np.random.default_rng(B * 11 + H + Tq + Tk)
+    qd, kd, vd, vt = _attn_inputs(rng, B, H, Tq, Tk)
+    m = (rng.random((B, Tk)) > 0.3).astype(np.float32)
+    m[:, 0] = 1
+    if all_masked:
+        m[0, :] = 0
+    bias = dev_f32((1 - m) * -10000.0)
+    o = torch.empty((B, Tq, H * 128), device="cuda", dtype=torch.bfloat16)
+    scale = 1.0 / math.sqrt(128.0)
+    gpu_ctx.op_attention(qd, kd, vt, bias, H, o, scale)
+    torch.cuda.synchronize()
+    ref = _attn_ref(qd.float().cpu(), kd.float().cpu(), vd.float().cpu(), H, bias.cpu(), scale).numpy()
+    got = as_f32(o)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-2
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-2
+
+
+@pytest.mark.parametrize("impl", [1, 2, 4])
+@pytest.mark.parametrize("Tk", [64, 256, 1000])
+def test_attention_scores_far_below_zero(gpu_ctx, attn_impl, impl, Tk):
+    """Every score of every row around -2560 (c*s = -326): exp2 of the unshifted score underflows to 0 and 2^+326 overflows, so
+    the very first tile has to set the reference maximum (regression: the assembly kernel once relied on the 2^8 threshold test
+    for the first tile as well and returned 0/0 here)."""
+    attn_impl(impl)
+    rng = np.random.default_rng(Tk)
+    Tq, H = 192, 1
+    k = (1.0 + 0.05 * rng.standard_normal((1, Tk, 128))).astype(np.float32)
+    q = (-20.0 + 0.05 * rng.standard_normal((1, Tq, 128))).astype(np.float32)
+    qd, kd, vd, vt = _attn_inputs(rng, 1, H, Tq, Tk, q=q, k=k)
+    o = torch.empty((1, Tq, 128), device="cuda", dtype=torch.bfloat16)
+    scale = 1.0 / math.sqrt(128.0)
+    gpu_ctx.op_attention(qd, kd, vt, None, H, o, scale)
+    torch.cuda.synchronize()
+    ref = _attn_ref(qd.float().cpu(), kd.float().cpu(), vd.float().cpu(), H, None, scale).numpy()
+    got = as_f32(o)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-2
+
+
 @pytest.mark.parametrize("impl", [1, 2, 4])
 def test_attention_reference_maximum_stress(gpu_ctx, attn_impl, impl):
     """The assembly kernel's rare path under stress, the other kernels beside it: key magnitudes grow with the key index (the

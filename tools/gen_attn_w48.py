@@ -30,7 +30,13 @@ HI = 212          # v[212:217] fragment addresses + 64 KB (ring slots 2, 3)
 NV = 220          # v0..v219 are assigned here; the compiler places the operands above
 LACC = 96         # a[96:107]: row sums l[qb] (every register of a tuple holds the same value)
 TAU = 8.0         # raise the reference only when a score exceeds it by more than 2^TAU: P stays <= 256
+BIASR = 184       # masked variant: v[184:199] = this lane's 16 bias values of the tile being prepared (live from the start of part B1
+                  # to the last bias add; shares v184..194 with MAXR / RT, which are only used afterwards)
+BIAS_LDS = 4 * 32768  # byte offset of the bias vector in LDS (after the four K / Vt ring slots), Tk <= 4096 floats
+BADDR = 221           # masked variant: LDS address of this lane's bias values of the tile being prepared
 STAGE = 32768
+if "--bias" in __import__("sys").argv:
+    FLOOR, ONES, NV = 220, 224, 228   # v195..199 belong to the bias values in this variant
 RA = 3  # fragment reads in flight ahead of their MFMAs (ring of 4 fragment registers)
 
 
@@ -55,6 +61,7 @@ def vblock_off(db):
     return db * 16 * 128
 
 
+BIAS = "--bias" in __import__("sys").argv   # masked variant: additive per-key bias (cross-attention text mask)
 ABL = set(os.environ.get("W48_ABLATE", "").split(","))  # timing experiments only (wrong results): nodma, noexp, nords, ra6
 
 
@@ -132,6 +139,26 @@ class Gen:
     # every tile; so the reference is only raised when a score exceeds it by more than 2^TAU (after the scale): P = exp2(s'*c)
     # <= 2^TAU, l (a row of ones in the PV product) accumulates against the same reference, and the common path is 24 v_max3 + 3
     # compares, 48 v_mul, 48 v_exp and 24 v_cvt_pk per tile - no row-sum adds, no cross-lane reduction, no rescale.
+    def bias_reads(self, slot_unused=None):
+        """Masked variant: this lane's 16 bias values of the tile whose scores are about to be checked: keys 32(kb>>1) + 4(kb&1) +
+        8g + j -> four ds_read_b128 at %[ba] (+ tile offset in s47) + 128 (kb>>1) + 16 (kb&1). They are the OLDEST LDS operations in
+        flight wherever they are issued (before the fragment reads of the stream that follows), so the fragment waits cover them."""
+        out = []
+        for kb in range(4):
+            out.append(f"ds_read_b128 v[{BIASR + 4 * kb}:{BIASR + 4 * kb + 3}], v{BADDR} offset:{128 * (kb >> 1) + 16 * (kb & 1)}")
+        return out
+
+    def bias_add(self, sbuf):
+        """S' += bias / scale (the bias is given in post-scale units) for the three query blocks: the reference maximum, the threshold test and the exponentials all see
+        the biased scores, so a fully masked row (-10000 on every key) still normalises like the reference's softmax."""
+        out = []
+        for kb in range(4):
+            for j in range(4):
+                for qb in range(3):
+                    r = s_reg(sbuf, kb, qb, j)
+                    out.append(f"v_fma_f32 v{r}, v{BIASR + 4 * kb + j}, %[isc], v{r}")   # + bias / scale
+        return out
+
     def sm_max(self, sbuf):
         """Phase 1: per-lane maximum of each query block's 16 scores and the wave-wide 'exceeds threshold' masks."""
         lists = []
@@ -191,7 +218,7 @@ class Gen:
                     e(f"v_cndmask_b32_e64 v{r}, v{r}, v{RT + 1}, s[48:49]")
         e(f"{label}:")
 
-    def sm_check_and_rare_path(self, label, sbuf):
+    def sm_check_and_rare_path(self, label, sbuf, force=False):
         """After phase 1 on `sbuf`: if any lane saw a score above the threshold, raise every query's reference to its running
         maximum: delta = max(row maximum, floor) in shifted units; S' -= delta, accumulator init -= delta, O and l *= 2^-delta."""
         e = self.e
@@ -199,7 +226,8 @@ class Gen:
         e("s_or_b64 s[48:49], s[48:49], s[50:51]")
         e("s_or_b64 s[48:49], s[48:49], s[52:53]")
         e("s_cmp_lg_u64 s[48:49], 0")
-        e(f"s_cbranch_scc0 {label}f")
+        if not force:  # the first tile always sets the reference to the true row maximum (the floor is -inf then): without it a row
+            e(f"s_cbranch_scc0 {label}f")  # whose scores are all far below zero (a fully masked row: -10000) would underflow to l = 0
         for qb in range(3):
             t = MAXR + qb
             for swap in ("v_permlane16_swap_b32", "v_permlane32_swap_b32"):  # maximum over the four lanes of a query
@@ -211,7 +239,8 @@ class Gen:
             e(f"v_max_f32 v{RT + 1}, v{t}, v{FLOOR}")             # delta
             e(f"v_mul_f32 v{RT + 2}, %[c], v{RT + 1}")
             e(f"v_sub_f32 v{RT + 2}, 0, v{RT + 2}")
-            e(f"v_exp_f32 v{RT + 2}, v{RT + 2}")                   # alpha = 2^(-delta*c)
+            e(f"v_min_f32 v{RT + 2}, 0, v{RT + 2}")                # first tile: the reference may move DOWN (O = l = 0 then; a
+            e(f"v_exp_f32 v{RT + 2}, v{RT + 2}")                   # fully masked row would give 2^14427 = inf, inf * 0 = NaN)
             for j in range(4):
                 e(f"v_sub_f32 v{NMCT[qb] + j}, v{NMCT[qb] + j}, v{RT + 1}")
             for kb in range(4):
@@ -321,6 +350,11 @@ class Gen:
         st(1)
         pv = self.pv_stream(slot)
         head, tail = self.split_stream(pv, 24)
+        if BIAS:  # bias of tile t+1: reads first (older than every fragment read of this stream), adds after the exponentials
+            self.e(f"v_add_u32 v{BADDR}, 256, v{BADDR}")
+            for ins in self.bias_reads():
+                self.e(ins)
+            vb = vb + self.bias_add(nxt)
         self.spread(head, [[x] for x in vb], 22)
         st(2)
         dma = [] if "nodma" in ABL else self.stage((slot + 3) & 3)
@@ -379,6 +413,17 @@ class Gen:
         e(f"v_mov_b32 v{FLOOR}, 0xff800000")
         for j in range(4):
             e(f"v_mov_b32 v{ONES + j}, 0x3f803f80")
+        if BIAS:
+            e("; ---- bias vector -> LDS (16 KB after the ring; the descriptor ends after key Tk-1: zeros beyond) ----")
+            e("s_mov_b32 s56, %[bilo]")
+            e("s_mov_b32 s57, %[bihi]")
+            e("s_mov_b32 s58, %[birec]")
+            e("s_mov_b32 s59, 0x00020000")
+            for i in range(4):
+                e(f"s_add_u32 m0, %[wlds], {BIAS_LDS + i * 4096}")
+                e(f"s_add_u32 s47, %[wlds], {i * 4096}")
+                e("buffer_load_dwordx4 %[bvo], s[56:59], s47 offen lds")
+            e(f"v_mov_b32 v{BADDR}, %[ba]")
         e("; ---- tiles 0, 1, 2 ----")
         for t in range(3):
             for grp in self.stage(t):
@@ -392,9 +437,15 @@ class Gen:
         e("s_nop 7")
         e("s_nop 7")
         self.tail_mask("8", SA, 1)       # a single, ragged tile
+        if BIAS:
+            for ins in self.bias_reads():
+                e(ins)
+            e("s_waitcnt lgkmcnt(0)")
+            for ins in self.bias_add(SA):
+                e(ins)
         for ins in self.sm_max(SA):
             e(ins)
-        self.sm_check_and_rare_path("9", SA)
+        self.sm_check_and_rare_path("9", SA, force=True)
         e("10:")
         self.step(0, SA, SB, 11)
         self.step(1, SB, SA, 12)
@@ -438,13 +489,14 @@ def main():
     g = Gen(stamps)
     lines = g.build()
     here = os.path.dirname(os.path.abspath(__file__))
-    out = os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", "attention_w48_asm_stamps.inc" if stamps else "attention_w48_asm.inc")
+    name = "attention_w48_asm" + ("_bias" if BIAS else "") + ("_stamps" if stamps else "") + ".inc"
+    out = os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", name)
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. gfx950 assembly body of attn_fwd_kernel_w48_asm (attention.hip).\n")
         for ln in lines:
             f.write('"' + ln.replace('"', '\\"') + '\\n\\t"\n')
     clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(LACC + 12)] + [f"s{i}" for i in range(36, 76)] + ["m0", "vcc", "scc", "memory"]
-    with open(os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", "attention_w48_clobbers.inc"), "w") as f:
+    with open(os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", "attention_w48_bias_clobbers.inc" if BIAS else "attention_w48_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. Registers the assembly body assigns by hand.\n")
         for i in range(0, len(clob), 12):
             f.write(", ".join('"' + c + '"' for c in clob[i:i + 12]) + ("," if i + 12 < len(clob) else "") + "\n")
