@@ -247,6 +247,8 @@ class Gen:
                 for j in range(4):
                     r = s_reg(sbuf, kb, qb, j)
                     e(f"v_sub_f32 v{r}, v{r}, v{RT + 1}")
+            if force:
+                continue  # first tile: O and l are still zero, nothing to rescale
             e("s_nop 7")
             e("s_nop 7")
             for a in [o_reg(db, qb) for db in range(8)] + [LACC + 4 * qb]:
