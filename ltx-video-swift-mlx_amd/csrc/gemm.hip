@@ -1031,9 +1031,11 @@ void launch_one(const GemmArgs& a, hipStream_t stream) {
 #ifdef GEMM_ASM_STAMPS
 __device__ unsigned long long g_gemm_stamps[5][8];
 #endif
+template <int BN>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_asm(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 192, BN = 256, WGM = 2, WGN = 2, NW = 4;
+    static_assert(BN == 256 || BN == 128, "generated main loops exist for 192x256 and 192x128");
+    constexpr int BM = 192, WGM = 2, WGN = 2, NW = 4;
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * ROW_BYTES;
     const int tid = threadIdx.x;
@@ -1068,44 +1070,61 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_asm(const GemmArgs g)
     unsigned long long* dbg = (blockIdx.x == 7) ? &g_gemm_stamps[wave][0] : &g_gemm_stamps[4][0];
     const unsigned long long t_before = __builtin_readcyclecounter();
 #endif
-    asm volatile(
+#define GEMM_ASM_OPERANDS                                                                                                           \
+    [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk), [sa] "s"(sa), \
+        [sb] "s"(sb), [ao] "v"(ao), [bo] "v"(bo), [wb] "v"(wb), [fa0] "v"(fa0), [fa1] "v"(fa1), [fb0] "v"(fb0), [fb1] "v"(fb1)
+    if constexpr (BN == 256) {
+        asm volatile(
 #ifdef GEMM_ASM_STAMPS
 #include "gemm_asm_192x256_stamps.inc"
 #else
 #include "gemm_asm_192x256.inc"
 #endif
-        :
-        : [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk),
-          [sa] "s"(sa), [sb] "s"(sb), [ao] "v"(ao), [bo] "v"(bo), [wb] "v"(wb), [fa0] "v"(fa0), [fa1] "v"(fa1), [fb0] "v"(fb0),
-          [fb1] "v"(fb1)
+            :
+            : GEMM_ASM_OPERANDS
 #ifdef GEMM_ASM_STAMPS
-          , [dbg] "s"(dbg)
+              , [dbg] "s"(dbg)
 #endif
-        :
+            :
 #include "gemm_asm_192x256_clobbers.inc"
-    );
+        );
+    } else {
+        asm volatile(
+#include "gemm_asm_192x128.inc"
+            :
+            : GEMM_ASM_OPERANDS
+            :
+#include "gemm_asm_192x128_clobbers.inc"
+        );
+    }
+#undef GEMM_ASM_OPERANDS
 #ifdef GEMM_ASM_STAMPS
     const unsigned long long t_after = __builtin_readcyclecounter();
 #endif
     __syncthreads();  // every wave is done with the K-tile slots before the epilogue scratch reuses them
-    // Epilogue: 32 rows x 128 columns at a time through 16 KB of LDS scratch per wave (assembly dump, see the generator), then a
-    // rolled loop over row pairs: one 16-byte column group per lane, two rows per iteration.
+    // Epilogue: 32 rows x WN columns at a time through the wave's LDS scratch (assembly dump, see the generator), then a rolled loop:
+    // one 16-byte column group per lane, 256 / WN rows per iteration.
+    constexpr int LPR = WN / 4, RPI = 64 / LPR;  // lanes per row, rows per iteration
     float* scr = (float*)(smem + wave * (32 * WN * 4));
     // LDS byte address of this lane's first scratch element (the dynamic LDS of this kernel starts at 0, as the main loop assumes)
     const unsigned scr_lane = (unsigned)(wave * (32 * WN * 4) + ((((lane >> 4) * 4) * WN + (lane & 15)) * 4));
     const GemmEpilogue& ep = g.ep;
-    const int gn = n0 + wc * WN + (lane & 31) * 4;
+    const int gn = n0 + wc * WN + (lane % LPR) * 4;
     const f32x4 bias = ep.bias_n ? *(const f32x4*)(ep.bias_n + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
     const float* rbase = ep.resid_src ? ep.resid_src : ep.out_f32;
     const long rld = ep.resid_src ? ep.ld_resid : ep.ld_f32;
     static_for<0, 3>([&](auto grp_c) {
         constexpr int grp = decltype(grp_c)::value;
+        if constexpr (BN == 256) {
 #include "gemm_asm_192x256_dump.inc"
+        } else {
+#include "gemm_asm_192x128_dump.inc"
+        }
 #pragma unroll 2
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 2 + (lane >> 5);
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + lane / LPR;
             const int gm = m0 + wr * WM + grp * 32 + row;
-            f32x4 v = *(const f32x4*)(scr + row * WN + (lane & 31) * 4);
+            f32x4 v = *(const f32x4*)(scr + row * WN + (lane % LPR) * 4);
             v += bias;
             if (ep.bias_m) {
                 const float bm = ep.bias_m[gm];
@@ -1218,19 +1237,21 @@ void validate(const GemmArgs& a) {
 
 }  // namespace
 
+template <int BN>
 static bool gemm_asm_takes(const GemmArgs& a) {
-    return !a.conv && a.split_k <= 1 && a.M % 192 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 64 && !a.ep.d2s;
+    return !a.conv && a.split_k <= 1 && a.M % 192 == 0 && a.N % BN == 0 && a.K % 64 == 0 && a.K >= 64 && !a.ep.d2s;
 }
+template <int BN>
 static void launch_asm(const GemmArgs& a, hipStream_t stream) {
-    LTX_REQUIRE(gemm_asm_takes(a), "gemm: the assembly kernel needs a dense A.B^T with M %% 192 == 0, N %% 256 == 0, K %% 64 == 0 (M=%d N=%d K=%d)",
-                a.M, a.N, a.K);
-    constexpr int smem = 2 * (192 + 256) * ROW_BYTES;
+    LTX_REQUIRE(gemm_asm_takes<BN>(a), "gemm: the assembly kernel needs a dense A.B^T with M %% 192 == 0, N %% %d == 0, K %% 64 == 0 (M=%d N=%d K=%d)",
+                BN, a.M, a.N, a.K);
+    constexpr int smem = 2 * (192 + BN) * ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_asm, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_asm<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_kernel_asm, dim3((a.M / 192) * (a.N / 256)), dim3(256), smem, stream, a);
+    hipLaunchKernelGGL(gemm_bf16_kernel_asm<BN>, dim3((a.M / 192) * (a.N / BN)), dim3(256), smem, stream, a);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1260,7 +1281,8 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 22: { GemmArgs b = a; b.group_m = 0; launch_v2<192, 128, 4, false, 4, 2>(b, stream); break; }  // A/B: column-major order
             case 23: launch_v2<256, 128, 3, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
-            case 71: launch_asm(a, stream); break;           // one wave per SIMD, assembly main loop, 192x256
+            case 71: launch_asm<256>(a, stream); break;      // one wave per SIMD, assembly main loop, 192x256
+            case 72: launch_asm<128>(a, stream); break;      // the same, 192x128
             case 41: launch_v4<192, 256>(a, stream); break;  // ping-pong, 8 waves (2x4), per-wave 96x64
             case 42: launch_v4<256, 256>(a, stream); break;  // ping-pong, per-wave 128x64
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
@@ -1322,7 +1344,7 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
     // not free) and its epilogue (10 us for 50 MB of output, every workgroup at the same time) is exposed once per launch.
     // LTX_GEMM_ASM=1 opts in for launches that fill the chip at least twice with 192x256 tiles (A/B runs).
     static const bool asm_on = getenv("LTX_GEMM_ASM") && getenv("LTX_GEMM_ASM")[0] == '1';
-    if (asm_on && gemm_asm_takes(a)) {
+    if (asm_on && gemm_asm_takes<256>(a)) {
         const long tiles_asm = (long)(a.M / 192) * (a.N / 256);
         if (tiles_asm >= 512 && tiles_asm % 256 == 0 && a.K <= 8192) {
             launch_gemm_bf16_cfg(a, 71, stream);

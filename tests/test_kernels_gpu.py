@@ -61,21 +61,22 @@ def test_gemm_split_k_integer_exact(gpu_ctx, M, N, K, S, cfg):
     assert np.array_equal(as_f32(outb), torch.from_numpy(ref).to(torch.bfloat16).float().numpy())
 
 
+@pytest.mark.parametrize("cfg", [71, 72])
 @pytest.mark.parametrize("M,N,K,reps", [(192, 256, 64, 1), (192, 256, 128, 1), (384, 512, 448, 1), (192, 768, 7 * 64, 1), (576, 256, 13 * 64, 2),
                                         (1536, 2048, 4096, 4), (768, 4096, 1024, 3)])
-def test_gemm_assembly_kernel_integer_exact(gpu_ctx, M, N, K, reps):
-    """One-wave-per-SIMD kernel with the assembly main loop (tile 192x256, three register sets, six-tile loop body left after
-    any tile): bit-exact on integer data for 1, 2, 7, 13 and 64 K-tiles - every exit point of the loop body and both LDS slots -
+def test_gemm_assembly_kernel_integer_exact(gpu_ctx, cfg, M, N, K, reps):
+    """One-wave-per-SIMD kernels with the generated assembly main loop (tile 192x256 = cfg 71, 192x128 = cfg 72; three register
+    sets, six-tile loop body left after any tile): bit-exact on integer data for 1, 2, 7, 13 and 64 K-tiles - every exit point of the loop body and both LDS slots -
     with bias, an f32 and a bf16 output through its own epilogue; the large shapes are repeated with fresh operands to screen the
     register-set / LDS-slot rotation for races (a stale or early-read tile shows as a wrong integer)."""
     for r in range(reps):
-        rng = np.random.default_rng(M + N + K + 71 + 1000 * r)
+        rng = np.random.default_rng(M + N + K + cfg + 1000 * r)
         A = rng.integers(-3, 4, (M, K)).astype(np.float32)
         B = rng.integers(-3, 4, (N, K)).astype(np.float32)
         bias = rng.integers(-5, 6, (N,)).astype(np.float32)
         out = torch.empty((M, N), device="cuda")
         outb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
-        gpu_ctx.op_gemm(dev_bf16(A), dev_bf16(B), dev_f32(bias), tile_cfg=71, out_f32=out, out_bf16=outb)
+        gpu_ctx.op_gemm(dev_bf16(A), dev_bf16(B), dev_f32(bias), tile_cfg=cfg, out_f32=out, out_bf16=outb)
         torch.cuda.synchronize()
         ref = A @ B.T + bias
         got = as_f32(out)

@@ -35,16 +35,24 @@ Register map (per wave):
 """
 import os
 
-SET = (0, 56, 112)
-FA = (168, 192)
-RING = 216
+import sys
+
+BN = 128 if "--bn128" in sys.argv else 256   # workgroup tile 192 x BN; wave tile 96 x BN/2
+MI, NI = 6, BN // 32
+NB = BN // 32          # B pieces (8 rows x 128 B) per wave and K-tile
+NL = 6 + NB            # global loads / ds_writes per wave and K-tile
+SETSZ = 4 * NL
+SET = (0, SETSZ, 2 * SETSZ)
+FA = (3 * SETSZ, 3 * SETSZ + 24)
+RING = 3 * SETSZ + 48
 R = 6      # B fragment ring depth; a fragment is read R-1 fragments (6 MFMAs each) ahead of its first MFMA
 S1 = RING + 4 * R  # wbase1, fa0_1, fa1_1, fb0_1, fb1_1
 NV = S1 + 5
 A_BYTES = 192 * 128
-STAGE = (192 + 256) * 128  # 57344
-MI, NI = 6, 8
-SOFF = 50  # s50..s55: A pieces, s56..s63: B pieces
+STAGE = (192 + BN) * 128
+TAILF = 2 if NI == 8 else 1   # B fragments whose MFMAs run after the barrier (with the next tile's entry reads in between)
+SOFF = 50  # s50..s55: A pieces, s56..: B pieces
+NAME = f"192x{BN}"
 
 
 def vr(b, n=4):
@@ -110,7 +118,7 @@ class Gen:
             self.e(f"buffer_load_dwordx4 {vr(SET[set_] + 4 * i)}, %[bo], s[40:43], s{SOFF + i} offen")
 
     def advance_k(self):
-        for i in range(14):
+        for i in range(NL):
             self.e(f"s_add_u32 s{SOFF + i}, s{SOFF + i}, 128")
 
     def write(self, set_, slot, i):
@@ -124,19 +132,22 @@ class Gen:
         of k-step 0, in the ENTRY order (B fragment R-2 last: its ring slot is the one fragment 14 of the previous tile uses)."""
         kind, x = self.ENTRY[k]
         if kind == "B":
-            self.read_b(slot, 0, x, (phase + x) % R)
+            self.read_b(slot, x // NI, x % NI, (phase + x) % R)   # with four fragments per k-step, fragment 4 is k-step 1's first
         else:
             self.read_a(slot, 0, x)
 
     def tile(self, j):
         """Tile body j of the six-tile loop: LDS slot j%2, loads into set j%3, ds_writes from set (j+1)%3, ring phase j%3."""
         p, q = j % 2, 1 - j % 2
-        ph = (16 * j) % R  # ring slot of this tile's B fragment 0
+        ph = (2 * NI * j) % R  # ring slot of this tile's B fragment 0
         e = self.e
         e(f"; ================= K-tile body {j}: slot {p}, loads -> set {j % 3}, writes <- set {(j + 1) % 3} =================")
-        loads = list(range(14))
-        writes = list(range(14))
+        loads = list(range(NL))
+        writes = list(range(NL))
         na1 = 0
+        pre = MI * (NI - TAILF)                     # MFMAs of k-step 1 before the barrier
+        a1_at = [MI + (i * (MI * NI - MI)) // 6 + 1 for i in range(6)]   # MFMAs of k-step 0 after which an A(k-step 1) read goes
+        wr_at = [1 + (i * (pre - 2)) // NL for i in range(NL)]          # MFMAs of k-step 1 after which a ds_write goes
         self.log = None
         tail_mfmas = []
         self.stamp_on = j == 0
@@ -144,12 +155,12 @@ class Gen:
         for ks in range(2):
             if ks == 1:
                 self.stamp(1)
-                e("s_waitcnt vmcnt(28)")  # tile t+1 has landed in its register set; tiles t+2 and t+3 may fly
+                e(f"s_waitcnt vmcnt({2 * NL})")  # tile t+1 has landed in its register set; tiles t+2 and t+3 may fly
                 self.stamp(2)
             for ni in range(NI):
                 f = ks * NI + ni  # B fragment index within the tile
                 ring = (ph + f) % R
-                tail = ks == 1 and ni >= 6  # after the barrier
+                tail = ks == 1 and ni >= NI - TAILF  # after the barrier
                 for mi in range(MI):
                     m = ni * MI + mi  # MFMA index within the k-step
                     text = f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {vr(FA[ks] + 4 * mi)}, {vr(RING + 4 * ring)}, {acc(mi, ni)}"
@@ -168,15 +179,15 @@ class Gen:
                     if ks == 0:
                         if m % 2 == 1 and loads:
                             self.load(j % 3, loads.pop(0))
-                        if m >= 6 and m % 6 == 3 and na1 < MI:
+                        while na1 < MI and a1_at[na1] <= m:
                             self.read_a(p, 1, na1)
                             na1 += 1
                     else:
-                        if m % 2 == 1 and writes:
+                        while writes and wr_at[NL - len(writes)] <= m:
                             self.write((j + 1) % 3, q, writes.pop(0))
                 if ks == 0 and ni == NI - 1:
                     assert na1 == MI and not loads, (na1, loads)
-                if ks == 1 and ni == 5:
+                if ks == 1 and ni == NI - TAILF - 1:
                     assert not writes, writes
                     self.stamp(3)
                     e("s_waitcnt lgkmcnt(0)")
@@ -186,14 +197,17 @@ class Gen:
         # tail: the last 12 MFMAs (B fragments 14, 15 are in their ring slots) with the entry reads of tile t+1 between them. The
         # next tile's fragment 0 goes to the ring slot fragment 13 used (free), its fragment 1 to the slot of fragment 14 - read
         # only once fragment 14's six MFMAs are issued.
-        nph = (ph + 16) % R
+        nph = (ph + 2 * NI) % R
         self.log = []
         k = 0
         ne = len(self.ENTRY)
         for idx, text in enumerate(tail_mfmas):
             e(text)
             # one entry read per MFMA; the last one (B fragment R-2, ring slot of fragment 14) only after fragment 14's six MFMAs
-            while k < ne and (k <= idx if k < ne - 1 else idx >= 6 and k <= idx):
+            # the last entry read (B fragment R-2) reuses the ring slot of fragment 2NI-2: with two tail fragments it waits for that
+            # fragment's six MFMAs; entry reads go two per MFMA when the tail is one fragment long
+            per = 1 if TAILF == 2 else 2
+            while k < ne and (k < per * (idx + 1) if (k < ne - 1 or TAILF == 1) else idx >= MI and k < per * (idx + 1)):
                 self.entry_read(q, nph, k)
                 k += 1
         while k < ne:
@@ -220,7 +234,7 @@ class Gen:
         for i in range(1, 6):
             e(f"s_add_u32 s{SOFF + i}, s{SOFF + i - 1}, %[sa]")   # piece i of A: rows 32 i .. of the tile
         e(f"s_mov_b32 s{SOFF + 6}, 0")
-        for i in range(7, 14):
+        for i in range(7, NL):
             e(f"s_add_u32 s{SOFF + i}, s{SOFF + i - 1}, %[sb]")
         e(f"v_add_u32 v{S1}, {STAGE}, %[wb]")
         for ks in range(2):
@@ -229,11 +243,11 @@ class Gen:
         for i in range(MI * NI * 4):
             e(f"v_accvgpr_write_b32 a{i}, 0")
         for t in range(3):  # tiles 0, 1, 2 -> register sets 0, 1, 2
-            for i in range(14):
+            for i in range(NL):
                 self.load(t, i)
             self.advance_k()
-        e("s_waitcnt vmcnt(28)")
-        for i in range(14):
+        e(f"s_waitcnt vmcnt({2 * NL})")
+        for i in range(NL):
             self.write(0, 0, i)
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
@@ -271,12 +285,12 @@ def main():
     lines = g.build()
     here = os.path.dirname(os.path.abspath(__file__))
     d = os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc")
-    with open(os.path.join(d, "gemm_asm_192x256_stamps.inc" if STAMPS else "gemm_asm_192x256.inc"), "w") as f:
+    with open(os.path.join(d, f"gemm_asm_{NAME}_stamps.inc" if STAMPS else f"gemm_asm_{NAME}.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py - do not edit. gfx950 assembly main loop of gemm_bf16_kernel_asm (gemm.hip).\n")
         for ln in lines:
             f.write('"' + ln + '\\n\\t"\n')
-    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(192)] + [f"s{i}" for i in range(36, 76)] + ["vcc", "scc", "memory"]
-    with open(os.path.join(d, "gemm_asm_192x256_clobbers.inc"), "w") as f:
+    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(MI * NI * 4)] + [f"s{i}" for i in range(36, 76)] + ["vcc", "scc", "memory"]
+    with open(os.path.join(d, f"gemm_asm_{NAME}_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py - do not edit. Registers the assembly main loop assigns by hand.\n")
         for i in range(0, len(clob), 12):
             f.write(", ".join('"' + c + '"' for c in clob[i:i + 12]) + ("," if i + 12 < len(clob) else "") + "\n")
@@ -285,7 +299,7 @@ def main():
     # the accumulators into C++ values made the compiler unroll the generic epilogue over 6 slabs x 8 row pairs: ~2000 basic
     # blocks of straight-line code run once by one wave per SIMD - 53 000 cycles of instruction fetch per tile.)
     # lane (c = lane & 15, g = lane >> 4) holds acc[mi][ni][r] = C[mi*16 + 4g + r][ni*16 + c]; %[sb] = scratch + ((4g)*128 + c)*4.
-    with open(os.path.join(d, "gemm_asm_192x256_dump.inc"), "w") as f:
+    with open(os.path.join(d, f"gemm_asm_{NAME}_dump.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py - do not edit. if constexpr (grp == G): slabs 2G, 2G+1 of a[0:191] -> LDS scratch.\n")
         for grp in range(3):
             ins = []
@@ -297,7 +311,7 @@ def main():
                         ins.append(f"v_accvgpr_read_b32 v{r}, a{base + r}")
                     ins.append("s_nop 0")
                     for r in range(4):
-                        ins.append(f"ds_write_b32 %[sb], v{r} offset:{((half * 16 + r) * 128 + ni * 16) * 4}")
+                        ins.append(f"ds_write_b32 %[sb], v{r} offset:{((half * 16 + r) * (16 * NI) + ni * 16) * 4}")
             ins.append("s_waitcnt lgkmcnt(0)")
             body = "".join(x + "\\n\\t" for x in ins)
             f.write(f'if constexpr (grp == {grp}) asm volatile("{body}" : : [sb] "v"(scr_lane) : "v0", "v1", "v2", "v3", "memory");\n')
