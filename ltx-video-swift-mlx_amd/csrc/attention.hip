@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_ref(const AttnArgs
 
 
 #ifdef W48_STAMPS
-__device__ unsigned long long g_w48_stamps[8][8];
+__device__ unsigned long long g_w48_stamps[8][32];
 #endif
 // The same kernel with the main loop in assembly (generated by tools/gen_attn_w48.py from the layout above; register map and
 // schedule in that script's header). C++ only prepares the per-lane offsets and the uniform operands.

@@ -1269,6 +1269,7 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 21: launch_v2<192, 128, 4, true, 4, 2>(a, stream); break;   // 8 waves (4x2), per-wave 48x64, 4-slot ring
             case 23: launch_v2<256, 128, 3, true, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, true, 2, 4>(a, stream); break;
+            case 27: launch_v2<256, 64, 4, true, 4, 2>(a, stream); break;   // narrow outputs (the VAE's 128 -> 48 conv_out): per-wave 64x32
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
         }
     } else {
@@ -1318,7 +1319,9 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
         // the two-stage 4-wave kernel serialises it and ran the 256-channel VAE stage at 150 TFLOP/s). M is huge, so
         // tile-count quantisation does not matter; N <= 128 wants the 192x128 tile, wide N the same (B re-use).
         const char* cc = getenv("LTX_CONV_CFG");  // A/B hook for tile experiments (21 = 192x128 ring, 23 = 256x128 ring)
-        launch_gemm_bf16_cfg(a, (cc && a.split_k <= 1) ? atoi(cc) : 21, stream);
+        // N <= 64 (the decoder's conv_out, 128 -> 48 channels): a 192x128 tile spends 62 % of its MFMAs on padding columns
+        const int conv_default = (a.N <= 64 && a.split_k <= 1) ? 27 : 21;
+        launch_gemm_bf16_cfg(a, (cc && a.split_k <= 1) ? atoi(cc) : conv_default, stream);
         return;
     }
     if (a.split_ws && a.split_k == 0) {

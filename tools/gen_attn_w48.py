@@ -381,8 +381,15 @@ class Gen:
         self.e("s_barrier")
         st(4)
 
+    def kstamp(self, i):
+        """--stamps build: whole-kernel stamps (start, prologue done, loop done, stores issued) in s[76+2i : 77+2i]."""
+        if self.stamps:
+            self.e(f"s_memtime s[{76 + 2 * i}:{77 + 2 * i}]")
+            self.e("s_waitcnt lgkmcnt(0)")
+
     def build(self):
         e = self.e
+        self.kstamp(0)
         e("; ---- descriptors, constants ----")
         e("s_mov_b32 s36, %[kblo]")
         e("s_mov_b32 s37, %[kbhi]")
@@ -448,6 +455,7 @@ class Gen:
         for ins in self.sm_max(SA):
             e(ins)
         self.sm_check_and_rare_path("9", SA, force=True)
+        self.kstamp(1)
         e("10:")
         self.step(0, SA, SB, 11)
         self.step(1, SB, SA, 12)
@@ -455,6 +463,7 @@ class Gen:
         self.step(3, SB, SA, 14)
         e("s_branch 10b")
         e("30:")
+        self.kstamp(2)
         e("; ---- epilogue ----")
         e("s_waitcnt vmcnt(0)")
         e("s_nop 7")
@@ -474,13 +483,21 @@ class Gen:
                 e(f"v_cvt_pk_bf16_f32 v{RT + 5}, v{RT + 1}, v{RT + 2}")   # v[192:193]: 64-bit aligned store data
                 e(f"v_cvt_pk_bf16_f32 v{RT + 6}, v{RT + 3}, v{RT + 4}")
                 e(f"buffer_store_dwordx2 v[{RT + 5}:{RT + 6}], %[oo{qb}], s[60:63], 0 offen offset:{db * 32}")
-        e("s_waitcnt vmcnt(0)")
+        # no wait for the stores: they may complete after the wave ends (the LDS-DMA issued past the last tile was waited for above)
+        if self.stamps:
+            e("s_waitcnt vmcnt(0)")
+        self.kstamp(3)
         if self.stamps:  # lane 0 of every wave writes its 5 stamps: dbg[wave][5] u64
             for i in range(10):
                 e(f"v_mov_b32 v{PF + i}, s{64 + i}")
             e(f"v_mov_b32 v{PF + 10}, 0")
             for i in range(5):
                 e(f"global_store_dwordx2 v{PF + 10}, v[{PF + 2 * i}:{PF + 2 * i + 1}], %[dbg] offset:{i * 8}")
+            e("s_waitcnt vmcnt(0)")
+            for i in range(8):
+                e(f"v_mov_b32 v{PF + i}, s{76 + i}")
+            for i in range(4):
+                e(f"global_store_dwordx2 v{PF + 10}, v[{PF + 2 * i}:{PF + 2 * i + 1}], %[dbg] offset:{128 + i * 8}")
             e("s_waitcnt vmcnt(0)")
         return self.lines
 
@@ -497,7 +514,7 @@ def main():
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. gfx950 assembly body of attn_fwd_kernel_w48_asm (attention.hip).\n")
         for ln in lines:
             f.write('"' + ln.replace('"', '\\"') + '\\n\\t"\n')
-    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(LACC + 12)] + [f"s{i}" for i in range(36, 76)] + ["m0", "vcc", "scc", "memory"]
+    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(LACC + 12)] + [f"s{i}" for i in range(36, 84)] + ["m0", "vcc", "scc", "memory"]
     with open(os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", "attention_w48_bias_clobbers.inc" if BIAS else "attention_w48_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. Registers the assembly body assigns by hand.\n")
         for i in range(0, len(clob), 12):

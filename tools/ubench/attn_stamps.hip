@@ -13,7 +13,7 @@ void Profiler::end(ProfRec*, hipStream_t) {}
 #include <vector>
 
 int main() {
-    const int T = 6144, H = 32, D = 4096;
+    const int T = getenv("ATTN_T") ? atoi(getenv("ATTN_T")) : 6144, H = 32, D = 4096;
     std::vector<bf16_t> h((size_t)T * D);
     for (size_t i = 0; i < h.size(); ++i) h[i] = host_f32_to_bf16((float)((i * 2654435761u >> 20) & 255) / 256.f - 0.5f);
     bf16_t *q, *k, *vt, *o;
@@ -29,13 +29,15 @@ int main() {
     for (int it = 0; it < 3; ++it) launch_attention(a, 0);
     hipDeviceSynchronize();
     {
-        unsigned long long st[8][8];
+        unsigned long long st[8][32];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(g_w48_stamps), sizeof(st));
         printf("48-query assembly kernel, one tile step (ring slot 0 of the last loop iteration), cycles:\n");
         printf("wave | A: QK+exp/pack  B1: PV k-step 0 + pack  B2: PV k-step 1 + maxima + DMA + check  vmcnt+barrier | step\n");
         for (int w = 0; w < 4; ++w)
             printf("  %d  | %8llu %16llu %14llu %16llu       | %llu\n", w, st[w][1] - st[w][0], st[w][2] - st[w][1], st[w][3] - st[w][2],
                    st[w][4] - st[w][3], st[w][4] - st[w][0]);
+        printf("whole kernel, wave 0 (T = %d, %d key tiles): prologue %llu cycles, tile loop %llu, epilogue %llu\n", T, T / 64,
+               st[0][17] - st[0][16], st[0][18] - st[0][17], st[0][19] - st[0][18]);
         return 0;
     }
 #endif
