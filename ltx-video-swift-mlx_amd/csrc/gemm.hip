@@ -1354,6 +1354,19 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
             return;
         }
     }
+    // A/B hook for in-pipeline tile experiments: LTX_GEMM_FORCE="8192:21,16384:21" forces a tile cfg for dense launches by N
+    if (const char* f = getenv("LTX_GEMM_FORCE")) {
+        for (const char* q = f; *q;) {
+            const long n = strtol(q, (char**)&q, 10);
+            if (*q != ':') break;
+            const long c = strtol(q + 1, (char**)&q, 10);
+            if (n == a.N) {
+                launch_gemm_bf16_cfg(a, (int)c, stream);
+                return;
+            }
+            if (*q == ',') ++q;
+        }
+    }
     int best = 0;
     double be = -1;
     for (const Cand& c : cands) {
