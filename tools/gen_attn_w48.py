@@ -410,6 +410,24 @@ class Gen:
             e(f"v_add_u32 v{HI + ks}, 0x10000, %[ka{ks}]")
         for i in range(2):
             e(f"v_add_u32 v{HI + 4 + i}, 0x10000, %[va{i}]")
+        # the long-latency work first: K / Vt tiles 0..2 (and the bias vector), then the Q fragments, then register init
+        e("; ---- tiles 0, 1, 2 ----")
+        for t in range(3):
+            for grp in self.stage(t):
+                for ins in grp:
+                    e(ins)
+            self.advance_stage_offsets()
+        if BIAS:
+            e("; ---- bias vector -> LDS (16 KB after the ring; the descriptor ends after key Tk-1: zeros beyond) ----")
+            e("s_mov_b32 s56, %[bilo]")
+            e("s_mov_b32 s57, %[bihi]")
+            e("s_mov_b32 s58, %[birec]")
+            e("s_mov_b32 s59, 0x00020000")
+            for i in range(4):
+                e(f"s_add_u32 m0, %[wlds], {BIAS_LDS + i * 4096}")
+                e(f"s_add_u32 s47, %[wlds], {i * 4096}")
+                e("buffer_load_dwordx4 %[bvo], s[56:59], s47 offen lds")
+            e(f"v_mov_b32 v{BADDR}, %[ba]")
         e("; ---- Q fragments ----")
         for qb in range(3):
             for ks in range(4):
@@ -422,23 +440,6 @@ class Gen:
         e(f"v_mov_b32 v{FLOOR}, 0xff800000")
         for j in range(4):
             e(f"v_mov_b32 v{ONES + j}, 0x3f803f80")
-        if BIAS:
-            e("; ---- bias vector -> LDS (16 KB after the ring; the descriptor ends after key Tk-1: zeros beyond) ----")
-            e("s_mov_b32 s56, %[bilo]")
-            e("s_mov_b32 s57, %[bihi]")
-            e("s_mov_b32 s58, %[birec]")
-            e("s_mov_b32 s59, 0x00020000")
-            for i in range(4):
-                e(f"s_add_u32 m0, %[wlds], {BIAS_LDS + i * 4096}")
-                e(f"s_add_u32 s47, %[wlds], {i * 4096}")
-                e("buffer_load_dwordx4 %[bvo], s[56:59], s47 offen lds")
-            e(f"v_mov_b32 v{BADDR}, %[ba]")
-        e("; ---- tiles 0, 1, 2 ----")
-        for t in range(3):
-            for grp in self.stage(t):
-                for ins in grp:
-                    e(ins)
-            self.advance_stage_offsets()
         e("s_waitcnt vmcnt(0)")
         e("s_barrier")
         for kind, text in self.qk_stream(SA, 0):
