@@ -1031,10 +1031,11 @@ void launch_one(const GemmArgs& a, hipStream_t stream) {
 #ifdef GEMM_ASM_STAMPS
 __device__ unsigned long long g_gemm_stamps[5][8];
 #endif
-template <int BN>
+template <int BN, bool RING = false>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_asm(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(BN == 256 || BN == 128, "generated main loops exist for 192x256 and 192x128");
+    static_assert(!RING || BN == 128, "the LDS-DMA ring variant exists for 192x128");
     constexpr int BM = 192, WGM = 2, WGN = 2, NW = 4;
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * ROW_BYTES;
@@ -1073,7 +1074,19 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_asm(const GemmArgs g)
 #define GEMM_ASM_OPERANDS                                                                                                           \
     [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk), [sa] "s"(sa), \
         [sb] "s"(sb), [ao] "v"(ao), [bo] "v"(bo), [wb] "v"(wb), [fa0] "v"(fa0), [fa1] "v"(fa1), [fb0] "v"(fb0), [fb1] "v"(fb1)
-    if constexpr (BN == 256) {
+    if constexpr (RING) {
+        // tile_cfg 73: the same wave tile, K-tiles staged by LDS-DMA into four 40 KB slots (tools/gen_gemm_asm_ring.py)
+        const uint32_t wlds = (uint32_t)wave * 1024u;
+        asm volatile(
+#include "gemm_asm_ring_192x128.inc"
+            :
+            : [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk),
+              [sa] "s"(sa), [sb] "s"(sb), [wlds] "s"(wlds), [ao] "v"(ao), [bo] "v"(bo), [fa0] "v"(fa0), [fa1] "v"(fa1),
+              [fb0] "v"(fb0), [fb1] "v"(fb1)
+            :
+#include "gemm_asm_ring_192x128_clobbers.inc"
+        );
+    } else if constexpr (BN == 256) {
         asm volatile(
 #ifdef GEMM_ASM_STAMPS
 #include "gemm_asm_192x256_stamps.inc"
@@ -1241,17 +1254,17 @@ template <int BN>
 static bool gemm_asm_takes(const GemmArgs& a) {
     return !a.conv && a.split_k <= 1 && a.M % 192 == 0 && a.N % BN == 0 && a.K % 64 == 0 && a.K >= 64 && !a.ep.d2s;
 }
-template <int BN>
+template <int BN, bool RING = false>
 static void launch_asm(const GemmArgs& a, hipStream_t stream) {
     LTX_REQUIRE(gemm_asm_takes<BN>(a), "gemm: the assembly kernel needs a dense A.B^T with M %% 192 == 0, N %% %d == 0, K %% 64 == 0 (M=%d N=%d K=%d)",
                 BN, a.M, a.N, a.K);
-    constexpr int smem = 2 * (192 + BN) * ROW_BYTES;
+    constexpr int smem = (RING ? 4 : 2) * (192 + BN) * ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_asm<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_asm<BN, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_kernel_asm<BN>, dim3((a.M / 192) * (a.N / BN)), dim3(256), smem, stream, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel_asm<BN, RING>), dim3((a.M / 192) * (a.N / BN)), dim3(256), smem, stream, a);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1284,6 +1297,7 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
             case 71: launch_asm<256>(a, stream); break;      // one wave per SIMD, assembly main loop, 192x256
             case 72: launch_asm<128>(a, stream); break;      // the same, 192x128
+            case 73: launch_asm<128, true>(a, stream); break;  // 192x128, one wave per SIMD, LDS-DMA ring of four slots
             case 41: launch_v4<192, 256>(a, stream); break;  // ping-pong, 8 waves (2x4), per-wave 96x64
             case 42: launch_v4<256, 256>(a, stream); break;  // ping-pong, per-wave 128x64
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
