@@ -1078,11 +1078,18 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_asm(const GemmArgs g)
         // tile_cfg 73: the same wave tile, K-tiles staged by LDS-DMA into four 40 KB slots (tools/gen_gemm_asm_ring.py)
         const uint32_t wlds = (uint32_t)wave * 1024u;
         asm volatile(
+#ifdef GEMM_ASM_STAMPS
+#include "gemm_asm_ring_192x128_stamps.inc"
+#else
 #include "gemm_asm_ring_192x128.inc"
+#endif
             :
             : [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk),
               [sa] "s"(sa), [sb] "s"(sb), [wlds] "s"(wlds), [ao] "v"(ao), [bo] "v"(bo), [fa0] "v"(fa0), [fa1] "v"(fa1),
               [fb0] "v"(fb0), [fb1] "v"(fb1)
+#ifdef GEMM_ASM_STAMPS
+              , [dbg] "s"(dbg)
+#endif
             :
 #include "gemm_asm_ring_192x128_clobbers.inc"
         );
@@ -1374,7 +1381,8 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
             const long n = strtol(q, (char**)&q, 10);
             if (*q != ':') break;
             const long c = strtol(q + 1, (char**)&q, 10);
-            if (n == a.N) {
+            const bool takes = c == 71 ? gemm_asm_takes<256>(a) : (c == 72 || c == 73) ? gemm_asm_takes<128>(a) : true;
+            if (n == a.N && takes) {
                 launch_gemm_bf16_cfg(a, (int)c, stream);
                 return;
             }

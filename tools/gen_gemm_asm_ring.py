@@ -36,6 +36,7 @@ STAGE = (192 + 128) * 128   # 40960
 NL = 10             # LDS-DMA pieces per wave and K-tile (6 A + 4 B)
 SOFF = 50
 STAMPS = "--stamps" in sys.argv
+ABLATE = set(filter(None, os.environ.get("GEMM_ABLATE", "").split(",")))   # nodma, nolds, nobar: timing experiments only (wrong results)
 
 
 def vr(b, n=4):
@@ -55,18 +56,31 @@ class Gen:
         self.lds_seq = 0
         self.ready = {}
         self.log = None
+        self.in_loop = False
 
     def e(self, s):
+        if self.in_loop and (("nodma" in ABLATE and s.startswith("buffer_load")) or ("nobar" in ABLATE and s == "s_barrier")):
+            return
+        if self.in_loop and "nolds" in ABLATE and s.startswith("s_waitcnt lgkmcnt"):
+            return
         self.lines.append(s)
 
     def lds(self, text, name):
+        if "nolds" in ABLATE and self.in_loop:
+            return
         self.e(text)
         self.ready[name] = self.lds_seq
         if self.log is not None:
             self.log.append(name)
         self.lds_seq += 1
 
+    def stamp(self, i, j):
+        if STAMPS and j == 0:
+            self.e(f"s_memtime s[{64 + 2 * i}:{65 + 2 * i}]")
+
     def need(self, name):
+        if "nolds" in ABLATE and self.in_loop:
+            return
         n = self.lds_seq - self.ready[name] - 1
         self.e(f"s_waitcnt lgkmcnt({min(n, 15)})")
 
@@ -107,7 +121,10 @@ class Gen:
         na1 = 0
         self.log = None
         tail = []
+        self.stamp(0, j)
         for ks in range(2):
+            if ks == 1:
+                self.stamp(1, j)
             for ni in range(NI):
                 f = ks * NI + ni
                 ring = f % R
@@ -137,8 +154,15 @@ class Gen:
                 if ks == 0 and ni == NI - 1:
                     assert na1 == MI and not dmas, (na1, len(dmas))
                 if ks == 1 and ni == NI - 2:
-                    e(f"s_waitcnt vmcnt({2 * NL}) lgkmcnt(0)")   # tile t+1 has landed for this wave; tiles t+2, t+3 may fly
+                    self.stamp(2, j)
+                    if STAMPS:
+                        e(f"s_waitcnt vmcnt({2 * NL})")
+                        self.stamp(3, j)
+                        e("s_waitcnt lgkmcnt(0)")
+                    else:
+                        e(f"s_waitcnt vmcnt({2 * NL}) lgkmcnt(0)")   # tile t+1 has landed for this wave; tiles t+2, t+3 may fly
                     e("s_barrier")
+                    self.stamp(4, j)
         self.advance_k()
         self.log = []
         k = 0
@@ -151,6 +175,9 @@ class Gen:
         while k < ne:
             self.entry_read(q, k)
             k += 1
+        self.stamp(5, j)
+        if STAMPS and j == 0:
+            e("s_waitcnt lgkmcnt(0)")
 
     def build(self):
         e = self.e
@@ -186,6 +213,7 @@ class Gen:
             self.entry_read(0, k)
         entry = list(self.log)
         e("10:")
+        self.in_loop = True
         for j in range(4):
             self.lds_seq = len(entry)
             self.ready = {name: k for k, name in enumerate(entry)}
@@ -194,11 +222,19 @@ class Gen:
             e("s_sub_u32 s46, s46, 1")
             e("s_cmp_eq_u32 s46, 0")
             e("s_cbranch_scc1 20f")
+        self.in_loop = False
         e("s_branch 10b")
         e("20:")
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
         e("s_nop 7")
         e("s_nop 7")
+        if STAMPS:
+            for i in range(12):
+                e(f"v_mov_b32 v{i}, s{64 + i}")
+            e("v_mov_b32 v12, 0")
+            for i in range(6):
+                e(f"global_store_dwordx2 v12, v[{2 * i}:{2 * i + 1}], %[dbg] offset:{i * 8}")
+            e("s_waitcnt vmcnt(0)")
         return self.lines
 
 
@@ -207,11 +243,11 @@ def main():
     lines = g.build()
     here = os.path.dirname(os.path.abspath(__file__))
     d = os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc")
-    with open(os.path.join(d, "gemm_asm_ring_192x128.inc"), "w") as f:
+    with open(os.path.join(d, "gemm_asm_ring_192x128_stamps.inc" if STAMPS or ABLATE else "gemm_asm_ring_192x128.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm_ring.py - do not edit. gfx950 assembly main loop of gemm_bf16_kernel_asm_ring (gemm.hip).\n")
         for ln in lines:
             f.write('"' + ln + '\\n\\t"\n')
-    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(MI * NI * 4)] + [f"s{i}" for i in range(36, 64)] + ["m0", "vcc", "scc", "memory"]
+    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(MI * NI * 4)] + [f"s{i}" for i in range(36, 76)] + ["m0", "vcc", "scc", "memory"]
     with open(os.path.join(d, "gemm_asm_ring_192x128_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm_ring.py - do not edit. Registers the assembly main loop assigns by hand.\n")
         for i in range(0, len(clob), 12):

@@ -27,15 +27,24 @@ int main() {
     if (ob) { g.ep.out_bf16 = (bf16_t*)c; g.ep.ld_bf16 = N; } else { g.ep.out_f32 = c; g.ep.ld_f32 = N; }
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int it = 0; it < 3; ++it) launch_gemm_bf16_cfg(g, 71, 0);
+    const int cfg = getenv("GEMM_CFG") ? atoi(getenv("GEMM_CFG")) : 71;
+    for (int it = 0; it < 3; ++it) launch_gemm_bf16_cfg(g, cfg, 0);
     (void)hipEventRecord(e0);
-    for (int it = 0; it < 10; ++it) launch_gemm_bf16_cfg(g, 71, 0);
+    for (int it = 0; it < 10; ++it) launch_gemm_bf16_cfg(g, cfg, 0);
     (void)hipEventRecord(e1);
     (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     printf("%dx%dx%d: %.1f us per launch, %.0f TFLOP/s\n", M, N, K, ms * 100, 2.0 * M * N * K / (ms / 10 * 1e-3) / 1e12);
     unsigned long long st[5][8];
     (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_gemm_stamps), sizeof(st));
+    if (cfg == 73) {
+        printf("tile_cfg 73, one K-tile body (last pass), cycles:\nwave | k-step 0 (24 MFMA + 10 LDS-DMA)  k-step 1 to the wait (18 MFMA)  vmcnt wait  lgkmcnt+barrier  tail (6 MFMA + entry reads) | tile\n");
+        for (int w = 0; w < 4; ++w)
+            printf("  %d  | %10llu %24llu %18llu %14llu %18llu              | %llu\n", w, st[w][1] - st[w][0], st[w][2] - st[w][1], st[w][3] - st[w][2],
+                   st[w][4] - st[w][3], st[w][5] - st[w][4], st[w][5] - st[w][0]);
+        printf("whole assembly block: %llu cycles; epilogue: %llu cycles (wave 0)\n", st[0][6], st[0][7]);
+        return 0;
+    }
     printf("one K-tile body (last pass), cycles:\nwave | k-step 0 (48 MFMA + loads)  vmcnt wait  k-step 1 up to the barrier (36 MFMA + ds_writes)  lgkmcnt+barrier  tail (12 MFMA + entry reads) | tile\n");
     for (int w = 0; w < 4; ++w)
         printf("  %d  | %10llu %20llu %22llu %30llu %20llu          | %llu\n", w, st[w][1] - st[w][0], st[w][2] - st[w][1], st[w][3] - st[w][2],
