@@ -23,11 +23,12 @@ struct GemmEpilogue {
     //   gate ? gate[(m / rows_per_batch) * gate_bstride + n] : gate_scalar
     // (reference residualGate: LTXTransformerBlock.swift:86-92; cross-attn scale :211-214)
     int resid = 0;
+    float gate_scalar = 1.0f;  // kept beside the other 4-byte fields: in a 16-byte slice shared with a pointer the kernels' by-value
+                               // argument copy is not promoted to registers and every epilogue read of it becomes a scratch load
     const float* gate = nullptr;
     long gate_bstride = 0;
     int rows_per_batch = 1;
     const int32_t* gate_rowmap = nullptr;  // optional: gate row of output row m = gate_rowmap[m] (per-token timestep groups, I2V)
-    float gate_scalar = 1.0f;
     const float* resid_src = nullptr;  // defaults to out_f32 (in-place) when null
     long ld_resid = 0;
     // depth-to-space store. 1: VAE upsampler (2,2,2) with first-frame drop and tiled D2S residual

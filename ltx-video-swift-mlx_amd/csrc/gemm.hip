@@ -70,8 +70,52 @@ LTX_DEVFN void tile_coords(const GemmArgs& g, int bid, int tiles_m, int BN_, int
 // `get(mi_c, slab)` hands over the 16-row slab mi of this wave's accumulators (f32x4 slab[NI]) - an array copy for the kernels
 // that accumulate in VGPRs, an AGPR read-out for the assembly kernel (whose 192 accumulator registers must never be live in
 // VGPRs all at once next to this function's prefetch buffers).
+// Residual-stream values of this wave's whole tile, loaded by the kernel under its last K-tiles (`gemm_residual_prefetch`) so that
+// the epilogue of a gated-residual GEMM - one workgroup per CU, nothing else resident - does not start with an exposed HBM read.
+template <int BM, int BN, int WGM, int WGN>
+struct ResidualTile {
+    static constexpr int MI = BM / WGM / 16, NIT = (16 * (BN / WGN / 4)) / 64;
+    f32x4 v[MI][NIT];
+    f32x4 bias[NIT];          // the column bias: what the epilogue's first slab waits on in launches without a residual
+    bool valid = false;       // v holds data
+    bool bias_valid = false;  // bias holds data
+};
+
+// Column bias of this wave's tile (every launch with interior columns), fetched under the last K-tiles as well.
+template <int BM, int BN, int WGM, int WGN>
+LTX_DEVFN void gemm_bias_prefetch(const GemmArgs& g, int n0, int wc, int lane, ResidualTile<BM, BN, WGM, WGN>& rt) {
+    constexpr int WN = BN / WGN, LPR = WN / 4, NIT = (16 * LPR) / 64;
+    const int gn_w = n0 + wc * WN;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c4 = ((it * 64 + lane) % LPR) * 4;
+        rt.bias[it] = g.ep.bias_n ? *(const f32x4*)(g.ep.bias_n + gn_w + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    rt.bias_valid = true;
+}
+
+template <int BM, int BN, int WGM, int WGN>
+LTX_DEVFN void gemm_residual_prefetch(const GemmArgs& g, int m0, int n0, int wr, int wc, int lane, ResidualTile<BM, BN, WGM, WGN>& rt) {
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, LPR = WN / 4, NIT = (16 * LPR) / 64;
+    const GemmEpilogue& ep = g.ep;
+    const float* rbase = ep.resid_src ? ep.resid_src : ep.out_f32;
+    const long rld = ep.resid_src ? ep.ld_resid : ep.ld_f32;
+    const int gn_w = n0 + wc * WN;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int chunk = it * 64 + lane;
+            int gm = m0 + wr * WM + mi * 16 + chunk / LPR;
+            gm = gm < g.M ? gm : g.M - 1;
+            rt.v[mi][it] = *(const f32x4*)(rbase + (long)gm * rld + gn_w + (chunk % LPR) * 4);
+        }
+    rt.valid = true;
+}
+
 template <int BM, int BN, int WGM = 2, int WGN = 2, class Get>
-LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, int wr, int wc, int lane, int wave, char* smem) {
+LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, int wr, int wc, int lane, int wave, char* smem,
+                                  const ResidualTile<BM, BN, WGM, WGN>* pre = nullptr) {
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
     float* scr = (float*)(smem + wave * (16 * WN * 4));
     constexpr int LPR = WN / 4;    // lanes per output row
@@ -83,12 +127,16 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
         // (the general path below) was costing 12-20 us per gated-residual GEMM (76.8 vs 57.1 us in the DiT block trace).
         constexpr int NIT = (16 * LPR) / 64;
         const bool has_res = ep.resid != 0;
+        const bool pre_res = pre && pre->valid;  // workgroup-uniform
         const int gn_w = n0 + wc * WN;
         f32x4 bias[NIT], rs[2][NIT], gt[2][NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c4 = ((it * 64 + lane) % LPR) * 4;
-            bias[it] = ep.bias_n ? *(const f32x4*)(ep.bias_n + gn_w + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (pre && pre->bias_valid)
+                bias[it] = pre->bias[it];
+            else
+                bias[it] = ep.bias_n ? *(const f32x4*)(ep.bias_n + gn_w + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const float* rbase = ep.resid_src ? ep.resid_src : ep.out_f32;
         const long rld = ep.resid_src ? ep.ld_resid : ep.ld_f32;
@@ -101,7 +149,10 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
                 const int c4 = (chunk % LPR) * 4;
                 int gm = m0 + wr * WM + mi * 16 + chunk / LPR;
                 gm = gm < g.M ? gm : g.M - 1;
-                rs[buf][it] = *(const f32x4*)(rbase + (long)gm * rld + gn_w + c4);
+                if (pre_res)
+                    rs[buf][it] = pre->v[mi][it];
+                else
+                    rs[buf][it] = *(const f32x4*)(rbase + (long)gm * rld + gn_w + c4);
                 if (ep.gate)
                     gt[buf][it] = *(const f32x4*)(ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[gm] : gm / ep.rows_per_batch) * ep.gate_bstride + gn_w + c4);
                 else
@@ -282,7 +333,7 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
 
 template <int BM, int BN, int WGM = 2, int WGN = 2>
 LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const GemmArgs& g, int m0, int n0, int wr, int wc,
-                             int lane, int wave, char* smem) {
+                             int lane, int wave, char* smem, const ResidualTile<BM, BN, WGM, WGN>* pre = nullptr) {
     constexpr int NI = BN / WGN / 16;
     gemm_epilogue_with<BM, BN, WGM, WGN>(
         [&](auto mi_c, f32x4(&slab)[NI]) {
@@ -290,7 +341,7 @@ LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const G
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) slab[ni] = acc[mi][ni];
         },
-        g, m0, n0, wr, wc, lane, wave, smem);
+        g, m0, n0, wr, wc, lane, wave, smem, pre);
 }
 
 template <int BM, int BN, bool CONV>
@@ -644,6 +695,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     // cost then hides under the previous MFMA's execution instead of serialising in front of the MFMA cluster
     // (ablation on MI355X: MFMA 98 us, LDS reads+barriers 74 us, DMA issue 57 us were ADDING UP to 207 us).
     int slot = 0;  // ring slot of tile kt
+    bool drained = false;
     auto ktile = [&](int kt, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         int nslot = slot + 1;
@@ -661,8 +713,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
         }
         __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - 1 - (MI + NI), 0);
-        // ---- tile kt+1 must have landed for every wave; tiles kt+2 .. kt+PD-1 may stay in flight
-        if constexpr (STEADY) wait_vmcnt_barrier<(PD - 2) * LPT>(); else wait_vmcnt_barrier<0>();
+        // ---- tile kt+1 must have landed for every wave; tiles kt+2 .. kt+PD-1 may stay in flight. The first tail tile drains the
+        // ring (every remaining tile visible to every wave); the tail tiles after it stage nothing and need neither wait nor barrier.
+        if constexpr (STEADY) wait_vmcnt_barrier<(PD - 2) * LPT>(); else if (!drained) wait_vmcnt_barrier<0>();
         // ---- second half
         mfma_first(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
@@ -689,6 +742,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     };
     int kt = 0;
     for (; kt < nk - PD; ++kt) ktile(kt, std::true_type{});
+    ResidualTile<BM, BN, WGM, WGN> rt;
+    if (kt < nk) {
+        ktile(kt, std::false_type{});
+        ++kt;
+        drained = true;
+        // gated-residual launches (the DiT's attention-out and FFN-out projections): fetch the residual-stream tile now, under the
+        // MFMAs of the last PD-1 K-tiles, instead of at the top of the epilogue
+        if (!g.ep.d2s && g.split_k <= 1 && n0 + BN <= g.N && kt < nk) {
+            gemm_bias_prefetch<BM, BN, WGM, WGN>(g, n0, wc, lane, rt);
+            if constexpr (!CONV) {
+                if (g.ep.resid) gemm_residual_prefetch<BM, BN, WGM, WGN>(g, m0, n0, wr, wc, lane, rt);
+            }
+        }
+    }
     for (; kt < nk; ++kt) ktile(kt, std::false_type{});
     __syncthreads();
     if (g.split_k > 1) {
@@ -699,7 +766,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         gemm_epilogue<BM, BN, WGM, WGN>(acc, gs, m0, n0, wr, wc, lane, wave, smem);
         return;
     }
-    gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem);
+    gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem, &rt);
 }
 
 
