@@ -520,6 +520,9 @@ LTX_DEVFN void wait_vmcnt_barrier() {
 // 128-B line, to hide the HBM latency of the once-streamed DiT weights. Same-process A/B on MI355X: 779 vs 963 TFLOP/s
 // cold and 932 vs 1040 warm at 1536x8192x4096 - every touched line crosses the CU's vector L1, +40 % bytes through the
 // texture path that this loop already saturates. The ring depth stays the only latency cover.)
+#if defined(GEMM_ASM_STAMPS) || defined(GEMM_V2_STAMPS)
+__device__ unsigned long long g_gemm_stamps[5][8];  // diagnostic builds only (tools/ubench/gemm_stamps.hip)
+#endif
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -542,6 +545,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     int tm, tn;
     tile_coords(g, bid, tiles_m, BN, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+#ifdef GEMM_V2_STAMPS  // tools/ubench/gemm_stamps.hip: 100 MHz wall-clock stamps of one wave (prologue / main loop / epilogue)
+    const unsigned long long st0 = wall_clock64();
+#endif
 
     const int srow = lane >> 3;
     const int pch = lane & 7;
@@ -688,6 +694,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     for (int s = 0; s < PD; ++s)
         if (s < nk) stage(s, kt0 + s);
     if (nk >= PD) wait_vmcnt_barrier<(PD - 1) * LPT>(); else wait_vmcnt_barrier<0>();
+#ifdef GEMM_V2_STAMPS
+    const unsigned long long st1 = wall_clock64();
+#endif
     load_frags(0, foff0, fa0, fb0);
 
     // One K-tile. STEADY iterations are branch-free so that each half is ONE scheduling region in which the LDS
@@ -758,6 +767,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     }
     for (; kt < nk; ++kt) ktile(kt, std::false_type{});
     __syncthreads();
+#ifdef GEMM_V2_STAMPS
+    const unsigned long long st2 = wall_clock64();
+#endif
     if (g.split_k > 1) {
         GemmArgs gs = g;  // raw partial tile -> workspace slice of this split
         gs.ep = GemmEpilogue{};
@@ -767,6 +779,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         return;
     }
     gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem, &rt);
+#ifdef GEMM_V2_STAMPS
+    {
+        const unsigned long long st3 = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st4 = wall_clock64();
+        if (lane == 0 && (blockIdx.x == 7 || blockIdx.x == 200) && wave < 4) {
+            unsigned long long* d = &g_gemm_stamps[blockIdx.x == 7 ? wave : 4][0];
+            if (blockIdx.x == 7 || wave == 0) {
+                d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = st4;
+            }
+        }
+    }
+#endif
 }
 
 
@@ -1095,9 +1120,6 @@ void launch_one(const GemmArgs& a, hipStream_t stream) {
 // C++ prepares the per-lane offsets / LDS addresses (the ring kernel's LDS image) and runs the shared epilogue on the accumulators
 // the assembly leaves in a[0:191].
 // ---------------------------------------------------------------------------------------------------------------
-#ifdef GEMM_ASM_STAMPS
-__device__ unsigned long long g_gemm_stamps[5][8];
-#endif
 template <int BN, bool RING = false>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_asm(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -12,7 +12,7 @@ ProfRec* Profiler::begin(int, double, hipStream_t) { return nullptr; }
 void Profiler::end(ProfRec*, hipStream_t) {}
 
 int main() {
-    const int M = 1536, N = 8192, K = 4096;
+    const int M = 1536, N = getenv("GEMM_N") ? atoi(getenv("GEMM_N")) : 8192, K = getenv("GEMM_K") ? atoi(getenv("GEMM_K")) : 4096;
     std::vector<bf16_t> ha((size_t)M * K), hb((size_t)N * K);
     for (size_t i = 0; i < ha.size(); ++i) ha[i] = host_f32_to_bf16((float)((i * 2654435761u >> 20) & 255) / 256.f - 0.5f);
     for (size_t i = 0; i < hb.size(); ++i) hb[i] = host_f32_to_bf16((float)((i * 40503u >> 12) & 255) / 256.f - 0.5f);
@@ -37,6 +37,15 @@ int main() {
     printf("%dx%dx%d: %.1f us per launch, %.0f TFLOP/s\n", M, N, K, ms * 100, 2.0 * M * N * K / (ms / 10 * 1e-3) / 1e12);
     unsigned long long st[5][8];
     (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_gemm_stamps), sizeof(st));
+#ifdef GEMM_V2_STAMPS
+    if (cfg == 21) {
+        printf("tile_cfg 21 (ring kernel), wall-clock stamps in ns (100 MHz counter):\nblock wave | prologue (first tile landed)   main loop   epilogue issue   stores drained | total\n");
+        for (int w = 0; w < 5; ++w)
+            printf("  %3d  %d  | %10llu %20llu %14llu %14llu       | %llu\n", w < 4 ? 7 : 200, w < 4 ? w : 0, 10 * (st[w][1] - st[w][0]), 10 * (st[w][2] - st[w][1]),
+                   10 * (st[w][3] - st[w][2]), 10 * (st[w][4] - st[w][3]), 10 * (st[w][4] - st[w][0]));
+        return 0;
+    }
+#endif
     if (cfg == 73) {
         printf("tile_cfg 73, one K-tile body (last pass), cycles:\nwave | k-step 0 (24 MFMA + 10 LDS-DMA)  k-step 1 to the wait (18 MFMA)  vmcnt wait  lgkmcnt+barrier  tail (6 MFMA + entry reads) | tile\n");
         for (int w = 0; w < 4; ++w)
