@@ -410,13 +410,12 @@ class Gen:
             e(f"v_add_u32 v{HI + ks}, 0x10000, %[ka{ks}]")
         for i in range(2):
             e(f"v_add_u32 v{HI + 4 + i}, 0x10000, %[va{i}]")
-        # the long-latency work first: K / Vt tiles 0..2 (and the bias vector), then the Q fragments, then register init
-        e("; ---- tiles 0, 1, 2 ----")
-        for t in range(3):
-            for grp in self.stage(t):
-                for ins in grp:
-                    e(ins)
-            self.advance_stage_offsets()
+        # the long-latency work first: the Q fragments (and the bias vector), then K / Vt tiles 0..2, then register init. The first
+        # QK needs Q and tile 0 only: tiles 1 and 2 stay in flight across the wait (vmcnt counts in issue order).
+        e("; ---- Q fragments ----")
+        for qb in range(3):
+            for ks in range(4):
+                e(f"global_load_dwordx4 {vr(QF + (qb * 4 + ks) * 4)}, %[qo{qb}], %[qbase] offset:{ks * 64}")
         if BIAS:
             e("; ---- bias vector -> LDS (16 KB after the ring; the descriptor ends after key Tk-1: zeros beyond) ----")
             e("s_mov_b32 s56, %[bilo]")
@@ -428,10 +427,15 @@ class Gen:
                 e(f"s_add_u32 s47, %[wlds], {i * 4096}")
                 e("buffer_load_dwordx4 %[bvo], s[56:59], s47 offen lds")
             e(f"v_mov_b32 v{BADDR}, %[ba]")
-        e("; ---- Q fragments ----")
-        for qb in range(3):
-            for ks in range(4):
-                e(f"global_load_dwordx4 {vr(QF + (qb * 4 + ks) * 4)}, %[qo{qb}], %[qbase] offset:{ks * 64}")
+        e("; ---- tiles 0, 1, 2 ----")
+        n_stage_ops = 0
+        for t in range(3):
+            for grp in self.stage(t):
+                for ins in grp:
+                    e(ins)
+                    n_stage_ops += ins.startswith("buffer_load")
+            self.advance_stage_offsets()
+        assert n_stage_ops == 24, n_stage_ops
         for i in range(LACC + 12):
             e(f"v_accvgpr_write_b32 a{i}, 0")
         for qb in range(3):
@@ -440,7 +444,7 @@ class Gen:
         e(f"v_mov_b32 v{FLOOR}, 0xff800000")
         for j in range(4):
             e(f"v_mov_b32 v{ONES + j}, 0x3f803f80")
-        e("s_waitcnt vmcnt(0)")
+        e("s_waitcnt vmcnt(16)")
         e("s_barrier")
         for kind, text in self.qk_stream(SA, 0):
             e(text)
