@@ -23,6 +23,13 @@ int main() {
     (void)hipMemcpy(b, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
     GemmArgs g;
     g.A = a; g.lda = K; g.B = b; g.ldb = K; g.M = M; g.N = N; g.K = K;
+    if (getenv("GATED")) {  // the DiT's gated-residual epilogue: x += gate[n] * (A.B^T + bias), in place on the f32 stream
+        float *gate, *bias;
+        (void)hipMalloc(&gate, (size_t)N * 4); (void)hipMalloc(&bias, (size_t)N * 4);
+        (void)hipMemset(gate, 0, (size_t)N * 4); (void)hipMemset(bias, 0, (size_t)N * 4);
+        (void)hipMemset(c, 0, (size_t)M * N * 4);
+        g.ep.resid = 1; g.ep.gate = gate; g.ep.gate_bstride = N; g.ep.rows_per_batch = M; g.ep.bias_n = bias;
+    }
     const char* ob = getenv("OUT_BF16");
     if (ob) { g.ep.out_bf16 = (bf16_t*)c; g.ep.ld_bf16 = N; } else { g.ep.out_f32 = c; g.ep.ld_f32 = N; }
     hipEvent_t e0, e1;
