@@ -1120,11 +1120,11 @@ void launch_one(const GemmArgs& a, hipStream_t stream) {
 // C++ prepares the per-lane offsets / LDS addresses (the ring kernel's LDS image) and runs the shared epilogue on the accumulators
 // the assembly leaves in a[0:191].
 // ---------------------------------------------------------------------------------------------------------------
-template <int BN, bool RING = false>
+template <int BN, int RING = 0>  // RING: 0 register-staged (71/72), 1 LDS-DMA ring (73), 2 A through the ring + B straight to registers (74)
 __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_asm(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(BN == 256 || BN == 128, "generated main loops exist for 192x256 and 192x128");
-    static_assert(!RING || BN == 128, "the LDS-DMA ring variant exists for 192x128");
+    static_assert(RING == 0 || BN == 128, "the LDS-DMA ring variants exist for 192x128");
     constexpr int BM = 192, WGM = 2, WGN = 2, NW = 4;
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * ROW_BYTES;
@@ -1163,7 +1163,22 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_asm(const GemmArgs g)
 #define GEMM_ASM_OPERANDS                                                                                                           \
     [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk), [sa] "s"(sa), \
         [sb] "s"(sb), [ao] "v"(ao), [bo] "v"(bo), [wb] "v"(wb), [fa0] "v"(fa0), [fa1] "v"(fa1), [fb0] "v"(fb0), [fb1] "v"(fb1)
-    if constexpr (RING) {
+    if constexpr (RING == 2) {
+        // tile_cfg 74: A by LDS-DMA into four 24 KB slots, B never touches LDS: each lane loads its 16 bytes of every B fragment
+        // (row 16 ni + (lane & 15) of this wave's 64 columns, k = 8 (lane >> 4) ..+7 of the k-step) four K-tiles ahead
+        // (tools/gen_gemm_asm_ring.py --bdirect)
+        const uint32_t wlds = (uint32_t)wave * 1024u;
+        const int bfo = ((wc * WN + (lane & 15)) * (int)g.ldb + 8 * (lane >> 4)) * 2;
+        const uint32_t sb16 = (uint32_t)(16 * g.ldb * 2);
+        asm volatile(
+#include "gemm_asm_hybrid_192x128.inc"
+            :
+            : [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk),
+              [sa] "s"(sa), [sb16] "s"(sb16), [wlds] "s"(wlds), [ao] "v"(ao), [bfo] "v"(bfo), [fa0] "v"(fa0), [fa1] "v"(fa1)
+            :
+#include "gemm_asm_hybrid_192x128_clobbers.inc"
+        );
+    } else if constexpr (RING == 1) {
         // tile_cfg 73: the same wave tile, K-tiles staged by LDS-DMA into four 40 KB slots (tools/gen_gemm_asm_ring.py)
         const uint32_t wlds = (uint32_t)wave * 1024u;
         asm volatile(
@@ -1350,11 +1365,11 @@ template <int BN>
 static bool gemm_asm_takes(const GemmArgs& a) {
     return !a.conv && a.split_k <= 1 && a.M % 192 == 0 && a.N % BN == 0 && a.K % 64 == 0 && a.K >= 64 && !a.ep.d2s;
 }
-template <int BN, bool RING = false>
+template <int BN, int RING = 0>
 static void launch_asm(const GemmArgs& a, hipStream_t stream) {
     LTX_REQUIRE(gemm_asm_takes<BN>(a), "gemm: the assembly kernel needs a dense A.B^T with M %% 192 == 0, N %% %d == 0, K %% 64 == 0 (M=%d N=%d K=%d)",
                 BN, a.M, a.N, a.K);
-    constexpr int smem = (RING ? 4 : 2) * (192 + BN) * ROW_BYTES;
+    constexpr int smem = RING == 2 ? 4 * 192 * ROW_BYTES : (RING ? 4 : 2) * (192 + BN) * ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_asm<BN, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1393,7 +1408,8 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
             case 71: launch_asm<256>(a, stream); break;      // one wave per SIMD, assembly main loop, 192x256
             case 72: launch_asm<128>(a, stream); break;      // the same, 192x128
-            case 73: launch_asm<128, true>(a, stream); break;  // 192x128, one wave per SIMD, LDS-DMA ring of four slots
+            case 73: launch_asm<128, 1>(a, stream); break;  // 192x128, one wave per SIMD, LDS-DMA ring of four slots
+            case 74: launch_asm<128, 2>(a, stream); break;  // the same with B as fragment-layout loads straight to registers
             case 41: launch_v4<192, 256>(a, stream); break;  // ping-pong, 8 waves (2x4), per-wave 96x64
             case 42: launch_v4<256, 256>(a, stream); break;  // ping-pong, per-wave 128x64
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
@@ -1470,7 +1486,7 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
             const long n = strtol(q, (char**)&q, 10);
             if (*q != ':') break;
             const long c = strtol(q + 1, (char**)&q, 10);
-            const bool takes = c == 71 ? gemm_asm_takes<256>(a) : (c == 72 || c == 73) ? gemm_asm_takes<128>(a) : true;
+            const bool takes = c == 71 ? gemm_asm_takes<256>(a) : (c >= 72 && c <= 74) ? gemm_asm_takes<128>(a) : true;
             if (n == a.N && takes) {
                 launch_gemm_bf16_cfg(a, (int)c, stream);
                 return;

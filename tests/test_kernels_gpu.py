@@ -61,12 +61,12 @@ def test_gemm_split_k_integer_exact(gpu_ctx, M, N, K, S, cfg):
     assert np.array_equal(as_f32(outb), torch.from_numpy(ref).to(torch.bfloat16).float().numpy())
 
 
-@pytest.mark.parametrize("cfg", [71, 72, 73])
+@pytest.mark.parametrize("cfg", [71, 72, 73, 74])
 @pytest.mark.parametrize("M,N,K,reps", [(192, 256, 64, 1), (192, 256, 128, 1), (384, 512, 448, 1), (192, 768, 7 * 64, 1), (576, 256, 13 * 64, 2),
                                         (1536, 2048, 4096, 4), (768, 4096, 1024, 3)])
 def test_gemm_assembly_kernel_integer_exact(gpu_ctx, cfg, M, N, K, reps):
     """One-wave-per-SIMD kernels with the generated assembly main loop (tile 192x256 = cfg 71, 192x128 = cfg 72: three register
-    sets, six-tile loop body; cfg 73: 192x128 with an LDS-DMA ring of four slots, four-tile loop body; all left after any tile): bit-exact on integer data for 1, 2, 7, 13 and 64 K-tiles - every exit point of the loop body and both LDS slots -
+    sets, six-tile loop body; cfg 73: 192x128 with an LDS-DMA ring of four slots, four-tile loop body; cfg 74: the same with the B fragments loaded straight to registers; all left after any tile): bit-exact on integer data for 1, 2, 7, 13 and 64 K-tiles - every exit point of the loop body and both LDS slots -
     with bias, an f32 and a bf16 output through its own epilogue; the large shapes are repeated with fresh operands to screen the
     register-set / LDS-slot rotation for races (a stale or early-read tile shows as a wrong integer)."""
     for r in range(reps):
