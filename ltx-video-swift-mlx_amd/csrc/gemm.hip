@@ -1168,10 +1168,19 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_asm(const GemmArgs g)
         // (row 16 ni + (lane & 15) of this wave's 64 columns, k = 8 (lane >> 4) ..+7 of the k-step) four K-tiles ahead
         // (tools/gen_gemm_asm_ring.py --bdirect)
         const uint32_t wlds = (uint32_t)wave * 1024u;
+#ifdef GEMM_HYBRID_PACKED_TIMING  // tools/ubench/gemm_stamps.hip: address pattern of fragment-ordered weights (timing only, wrong results)
+        const int bfo = wc * 8192 + lane * 16;
+        const uint32_t sb16 = 2048u;
+#else
         const int bfo = ((wc * WN + (lane & 15)) * (int)g.ldb + 8 * (lane >> 4)) * 2;
         const uint32_t sb16 = (uint32_t)(16 * g.ldb * 2);
+#endif
         asm volatile(
+#ifdef GEMM_HYBRID_PACKED_TIMING
+#include "gemm_asm_hybrid_192x128_stamps.inc"
+#else
 #include "gemm_asm_hybrid_192x128.inc"
+#endif
             :
             : [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk),
               [sa] "s"(sa), [sb16] "s"(sb16), [wlds] "s"(wlds), [ao] "v"(ao), [bfo] "v"(bfo), [fa0] "v"(fa0), [fa1] "v"(fa1)

@@ -127,6 +127,10 @@ class Gen:
     def load_b(self, t, f):
         """B fragment f = (k-step, 16-column block) of K-tile t: lane l gets B[16 ni + (l & 15)][32 ks + 8 (l >> 4) ..+7], 16 bytes."""
         ks, ni = f // NI, f % NI
+        if "packedb" in ABLATE:   # timing experiment: what fragment-ordered weights (1 KB contiguous per fragment) would cost
+            self.e(f"buffer_load_dwordx4 {self.bfrag(t, f)}, %[bfo], s[40:43], s{SOFF + 6 + ni} offen offset:{ks * 1024}")
+            self.vm_issue(("B", t, f))
+            return
         self.e(f"buffer_load_dwordx4 {self.bfrag(t, f)}, %[bfo], s[40:43], s{SOFF + 6 + ni} offen offset:{ks * 64}")
         self.vm_issue(("B", t, f))
 
@@ -150,7 +154,7 @@ class Gen:
 
     def advance_b(self):
         for i in range(NI):
-            self.e(f"s_add_u32 s{SOFF + 6 + i}, s{SOFF + 6 + i}, 128")
+            self.e(f"s_add_u32 s{SOFF + 6 + i}, s{SOFF + 6 + i}, {16384 if 'packedb' in ABLATE else 128}")
 
     def entry_read(self, slot, k):
         kind, x = self.ENTRY[k]
