@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Random-shape sweep of the GEMM epilogues and the attention dispatcher against f32 references (torch on the CPU): a wider net
+than the fixed cases of tests/test_kernels_gpu.py, same tolerances. Usage: python tools/fuzz_kernels.py [cases] [seed]"""
+import importlib
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ltx = importlib.import_module("ltx-video-swift-mlx_amd")
+
+
+def bf16(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda().to(torch.bfloat16)
+
+
+def f32(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+def run(ctx, cases, seed, verbose=True):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(cases):
+        # ---- gated residual GEMM: x += gate * (A.B^T + bias), ragged M, N (multiple of 4), K (multiple of 64: 1..40 K-tiles)
+        M = int(rng.integers(1, 700))
+        N = int(rng.integers(1, 200)) * 4
+        K = int(rng.integers(1, 41)) * 64
+        A = rng.standard_normal((M, K))
+        B = rng.standard_normal((N, K)) / math.sqrt(K)
+        bias, gate, x0 = rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal((M, N))
+        Ad, Bd = bf16(A), bf16(B)
+        use_gate = bool(rng.integers(0, 2))
+        use_mirror = bool(rng.integers(0, 2))
+        x = f32(x0)
+        mirror = torch.empty((M, N), device="cuda", dtype=torch.bfloat16) if use_mirror else None
+        ctx.op_gemm_gated_residual(Ad, Bd, f32(bias), f32(gate) if use_gate else None, 0.75, x, mirror)
+        torch.cuda.synchronize()
+        g = gate[None] if use_gate else 0.75
+        ref = x0 + g * ((Ad.float().cpu() @ Bd.float().cpu().T).numpy() + bias[None])
+        err = np.abs(x.cpu().numpy() - ref).max()
+        ok = err <= 1e-4
+        if use_mirror:
+            ok = ok and np.abs(mirror.float().cpu().numpy() - ref).max() <= 2 ** -8 * np.abs(ref).max() + 1e-3
+        if not ok:
+            bad += 1
+        if verbose:
+            print(f"gemm gated M={M:4d} N={N:4d} K={K:5d} gate={use_gate} mirror={use_mirror}: max err {err:.2e} {'ok' if ok else 'FAIL'}", flush=True)
+
+        # ---- attention: any Tq, Tk, optional key mask
+        Bn, H = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+        Tq, Tk = int(rng.integers(1, 900)), int(rng.integers(1, 1300))
+        D = H * 128
+        q, k, v = (bf16(rng.standard_normal((Bn, t, D))) for t in (Tq, Tk, Tk))
+        biasv = None
+        if rng.integers(0, 2):
+            m = (rng.random((Bn, Tk)) > 0.3).astype(np.float32)
+            m[:, 0] = 1
+            biasv = f32((1 - m) * -10000.0)
+        ldvt = ((Tk + 63) // 64) * 64
+        vt = torch.zeros((Bn, D, ldvt), device="cuda", dtype=torch.bfloat16)
+        vt[:, :, :Tk] = v.transpose(1, 2)
+        o = torch.empty((Bn, Tq, D), device="cuda", dtype=torch.bfloat16)
+        scale = 1.0 / math.sqrt(128.0)
+        ctx.op_attention(q, k, vt, biasv, H, o, scale)
+        torch.cuda.synchronize()
+        qh, kh, vh = (t.float().cpu().reshape(Bn, -1, H, 128).permute(0, 2, 1, 3) for t in (q, k, v))
+        s = qh @ kh.transpose(-1, -2) * scale
+        if biasv is not None:
+            s = s + biasv.cpu()[:, None, None, :]
+        ref = (torch.softmax(s, dim=-1) @ vh).permute(0, 2, 1, 3).reshape(Bn, Tq, D).numpy()
+        got = o.float().cpu().numpy()
+        err = np.abs(got - ref).max()
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        ok = err <= 2e-2 and rel <= 1e-2
+        if not ok:
+            bad += 1
+        if verbose:
+            print(f"attention B={Bn} H={H} Tq={Tq:4d} Tk={Tk:4d} mask={biasv is not None}: max err {err:.2e} rel {rel:.2e} {'ok' if ok else 'FAIL'}", flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    n_bad = run(ltx.Context(0), n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{2 * n_cases} cases, {n_bad} failures")
+    sys.exit(1 if n_bad else 0)
