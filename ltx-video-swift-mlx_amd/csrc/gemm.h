@@ -17,14 +17,16 @@ struct GemmEpilogue {
     long ld_bf16 = 0;
     const float* bias_n = nullptr;  // per output column (the usual Linear bias)
     const float* bias_m = nullptr;  // per output row (used when operands are swapped to emit C^T)
+    // gate_scalar FIRST of four 4-byte fields: hipcc reads it with a 16-byte vector load (the splat to four lanes), and when those 16
+    // bytes also hold a pointer the kernels' by-value argument copy is not promoted to registers - every epilogue read of the
+    // neighbouring fields then becomes a scratch load with a vmcnt(0) behind it
+    float gate_scalar = 1.0f;
     int act = LTX_ACT_NONE;
     int round_bf16 = 0;  // round (acc+bias, activated) through bf16 before any f32 store/residual use
     // residual mode: out_f32[m][n] = resid_src[m][n] + gate(m,n) * (acc + bias); gate(m,n) =
     //   gate ? gate[(m / rows_per_batch) * gate_bstride + n] : gate_scalar
     // (reference residualGate: LTXTransformerBlock.swift:86-92; cross-attn scale :211-214)
     int resid = 0;
-    float gate_scalar = 1.0f;  // kept beside the other 4-byte fields: in a 16-byte slice shared with a pointer the kernels' by-value
-                               // argument copy is not promoted to registers and every epilogue read of it becomes a scratch load
     const float* gate = nullptr;
     long gate_bstride = 0;
     int rows_per_batch = 1;

@@ -140,6 +140,17 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
         }
         const float* rbase = ep.resid_src ? ep.resid_src : ep.out_f32;
         const long rld = ep.resid_src ? ep.ld_resid : ep.ld_f32;
+        // the usual case - all rows of this wave's tile in one batch element - needs one gate vector, not an integer division
+        // per lane and slab: load it once, beside the bias
+        const int row_lo = (m0 + wr * WM) < g.M ? (m0 + wr * WM) : g.M - 1;
+        const int row_hi = (m0 + wr * WM + WM - 1) < g.M ? (m0 + wr * WM + WM - 1) : g.M - 1;
+        const int gb_lo = row_lo / ep.rows_per_batch;
+        const bool gate_uniform = has_res && ep.gate && !ep.gate_rowmap && gb_lo == row_hi / ep.rows_per_batch;
+        f32x4 gtu[NIT];
+        if (gate_uniform) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) gtu[it] = *(const f32x4*)(ep.gate + (long)gb_lo * ep.gate_bstride + gn_w + ((it * 64 + lane) % LPR) * 4);
+        }
         auto prefetch = [&](auto mi_c, auto buf_c) {
             constexpr int mi = decltype(mi_c)::value, buf = decltype(buf_c)::value;
             if (!has_res) return;
@@ -153,7 +164,9 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
                     rs[buf][it] = pre->v[mi][it];
                 else
                     rs[buf][it] = *(const f32x4*)(rbase + (long)gm * rld + gn_w + c4);
-                if (ep.gate)
+                if (gate_uniform)
+                    gt[buf][it] = gtu[it];
+                else if (ep.gate)
                     gt[buf][it] = *(const f32x4*)(ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[gm] : gm / ep.rows_per_batch) * ep.gate_bstride + gn_w + c4);
                 else
                     gt[buf][it] = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
