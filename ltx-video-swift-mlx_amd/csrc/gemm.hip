@@ -1449,7 +1449,18 @@ int gemm_suggest_split_k(int M, int N, int K) {
     return s < 1 ? 1 : (int)s;
 }
 
-void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
+void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
+    // A/B hook: LTX_GEMM_GROUP_M="N:g,..." overrides the supertile height of dense launches with that N (tile_coords)
+    GemmArgs a = a_in;
+    if (const char* f = getenv("LTX_GEMM_GROUP_M")) {
+        for (const char* q = f; *q;) {
+            const long n = strtol(q, (char**)&q, 10);
+            if (*q != ':') break;
+            const long gm = strtol(q + 1, (char**)&q, 10);
+            if (n == a.N && !a.conv) a.group_m = (int)gm;
+            if (*q == ',') ++q;
+        }
+    }
     // Tile choice = workgroup-count quantisation x structure efficiency. Two structures:
     //   v1 (cfg 0,1,3,4): 4 waves, 2 LDS stages, TWO workgroups resident per CU (512 slots) - two waves per SIMD from
     //       co-residency; best when a launch has >= 512 tiles. Its single-tile prefetch exposes HBM latency on

@@ -12,7 +12,7 @@ ProfRec* Profiler::begin(int, double, hipStream_t) { return nullptr; }
 void Profiler::end(ProfRec*, hipStream_t) {}
 
 int main() {
-    const int M = 1536, N = getenv("GEMM_N") ? atoi(getenv("GEMM_N")) : 8192, K = getenv("GEMM_K") ? atoi(getenv("GEMM_K")) : 4096;
+    const int M = getenv("GEMM_M") ? atoi(getenv("GEMM_M")) : 1536, N = getenv("GEMM_N") ? atoi(getenv("GEMM_N")) : 8192, K = getenv("GEMM_K") ? atoi(getenv("GEMM_K")) : 4096;
     std::vector<bf16_t> ha((size_t)M * K), hb((size_t)N * K);
     for (size_t i = 0; i < ha.size(); ++i) ha[i] = host_f32_to_bf16((float)((i * 2654435761u >> 20) & 255) / 256.f - 0.5f);
     for (size_t i = 0; i < hb.size(); ++i) hb[i] = host_f32_to_bf16((float)((i * 40503u >> 12) & 255) / 256.f - 0.5f);
@@ -30,6 +30,12 @@ int main() {
         (void)hipMemset(c, 0, (size_t)M * N * 4);
         g.ep.resid = 1; g.ep.gate = gate; g.ep.gate_bstride = N; g.ep.rows_per_batch = M; g.ep.bias_n = bias;
     }
+    if (getenv("BIAS_M")) {  // the V^T projection: weights as the row operand, bias per output row
+        float* bm;
+        (void)hipMalloc(&bm, (size_t)M * 4);
+        (void)hipMemset(bm, 0, (size_t)M * 4);
+        g.ep.bias_m = bm;
+    }
     const char* ob = getenv("OUT_BF16");
     if (ob) { g.ep.out_bf16 = (bf16_t*)c; g.ep.ld_bf16 = N; } else { g.ep.out_f32 = c; g.ep.ld_f32 = N; }
     hipEvent_t e0, e1;
@@ -45,8 +51,8 @@ int main() {
     unsigned long long st[5][8];
     (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_gemm_stamps), sizeof(st));
 #ifdef GEMM_V2_STAMPS
-    if (cfg == 21) {
-        printf("tile_cfg 21 (ring kernel), wall-clock stamps in ns (100 MHz counter):\nblock wave | prologue (first tile landed)   main loop   epilogue issue   stores drained | total\n");
+    if (cfg == 21 || cfg == 25) {
+        printf("tile_cfg 21 / 25 (ring kernel), wall-clock stamps in ns (100 MHz counter):\nblock wave | prologue (first tile landed)   main loop   epilogue issue   stores drained | total\n");
         for (int w = 0; w < 5; ++w)
             printf("  %3d  %d  | %10llu %20llu %14llu %14llu       | %llu\n", w < 4 ? 7 : 200, w < 4 ? w : 0, 10 * (st[w][1] - st[w][0]), 10 * (st[w][2] - st[w][1]),
                    10 * (st[w][3] - st[w][2]), 10 * (st[w][4] - st[w][3]), 10 * (st[w][4] - st[w][0]));
