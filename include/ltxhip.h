@@ -366,6 +366,10 @@ int ltx_prof_collect(ltx_ctx* ctx, int kind, double* total_ms, long* launches, d
 int ltx_op_gemm_bf16(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb, const float* bias, int M,
                      int N, int K, int act, int tile_cfg, float* out_f32, long ld_f32, uint16_t* out_bf16,
                      long ld_bf16);
+/* vt[n][t] = bf16(sum_k X[t][k] W[n][k] + bias[n]): the value projection in the transposed layout the attention op takes
+ * (to_v of LTXAttention.swift:100-104 followed by the head split; columns t >= tokens of vt are left untouched), ldvt % 4 == 0 */
+int ltx_op_value_projection_t(ltx_ctx* ctx, const uint16_t* X, long ldx, int tokens, const uint16_t* W, const float* bias, int out_features,
+                              int in_features, uint16_t* vt, long ldvt);
 /* x[m][n] += gate[n] * (A.B^T + bias) in place on an f32 stream, optional bf16 mirror of the result */
 int ltx_op_gemm_bf16_gated_residual(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb,
                                     const float* bias, const float* gate, float gate_scalar, int M, int N, int K,

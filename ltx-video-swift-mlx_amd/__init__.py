@@ -487,6 +487,10 @@ class Context:
                                       _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
                                       _ptr(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0))
 
+    def op_value_projection_t(self, X, W, bias, vt):
+        tokens, K = X.shape
+        self._ck(lib.ltx_op_value_projection_t(self._h, _ptr(X), X.stride(0), tokens, _ptr(W), _ptr(bias), W.shape[0], K, _ptr(vt), vt.stride(0)))
+
     def op_gemm_gated_residual(self, A, B, bias, gate, gate_scalar, x, mirror=None):
         M, K = A.shape
         N = B.shape[0]

@@ -17,6 +17,7 @@
 #include "vae.h"
 #include "vae_encoder.h"
 #include "runtime.h"
+#include "linear_ops.h"
 
 namespace {
 
@@ -858,6 +859,19 @@ int ltx_op_gemm_bf16(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* 
             g.split_ws = ctx->op_ws.as<float>();
         }
         if (tile_cfg < 0) launch_gemm_bf16(g, ctx->stream); else launch_gemm_bf16_cfg(g, tile_cfg, ctx->stream);
+    });
+}
+
+int ltx_op_value_projection_t(ltx_ctx* ctx, const uint16_t* X, long ldx, int tokens, const uint16_t* W, const float* bias, int out_features,
+                              int in_features, uint16_t* vt, long ldvt) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        LinearW w;
+        w.w = (bf16_t*)W;
+        w.b = (float*)bias;
+        w.out = out_features;
+        w.in = in_features;
+        gemm_vt(X, ldx, tokens, w, vt, ldvt, ctx->stream);
     });
 }
 

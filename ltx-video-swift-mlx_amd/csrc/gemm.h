@@ -15,6 +15,11 @@ struct GemmEpilogue {
     long ld_f32 = 0;
     bf16_t* out_bf16 = nullptr;   // [M, ld_bf16]
     long ld_bf16 = 0;
+    // transposed output: out_bf16_t[n * ld_bf16_t + m] = bf16(acc + bias_n[n]) and nothing else (no activation, residual or other
+    // output). Stored straight from the accumulator layout - a lane holds four consecutive rows m of one column n, i.e. 8 contiguous
+    // bytes of the transposed matrix. Used for V^T = (X.Wv^T)^T with the tokens as rows (the attention kernels take V^T).
+    bf16_t* out_bf16_t = nullptr;  // [N, ld_bf16_t], ld_bf16_t % 4 == 0
+    long ld_bf16_t = 0;
     const float* bias_n = nullptr;  // per output column (the usual Linear bias)
     const float* bias_m = nullptr;  // per output row (used when operands are swapped to emit C^T)
     // gate_scalar FIRST of four 4-byte fields: hipcc reads it with a 16-byte vector load (the splat to four lanes), and when those 16

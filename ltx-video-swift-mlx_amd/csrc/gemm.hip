@@ -120,6 +120,33 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
     float* scr = (float*)(smem + wave * (16 * WN * 4));
     constexpr int LPR = WN / 4;    // lanes per output row
     const GemmEpilogue& ep = g.ep;
+    if (ep.out_bf16_t) {
+        // transposed bf16 store from the accumulator layout: acc[mi][ni][r] = C[16 mi + 4 (lane >> 4) + r][16 ni + (lane & 15)]
+        static_for<0, MI>([&](auto mi_c) {
+            constexpr int mi = decltype(mi_c)::value;
+            f32x4 slab[NI];
+            get(mi_c, slab);
+            const int gm0 = m0 + wr * WM + mi * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int gn = n0 + wc * WN + ni * 16 + (lane & 15);
+                if (gn >= g.N || gm0 >= g.M) continue;
+                const float bn = ep.bias_n ? ep.bias_n[gn] : 0.f;
+                bf16_t* o = ep.out_bf16_t + (long)gn * ep.ld_bf16_t + gm0;
+                if (gm0 + 3 < g.M) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(slab[ni][0] + bn, slab[ni][1] + bn);
+                    pk.y = pack_bf16x2(slab[ni][2] + bn, slab[ni][3] + bn);
+                    *(uint2*)o = pk;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (gm0 + r < g.M) o[r] = f32_to_bf16(slab[ni][r] + bn);
+                }
+            }
+        });
+        return;
+    }
     if (!ep.d2s && n0 + BN <= g.N) {
         // Interior columns (every DiT GEMM): branch-free 16-B accesses, and the residual-stream / gate reads of slab
         // mi+1 are issued BEFORE slab mi's LDS transpose so that their HBM/MALL latency overlaps it. One workgroup
@@ -1369,7 +1396,7 @@ void validate(const GemmArgs& a) {
         LTX_REQUIRE(a.lda % 8 == 0, "gemm: lda=%ld must be a multiple of 8", a.lda);
     }
     const GemmEpilogue& e = a.ep;
-    LTX_REQUIRE(e.out_f32 || e.out_bf16, "gemm: no output");
+    LTX_REQUIRE(e.out_f32 || e.out_bf16 || e.out_bf16_t, "gemm: no output");
     if (e.out_f32) LTX_REQUIRE(e.ld_f32 % 4 == 0 && ((uintptr_t)e.out_f32 & 15) == 0, "gemm: f32 output alignment");
     if (e.out_bf16) LTX_REQUIRE(e.ld_bf16 % 4 == 0 && ((uintptr_t)e.out_bf16 & 7) == 0, "gemm: bf16 output alignment");
     if (e.resid && !e.d2s) LTX_REQUIRE(e.out_f32 || e.resid_src, "gemm: residual mode needs an f32 stream");
@@ -1402,6 +1429,12 @@ static void launch_asm(const GemmArgs& a, hipStream_t stream) {
 }
 
 void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
+    if (a.ep.out_bf16_t) {
+        const GemmEpilogue& e = a.ep;
+        LTX_REQUIRE(!e.out_f32 && !e.out_bf16 && !e.resid && !e.d2s && !e.bias_m && e.act == LTX_ACT_NONE && !e.round_bf16 && a.split_k <= 1 &&
+                        !a.split_ws && e.ld_bf16_t % 4 == 0 && e.ld_bf16_t >= a.M && (cfg < 41 || cfg > 74),
+                    "gemm: the transposed bf16 output takes bias_n only, no split-K, ld %% 4 == 0 (ld=%ld M=%d cfg=%d)", e.ld_bf16_t, a.M, cfg);
+    }
     validate(a);
     LTX_REQUIRE(a.split_k <= 1 || (cfg >= 20 && cfg < 30), "gemm: split-K needs a ring kernel (tile cfg %d)", cfg);
     ProfScope prof(a.conv ? PROF_CONV : PROF_GEMM, 2.0 * a.M * a.N * a.K, stream);

@@ -31,6 +31,23 @@ inline void gemm_linear(const bf16_t* A, long lda, const LinearW& w, int M, Gemm
 
 // V^T[d][token] = W_v[d][:] . X[token][:] + b_v[d]  (swapped operands -> the attention kernel's Vt layout)
 inline void gemm_vt(const bf16_t* X, long ldx, int tokens, const LinearW& wv, bf16_t* vt, long ldvt, hipStream_t s, SplitWs ws = {}) {
+    if (ldvt % 4 == 0 && gemm_suggest_split_k(tokens, wv.out, wv.in) <= 1) {
+        // enough output tiles without a K split: tokens as rows (the weights stay the column operand, as in every other launch -
+        // 50.4 us against 56.5 us at 1536 tokens with HBM-cold weights) and the epilogue stores transposed
+        GemmArgs g;
+        g.A = X;
+        g.lda = ldx;
+        g.B = wv.w;
+        g.ldb = wv.in;
+        g.M = tokens;
+        g.N = wv.out;
+        g.K = wv.in;
+        g.ep.out_bf16_t = vt;
+        g.ep.ld_bf16_t = ldvt;
+        g.ep.bias_n = wv.b;
+        launch_gemm_bf16(g, s);
+        return;
+    }
     GemmArgs g;
     g.A = wv.w;
     g.lda = wv.in;

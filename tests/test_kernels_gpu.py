@@ -168,6 +168,26 @@ def test_gemm_gated_residual(gpu_ctx):
     assert np.abs(as_f32(x) - ref).max() <= 5e-5
 
 
+@pytest.mark.parametrize("tokens,N,K", [(1536, 512, 1024), (1000, 384, 2048), (777, 256, 512), (70, 256, 4096), (128, 512, 4096), (301, 130 * 2, 256)])
+def test_value_projection_transposed(gpu_ctx, tokens, N, K):
+    """V^T = (X.Wv^T + b)^T in the layout the attention op takes. Both routes of the helper: tokens as GEMM rows with the transposed
+    epilogue store (enough tiles: integer-exact, ragged 4-row groups at the end) and the swapped-operand launch with a K split (few
+    tokens). Padding columns of V^T stay untouched."""
+    rng = np.random.default_rng(tokens + N + K)
+    X = rng.integers(-3, 4, (tokens, K)).astype(np.float32)
+    W = rng.integers(-3, 4, (N, K)).astype(np.float32)
+    b = rng.integers(-8, 9, (N,)).astype(np.float32)
+    ldvt = ((tokens + 63) // 64) * 64
+    vt = torch.full((N, ldvt), 7.0, device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_value_projection_t(dev_bf16(X), dev_bf16(W), dev_f32(b), vt)
+    torch.cuda.synchronize()
+    ref = (X @ W.T + b[None]).T
+    got = as_f32(vt)
+    want = torch.from_numpy(ref).to(torch.bfloat16).float().numpy()  # integer sums are exact in f32; one rounding to bf16
+    assert np.array_equal(got[:, :tokens], want)
+    assert np.all(got[:, tokens:] == 7.0)
+
+
 @pytest.mark.parametrize("M,in_act", [(1, 0), (2, 2), (5, 2)])
 def test_gemv(gpu_ctx, M, in_act):
     rng = np.random.default_rng(3)
