@@ -410,8 +410,9 @@ class Gen:
             e(f"v_add_u32 v{HI + ks}, 0x10000, %[ka{ks}]")
         for i in range(2):
             e(f"v_add_u32 v{HI + 4 + i}, 0x10000, %[va{i}]")
-        # the long-latency work first: the Q fragments (and the bias vector), then K / Vt tiles 0..2, then register init. The first
-        # QK needs Q and tile 0 only: tiles 1 and 2 stay in flight across the wait (vmcnt counts in issue order).
+        # the long-latency work first: the Q fragments (and the bias vector), then K / Vt tiles 0..2, then register init. ALL three
+        # tiles must have landed before the loop: its first step already multiplies Q with the keys of tile 1 (part A works one tile
+        # ahead of the PV products), so a wait that leaves tiles 1 and 2 in flight reads a ring slot that may still be empty.
         e("; ---- Q fragments ----")
         for qb in range(3):
             for ks in range(4):
@@ -444,7 +445,7 @@ class Gen:
         e(f"v_mov_b32 v{FLOOR}, 0xff800000")
         for j in range(4):
             e(f"v_mov_b32 v{ONES + j}, 0x3f803f80")
-        e("s_waitcnt vmcnt(16)")
+        e("s_waitcnt vmcnt(0)")
         e("s_barrier")
         for kind, text in self.qk_stream(SA, 0):
             e(text)
