@@ -128,6 +128,11 @@ int ltx_dit_load(ltx_ctx* ctx, const char* safetensors_path, const ltx_transform
 int ltx_dit_init_synthetic(ltx_ctx* ctx, const ltx_transformer_config* cfg, uint64_t seed);
 /* quantize(model:groupSize:bits:) applied to an already loaded / synthetic model (LTXPipeline.swift:329). */
 int ltx_dit_quantize(ltx_ctx* ctx, int bits, int group_size);
+/* Reads one parameter of the resident model back to the HOST as f32 (bf16 values widened; of a quantised model the de-quantised
+ * value the GEMMs use). module_key: the reference's module path, e.g. "transformer_blocks.3.attn1.to_q.weight".
+ * Returns the element count (written only if <= cap; out NULL = query) or <0. Parity tests use it to hand the on-device
+ * synthetic weights of ltx_dit_init_synthetic to the CPU oracle at the reference's full width. */
+long ltx_dit_export_param(ltx_ctx* ctx, const char* module_key, float* out, long cap);
 /* Replaces LTXPipeline.fuseLoRA(from:scale:) -> Module.fuseLoRA (LTXPipeline.swift:3134-3153, LoRAAdapter.swift:64-166):
  * W' = W + cast(scale * (alpha/rank | 1) * (up @ down)) for every LoRA layer whose mapped key (ltx_map_lora_key) names a
  * Linear weight; on a quantised model dequant -> merge -> requant. *n_fused = number of fused layers. */
@@ -157,9 +162,12 @@ int ltx_dit_forward_dev(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* co
  * self-attention all-gathers its K rows and V^T block through `gather`, called 2 x num_layers times per forward:
  *   gather(user, send, recv, bytes): all-gather `bytes` from every rank into recv = [sp_world][bytes] in rank order. DEVICE pointers.
  *   It must either enqueue the collective on the context's stream (RCCL on the stream given to ltx_ctx_set_stream) or finish it
- *   before returning (then synchronise that stream first). Every rank must call the forward with the same arguments.
- * DEVICE pointers, asynchronous on the context stream when `gather` is. */
-typedef void (*ltx_allgather_fn)(void* user, const void* send, void* recv, long bytes);
+ *   before returning (then synchronise that stream first), and return 0; any other value aborts the forward with
+ *   LTX_ERR_GENERATION_FAILED (the kernels behind a failed gather would read unfilled buffers). Every rank must call the forward
+ *   with the same arguments. gather NULL = the context's own transport (ltx_dist_init: RCCL; ltx_dist_set_transport: host
+ *   callback), whose rank/world must equal sp_rank/sp_world.
+ * DEVICE pointers, asynchronous on the context stream when the transport is. */
+typedef int (*ltx_allgather_fn)(void* user, const void* send, void* recv, long bytes);
 int ltx_dit_forward_sp_dev(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* context, const float* timesteps,
                            const int32_t* mask, int mask_all_ones, int F, int H, int W, int S, uint64_t ctx_version,
                            int sp_rank, int sp_world, ltx_allgather_fn gather, void* user, float* velocity);
@@ -330,7 +338,19 @@ typedef struct ltx_denoise_options {
     const float* cond_latent;
     float image_cond_noise_scale;
     const float* cond_noise;
+    /* Multi-GPU sharding of the loop over the ranks of this context's group (ltx_dist_init / ltx_dist_set_transport; the reference is
+     * single-device - SURVEY 8(e)). Every rank calls ltx_denoise(_dev) with the same arguments and ends with the same latent, bit
+     * for bit: CFG / rescale / STG / GE / Euler run redundantly on every rank with the library's own kernels.
+     *   LTX_SHARD_NONE     (0) this context evaluates everything.
+     *   LTX_SHARD_CFG      (1) the CFG pair is split: rank 0 = negative branch, rank 1 = positive branch (the two B=1 forwards of
+     *                          LTXPipeline.swift:829-848 / the B=2 forward of :2236-2264), rank 2 of a three-rank group = the STG
+     *                          pass; ONE all-gather of the [C*T] f32 velocities per step. Needs cfg_scale > 1 and 2 (or 3) ranks.
+     *   LTX_SHARD_SEQUENCE (2) one sample's tokens are split into equal contiguous slices (F*H*W divisible by the group size into
+     *                          multiples of 8): per transformer block one all-gather of K rows and one of V^T, per forward one
+     *                          all-gather of the velocity slices. */
+    int shard;
 } ltx_denoise_options;
+enum { LTX_SHARD_NONE = 0, LTX_SHARD_CFG = 1, LTX_SHARD_SEQUENCE = 2 };
 
 /* Replaces the denoise loop of generateVideo (LTXPipeline.swift:800-956) / denoise(...) (:2191-2401), T2V.
  *   latent  [1][C][F][H][W] f32, in/out; must already be scaled by sigmas[0] (LTXPipeline.swift:793)
@@ -345,6 +365,49 @@ int ltx_denoise(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* s
 int ltx_denoise_dev(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* sigmas, int n_sigmas,
                     const uint16_t* context, const int32_t* mask, int mask_all_ones, int S, uint64_t ctx_version,
                     const ltx_denoise_options* opt, ltx_progress_cb cb, void* user);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, one ltx_ctx per process, RCCL over xGMI called by the library itself (librccl is loaded
+ * on the first ltx_dist_* call; no PyTorch on this path). The reference is a single-device program: this section has no Swift
+ * counterpart, it shards what SURVEY 8(e) says shards - the CFG pair (LTXPipeline.swift:820-865, :2235-2283), one sample's
+ * tokens, the VAE's temporal tiles (VideoDecoder.swift:517-592). Independent samples need nothing from here (replicas).
+ * ---------------------------------------------------------------------------------------------------------- */
+#define LTX_DIST_ID_BYTES 128
+/* ncclGetUniqueId: called on ONE rank; the host carries the 128 bytes to the other ranks of the group (any channel: MPI, a TCP
+ * store, a file) and every rank passes them to ltx_dist_init. */
+int ltx_dist_unique_id(void* id_out);
+/* ncclCommInitRank on the context's device; collective over the group's ranks. A group is whatever set of contexts shares one
+ * id: the CFG pair of one sample (2 ranks), the ranks decoding one video's tiles, all 8 GPUs of one sequence-parallel sample. */
+int ltx_dist_init(ltx_ctx* ctx, int rank, int world, const void* id);
+/* The same group membership with a caller-supplied all-gather instead of RCCL (contract as ltx_allgather_fn above). For hosts
+ * that already own a transport, and for world-size-2 tests where RCCL cannot run (two processes on one GPU). */
+int ltx_dist_set_transport(ltx_ctx* ctx, int rank, int world, ltx_allgather_fn gather, void* user);
+int ltx_dist_shutdown(ltx_ctx* ctx);
+/* rank / world of the context's group (0 / 1 without one); *native = 1 when the transport is RCCL; *n_collectives = collectives
+ * enqueued so far. Any pointer may be NULL. */
+int ltx_dist_info(const ltx_ctx* ctx, int* rank, int* world, int* native_transport, long* n_collectives);
+/* Collectives on the context's stream for the host's own exchanges (the one-time broadcast of the text context).
+ * DEVICE pointers. recv = [world][bytes] in rank order. */
+int ltx_dist_allgather_dev(ltx_ctx* ctx, const void* send, void* recv, long bytes);
+int ltx_dist_broadcast_dev(ltx_ctx* ctx, void* buf, long bytes, int root);
+
+/* Tiled VAE decode as building blocks (decodeWithTemporalTiling, VideoDecoder.swift:517-602), for hosts that place tiles on GPUs
+ * themselves. ltx_vae_decode_tile_dev: the RAW frames - before blending and before the (x+1)/2 clip of :501-505 - of tile
+ * `tile_index` of the plan (tile, overlap) over `latent` [1][128][F][H][W] -> tile_out (n, 32H, 32W, 3) f32, n = 8(len-1)+1.
+ * Blending clipped tiles is not the reference: raw frames are what travels between GPUs. DEVICE pointers. */
+int ltx_vae_decode_tile_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
+                            const float* noise, int tile, int overlap, int tile_index, float* tile_out, long tile_cap,
+                            int* n_frames_out);
+/* Blend raw tiles in tile order over 8*overlap frames (VideoDecoder.swift:561-592), then clip((x+1)/2, 0, 1) (:501-505).
+ * tiles: HOST array of n_tiles DEVICE pointers, tile_frames their frame counts; tiles[0] may be frames_out. */
+int ltx_vae_blend_tiles_dev(ltx_ctx* ctx, const float* const* tiles, const int* tile_frames, int n_tiles, int overlap, int H,
+                            int W, float* frames_out, long frames_cap, int* n_frames_out);
+/* ltx_vae_decode_dev with the tiles decoded round-robin by the ranks of the context's group (tile i on rank i % world), each raw
+ * tile broadcast from its owner, and the blend + clip done on every rank: every rank returns the full frames, bit-identical to
+ * the single-GPU ltx_vae_decode_dev. Every rank must call it with the same arguments. */
+int ltx_vae_decode_sharded_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
+                               const float* noise, int tile, int overlap, float* frames_out, long frames_cap,
+                               int* n_frames_out);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Live kernel timing (replaces the reference's wall-clock GenerationTimings, LTXVideo.swift:255-297, with HIP

@@ -14,7 +14,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ConnectorConfig, PROGRESS_CB, DenoiseOptions, LTXError, TransformerConfig, lib
+from ._lib import (ALLGATHER_FN, DIST_ID_BYTES, SHARD_CFG, SHARD_NONE, SHARD_SEQUENCE, ConnectorConfig, PROGRESS_CB, DenoiseOptions,
+                   LTXError, TransformerConfig, lib)
 
 __version__ = lib.ltx_version().decode()
 
@@ -121,7 +122,37 @@ def threefry2x32(key, ctr):
     return o
 
 
-_ALLGATHER_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long)
+
+
+def dist_unique_id():
+    """``ltx_dist_unique_id``: the 128 bytes one rank creates and the host carries to the others (RCCL's ncclUniqueId)."""
+    buf = C.create_string_buffer(DIST_ID_BYTES)
+    _check(lib.ltx_dist_unique_id(buf))
+    return buf.raw
+
+
+class _Transport:
+    """Python all-gather behind ``ltx_allgather_fn``. ctypes would print and swallow an exception raised inside a callback and the
+    C side would carry on with unfilled buffers: here the exception is stashed, the callback returns 1 (the library aborts the call
+    with LTX_ERR_GENERATION_FAILED) and ``reraise`` surfaces the original error once the C call has returned."""
+
+    def __init__(self, gather):
+        self.error = None
+
+        def _cb(_user, send, recv, nbytes):
+            try:
+                gather(send, recv, nbytes)
+                return 0
+            except BaseException as e:  # noqa: BLE001 - must not propagate through the C frames
+                self.error = e
+                return 1
+
+        self.cfn = ALLGATHER_FN(_cb)
+
+    def reraise(self):
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
 
 
 def frames_to_u8(frames):
@@ -209,8 +240,51 @@ class Context:
             pass
 
     def _ck(self, rc):
+        tr = getattr(self, "_transport", None)
+        if tr is not None:
+            tr.reraise()
         if rc != 0:
             raise LTXError(rc, lib.ltx_last_error(self._h).decode(errors="replace"))
+
+    # ---- multi-GPU group of this context (include/ltxhip.h, "Multi-GPU") ----
+    def dist_init(self, rank, world, unique_id):
+        """RCCL communicator over the group's ranks (collective call); ``unique_id`` from ``dist_unique_id()`` on one rank."""
+        assert len(unique_id) == DIST_ID_BYTES
+        self._transport = None
+        self._ck(lib.ltx_dist_init(self._h, rank, world, C.c_char_p(bytes(unique_id))))
+
+    def dist_set_transport(self, rank, world, gather):
+        """Same membership over a Python all-gather ``gather(send_ptr, recv_ptr, nbytes)`` (tests over gloo)."""
+        self._transport = None
+        tr = _Transport(gather)
+        self._ck(lib.ltx_dist_set_transport(self._h, rank, world, C.cast(tr.cfn, C.c_void_p), None))
+        self._transport = tr
+
+    def dist_shutdown(self):
+        self._transport = None
+        self._ck(lib.ltx_dist_shutdown(self._h))
+
+    def dist_info(self):
+        r, w, nat, n = C.c_int(), C.c_int(), C.c_int(), C.c_long()
+        self._ck(lib.ltx_dist_info(self._h, C.byref(r), C.byref(w), C.byref(nat), C.byref(n)))
+        return {"rank": r.value, "world": w.value, "native": bool(nat.value), "collectives": n.value}
+
+    def dist_allgather_dev(self, send, recv):
+        self._ck(lib.ltx_dist_allgather_dev(self._h, _ptr(send), _ptr(recv), send.numel() * send.element_size()))
+
+    def dist_broadcast_dev(self, buf, root=0):
+        self._ck(lib.ltx_dist_broadcast_dev(self._h, _ptr(buf), buf.numel() * buf.element_size(), root))
+
+    def dit_export_param(self, key):
+        """One resident parameter as an f32 numpy array (flat), e.g. to hand the synthetic weights to the oracle."""
+        n = lib.ltx_dit_export_param(self._h, key.encode(), None, 0)
+        if n < 0:
+            raise LTXError(-n, lib.ltx_last_error(self._h).decode(errors="replace"))
+        out = np.empty(n, dtype=np.float32)
+        n2 = lib.ltx_dit_export_param(self._h, key.encode(), out.ctypes.data, n)
+        if n2 < 0:
+            raise LTXError(-n2, lib.ltx_last_error(self._h).decode(errors="replace"))
+        return out
 
     def set_stream(self, stream_handle):
         self._ck(lib.ltx_ctx_set_stream(self._h, C.c_void_p(stream_handle)))
@@ -279,14 +353,13 @@ class Context:
         """Sequence-parallel forward: `latent` [1,Tn,C] / `velocity` [1,Tn,C] hold this rank's token slice; `gather(send_ptr,
         recv_ptr, nbytes)` all-gathers device memory over the ranks (see dist.sp_allgather_fn). Device tensors."""
         S = context.shape[1]
-
-        def _cb(_user, send, recv, nbytes):
-            gather(send, recv, nbytes)
-
-        cb = _ALLGATHER_FN(_cb)  # kept alive for the duration of the call
-        self._ck(lib.ltx_dit_forward_sp_dev(self._h, _ptr(latent), _ptr(context), _ptr(timesteps), _ptr(mask), int(mask_all_ones),
-                                            F, H, W, S, ctx_version, sp_rank, sp_world, C.cast(cb, C.c_void_p), None,
-                                            _ptr(velocity)))
+        tr = _Transport(gather) if gather is not None else None  # None: the context's own transport (dist_init / dist_set_transport)
+        rc = lib.ltx_dit_forward_sp_dev(self._h, _ptr(latent), _ptr(context), _ptr(timesteps), _ptr(mask), int(mask_all_ones),
+                                        F, H, W, S, ctx_version, sp_rank, sp_world, C.cast(tr.cfn, C.c_void_p) if tr else None, None,
+                                        _ptr(velocity))
+        if tr:
+            tr.reraise()
+        self._ck(rc)
 
     def dit_set_cross_attn_scale(self, scale, first=0, last=-1):
         self._ck(lib.ltx_dit_set_cross_attn_scale(self._h, scale, first, last))
@@ -331,6 +404,27 @@ class Context:
         n = C.c_int()
         self._ck(lib.ltx_vae_decode_dev(self._h, _ptr(latent), F, H, W, int(timestep is not None), float(timestep or 0.0),
                                         _ptr(noise), tile, overlap, _ptr(frames), frames.numel(), C.byref(n)))
+        return n.value
+
+    def vae_decode_sharded_dev(self, latent, F, H, W, frames, timestep=None, noise=None, tile=0, overlap=1):
+        """Tiles round-robin over the context's group, raw tiles broadcast, blend + clip on every rank."""
+        n = C.c_int()
+        self._ck(lib.ltx_vae_decode_sharded_dev(self._h, _ptr(latent), F, H, W, int(timestep is not None), float(timestep or 0.0),
+                                                _ptr(noise), tile, overlap, _ptr(frames), frames.numel(), C.byref(n)))
+        return n.value
+
+    def vae_decode_tile_dev(self, latent, F, H, W, tile, overlap, tile_index, out, timestep=None, noise=None):
+        """RAW frames (pre-blend, pre-clip) of one tile of the plan -> out; returns its frame count."""
+        n = C.c_int()
+        self._ck(lib.ltx_vae_decode_tile_dev(self._h, _ptr(latent), F, H, W, int(timestep is not None), float(timestep or 0.0),
+                                             _ptr(noise), tile, overlap, tile_index, _ptr(out), out.numel(), C.byref(n)))
+        return n.value
+
+    def vae_blend_tiles_dev(self, tiles, tile_frames, overlap, H, W, frames):
+        n = C.c_int()
+        ptrs = (C.c_void_p * len(tiles))(*[t.data_ptr() for t in tiles])
+        nfs = (C.c_int * len(tiles))(*tile_frames)
+        self._ck(lib.ltx_vae_blend_tiles_dev(self._h, ptrs, nfs, len(tiles), overlap, H, W, _ptr(frames), frames.numel(), C.byref(n)))
         return n.value
 
     def op_conv3d(self, x, w, bias, out, causal=False):
@@ -439,7 +533,7 @@ class Context:
     # ---- denoise loop ----
     @staticmethod
     def _options(cfg_scale=1.0, guidance_rescale=0.0, stg_scale=0.0, stg_blocks=(29,), ge_gamma=0.0, cond_latent=None,
-                 image_cond_noise_scale=0.0, cond_noise=None):
+                 image_cond_noise_scale=0.0, cond_noise=None, shard=SHARD_NONE):
         """cond_latent / cond_noise (image-to-video): numpy arrays for the host entry point, torch tensors for the device one."""
         arr = (C.c_int * max(1, len(stg_blocks)))(*stg_blocks)
         if isinstance(cond_latent, np.ndarray):
@@ -447,7 +541,7 @@ class Context:
         if isinstance(cond_noise, np.ndarray):
             cond_noise = np.ascontiguousarray(cond_noise, dtype=np.float32)
         o = DenoiseOptions(cfg_scale, guidance_rescale, stg_scale, C.cast(arr, C.POINTER(C.c_int)), len(stg_blocks), ge_gamma,
-                           _ptr(cond_latent), image_cond_noise_scale, _ptr(cond_noise))
+                           _ptr(cond_latent), image_cond_noise_scale, _ptr(cond_noise), int(shard))
         o._keep = (arr, cond_latent, cond_noise)
         return o
 

@@ -31,10 +31,14 @@ class DenoiseOptions(C.Structure):
 
     _fields_ = [("cfg_scale", C.c_float), ("guidance_rescale", C.c_float), ("stg_scale", C.c_float),
                 ("stg_blocks", C.POINTER(C.c_int)), ("n_stg_blocks", C.c_int), ("ge_gamma", C.c_float),
-                ("cond_latent", C.c_void_p), ("image_cond_noise_scale", C.c_float), ("cond_noise", C.c_void_p)]
+                ("cond_latent", C.c_void_p), ("image_cond_noise_scale", C.c_float), ("cond_noise", C.c_void_p),
+                ("shard", C.c_int)]
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_float, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long)  # ltx_allgather_fn
+SHARD_NONE, SHARD_CFG, SHARD_SEQUENCE = 0, 1, 2
+DIST_ID_BYTES = 128
 
 
 class ConnectorConfig(C.Structure):
@@ -94,6 +98,17 @@ SIGNATURES = {
     "ltx_dit_unload": (_i, [_vp]),
     "ltx_dit_quantize": (_i, [_vp, _i, _i]),
     "ltx_dit_fuse_lora": (_i, [_vp, C.c_char_p, _f, _ip]),
+    "ltx_dit_export_param": (_l, [_vp, C.c_char_p, _vp, _l]),
+    "ltx_dist_unique_id": (_i, [_vp]),
+    "ltx_dist_init": (_i, [_vp, _i, _i, _vp]),
+    "ltx_dist_set_transport": (_i, [_vp, _i, _i, _vp, _vp]),
+    "ltx_dist_shutdown": (_i, [_vp]),
+    "ltx_dist_info": (_i, [_vp, _ip, _ip, _ip, C.POINTER(C.c_long)]),
+    "ltx_dist_allgather_dev": (_i, [_vp, _vp, _vp, _l]),
+    "ltx_dist_broadcast_dev": (_i, [_vp, _vp, _l, _i]),
+    "ltx_vae_decode_tile_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp, _l, _ip]),
+    "ltx_vae_blend_tiles_dev": (_i, [_vp, C.POINTER(_vp), _ip, _i, _i, _i, _i, _vp, _l, _ip]),
+    "ltx_vae_decode_sharded_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _l, _ip]),
     "ltx_dit_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ltx_dit_forward_tokens": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ltx_dit_forward_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _vp]),

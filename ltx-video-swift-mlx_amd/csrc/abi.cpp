@@ -8,6 +8,7 @@
 #include "../../include/ltxhip.h"
 #include "attention.h"
 #include "connector.h"
+#include "dist.h"
 #include "dit.h"
 #include "elementwise.h"
 #include "gemm.h"
@@ -133,6 +134,7 @@ void ltx_ctx_destroy(ltx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    try { dist_shutdown(ctx); } catch (...) {}
     if (ctx->dit) dit_destroy(ctx->dit);
     if (ctx->vae) vae_destroy(ctx->vae);
     if (ctx->upscaler) upscaler_destroy(ctx->upscaler);
@@ -372,7 +374,7 @@ int ltx_dit_forward_sp_dev(ltx_ctx* ctx, const uint16_t* latent, const uint16_t*
     if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
     return guarded(ctx, [&] {
         DiTModel* m = need_dit(ctx);
-        LTX_REQUIRE(sp_world >= 1 && (sp_world == 1 || gather), "ltx_dit_forward_sp_dev: %d ranks need a gather callback", sp_world);
+        LTX_REQUIRE(sp_world >= 1 && (sp_world == 1 || gather || ctx->dist), "ltx_dit_forward_sp_dev: %d ranks need a gather callback or ltx_dist_init", sp_world);
         DiTForwardArgs a;
         a.latent = latent;
         a.context = context;
@@ -605,6 +607,48 @@ int ltx_vae_decode_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, i
     });
 }
 
+int ltx_vae_decode_sharded_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
+                               const float* noise, int tile, int overlap, float* frames_out, long frames_cap,
+                               int* n_frames_out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        VaeModel* m = need_vae(ctx);
+        LTX_REQUIRE(ctx->dist, "ltx_vae_decode_sharded_dev: no group on this context (ltx_dist_init / ltx_dist_set_transport)");
+        VaeDecodeArgs a;
+        a.latent = latent; a.F = F; a.H = H; a.W = W;
+        a.has_timestep = has_timestep; a.timestep = timestep; a.noise = noise;
+        a.tile = tile; a.overlap = overlap;
+        a.frames = frames_out; a.frames_cap = frames_cap; a.n_frames_out = n_frames_out;
+        a.shard = 1;
+        vae_decode(ctx, m, a);
+    });
+}
+
+int ltx_vae_decode_tile_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
+                            const float* noise, int tile, int overlap, int tile_index, float* tile_out, long tile_cap,
+                            int* n_frames_out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        VaeModel* m = need_vae(ctx);
+        VaeDecodeArgs a;
+        a.latent = latent; a.F = F; a.H = H; a.W = W;
+        a.has_timestep = has_timestep; a.timestep = timestep; a.noise = noise;
+        a.tile = tile; a.overlap = overlap;
+        a.frames = tile_out; a.frames_cap = tile_cap; a.n_frames_out = n_frames_out;
+        vae_decode_tile(ctx, m, a, tile_index);
+    });
+}
+
+int ltx_vae_blend_tiles_dev(ltx_ctx* ctx, const float* const* tiles, const int* tile_frames, int n_tiles, int overlap, int H,
+                            int W, float* frames_out, long frames_cap, int* n_frames_out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        LTX_REQUIRE(H >= 1 && W >= 1, "ltx_vae_blend_tiles_dev: bad latent size");
+        const int n = vae_blend_tiles(ctx, tiles, tile_frames, n_tiles, overlap, H, W, frames_out, frames_cap);
+        if (n_frames_out) *n_frames_out = n;
+    });
+}
+
 int ltx_vae_decode(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
                    const float* noise, int tile, int overlap, float* frames_out, long frames_cap, int* n_frames_out) {
     if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
@@ -751,6 +795,7 @@ static void fill_params(DenoiseParams& p, const ltx_denoise_options* o) {
     p.cond_latent = o->cond_latent;  // device variant: used as given; host variant: replaced by staged copies below
     p.image_cond_noise_scale = o->image_cond_noise_scale;
     p.cond_noise = o->cond_noise;
+    p.shard = o->shard;
 }
 
 int ltx_denoise_dev(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* sigmas, int n_sigmas,
@@ -817,6 +862,63 @@ int ltx_denoise(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* s
         HIP_CHECK(hipMemcpyAsync(latent, ctx->h2d[5].p, n_lat, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
     });
+}
+
+// ---- multi-GPU ----
+int ltx_dist_unique_id(void* id_out) {
+    if (!id_out) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(nullptr, [&] { dist_unique_id(id_out); });
+}
+
+int ltx_dist_init(ltx_ctx* ctx, int rank, int world, const void* id) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { dist_init_native(ctx, rank, world, id); });
+}
+
+int ltx_dist_set_transport(ltx_ctx* ctx, int rank, int world, ltx_allgather_fn gather, void* user) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { dist_set_transport(ctx, rank, world, gather, user); });
+}
+
+int ltx_dist_shutdown(ltx_ctx* ctx) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { dist_shutdown(ctx); });
+}
+
+int ltx_dist_info(const ltx_ctx* ctx, int* rank, int* world, int* native_transport, long* n_collectives) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    if (rank) *rank = dist_rank(ctx);
+    if (world) *world = dist_world(ctx);
+    if (native_transport) *native_transport = (ctx->dist && ctx->dist->comm) ? 1 : 0;
+    if (n_collectives) *n_collectives = ctx->dist ? ctx->dist->n_collectives : 0;
+    return LTX_OK;
+}
+
+int ltx_dist_allgather_dev(ltx_ctx* ctx, const void* send, void* recv, long bytes) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { dist_allgather(ctx, send, recv, bytes); });
+}
+
+int ltx_dist_broadcast_dev(ltx_ctx* ctx, void* buf, long bytes, int root) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { dist_broadcast(ctx, buf, bytes, root); });
+}
+
+long ltx_dit_export_param(ltx_ctx* ctx, const char* module_key, float* out, long cap) {
+    if (!ctx || !module_key) return -LTX_ERR_INVALID_CONFIGURATION;
+    long n = 0;
+    const int rc = guarded(ctx, [&] {
+        DiTModel* m = need_dit(ctx);
+        auto it = m->slots.find(module_key);
+        LTX_REQUIRE(it != m->slots.end(), "ltx_dit_export_param: no parameter '%s'", module_key);
+        const ParamSlot& sl = it->second;
+        n = sl.numel;
+        if (!out) return;
+        LTX_REQUIRE(cap >= n, "ltx_dit_export_param: buffer too small (%ld < %ld)", cap, n);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        dit_export_slot(ctx, m, sl, out);
+    });
+    return rc == 0 ? n : -rc;
 }
 
 int ltx_prof_enable(ltx_ctx* ctx, int on) {

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "attention.h"
+#include "dist.h"
 #include "elementwise.h"
 #include "gemm.h"
 #include "linear_ops.h"
@@ -189,6 +190,18 @@ void dit_init_synthetic(ltx_ctx* ctx, DiTModel* m, uint64_t seed) {
     for (auto* c : m->ctx_cache) c->version = 0;
 }
 
+void dit_export_slot(ltx_ctx* ctx, DiTModel* m, const ParamSlot& s, float* out) {
+    (void)ctx;
+    (void)m;
+    if (s.kind == SLOT_F32) {
+        HIP_CHECK(hipMemcpy(out, s.dst, (size_t)s.numel * 4, hipMemcpyDeviceToHost));
+        return;
+    }
+    std::vector<bf16_t> h((size_t)s.numel);
+    HIP_CHECK(hipMemcpy(h.data(), s.dst, (size_t)s.numel * 2, hipMemcpyDeviceToHost));
+    for (long i = 0; i < s.numel; ++i) out[i] = host_bf16_to_f32(h[i]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
@@ -306,9 +319,20 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     const int D = m->D, L = m->L, B = a.B;
     const int Tfull = a.F * a.H * a.W;
     const int NW = a.sp_world < 1 ? 1 : a.sp_world;
-    LTX_REQUIRE(NW == 1 || (a.sp_gather && B == 1 && a.sp_rank >= 0 && a.sp_rank < NW && Tfull % NW == 0 && (Tfull / NW) % 8 == 0),
-                "dit_forward: sequence parallelism needs a gather callback, batch 1 and F*H*W = %d divisible by %d ranks into multiples of 8",
-                Tfull, NW);
+    LTX_REQUIRE(NW == 1 || ((a.sp_gather || (ctx->dist && ctx->dist->world == NW && ctx->dist->rank == a.sp_rank)) && B == 1 &&
+                            a.sp_rank >= 0 && a.sp_rank < NW && Tfull % NW == 0 && (Tfull / NW) % 8 == 0),
+                "dit_forward: sequence parallelism needs a transport (callback or ltx_dist_init with the same rank/world), batch 1 and "
+                "F*H*W = %d divisible by %d ranks into multiples of 8", Tfull, NW);
+    // all-gather of this forward: the caller's callback, else the context's transport. A failing transport stops the forward - the
+    // kernels behind it would read unfilled K / V^T while the peer rank blocks in its collective.
+    auto sp_allgather = [&](const void* send, void* recv, long bytes) {
+        if (a.sp_gather) {
+            const int rc = a.sp_gather(a.sp_user, send, recv, bytes);
+            if (rc != 0) LTX_THROW(LTXS_GENERATION_FAILED, "sequence-parallel all-gather failed on rank %d of %d (status %d)", a.sp_rank, NW, rc);
+        } else {
+            dist_allgather(ctx, send, recv, bytes);
+        }
+    };
     const int T = Tfull / NW;            // rows this rank evaluates
     const int tok0 = a.sp_rank * T;      // first global token of this rank (NW == 1: 0)
     LTX_REQUIRE(B >= 1 && B <= 8 && T >= 1 && a.S >= 1, "dit_forward: bad shapes B=%d T=%d S=%d", B, T, a.S);
@@ -398,8 +422,8 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
                 // keys / values of every rank's tokens: K rows gather straight into global token order; V^T blocks [D][T] of
                 // the ranks are interleaved into [D][Tfull] after the gather
                 gemm_vt(xn, D, T, blk.v1, vt, T, st, sk);  // V^T of the local tokens, dense [D][T]
-                a.sp_gather(a.sp_user, k, k_full, (long)T * D * 2);
-                a.sp_gather(a.sp_user, vt, m->ws_sp_vtg.p, (long)D * T * 2);
+                sp_allgather(k, k_full, (long)T * D * 2);
+                sp_allgather(vt, m->ws_sp_vtg.p, (long)D * T * 2);
                 launch_sp_vt_interleave(m->ws_sp_vtg.as<bf16_t>(), vt_full, NW, D, T, TfullPad, st);
                 at.Vt = vt_full; at.ldvt = TfullPad; at.vt_bstride = (long)D * TfullPad;
                 at.K = k_full; at.k_bstride = (long)Tfull * D;

@@ -84,6 +84,8 @@ void dit_destroy(DiTModel* m);
 // Fill every parameter from a safetensors file using the reference's key mapping; returns counts via ctx.
 void dit_load_safetensors(ltx_ctx* ctx, DiTModel* m, const std::string& path);
 void dit_init_synthetic(ltx_ctx* ctx, DiTModel* m, uint64_t seed);
+// one parameter back to the host as f32 (parity tests hand the resident weights to the CPU oracle)
+void dit_export_slot(ltx_ctx* ctx, DiTModel* m, const ParamSlot& s, float* out);
 
 struct DiTForwardArgs {
     const bf16_t* latent = nullptr;   // device [B][T][in_channels] bf16
@@ -102,9 +104,10 @@ struct DiTForwardArgs {
     // Sequence parallelism over sp_world ranks (single sample on several GPUs): this rank owns tokens
     // [sp_rank*Tn, (sp_rank+1)*Tn), Tn = F*H*W / sp_world, and `latent`, `row_map`, `velocity` hold only those Tn rows. Every
     // per-token operation is local; self-attention all-gathers K and V^T of each layer through `sp_gather`, which must
-    // enqueue on the context's stream (or synchronise) an all-gather of `bytes` per rank: recv = [sp_world][bytes], rank order.
+    // enqueue on the context's stream (or synchronise) an all-gather of `bytes` per rank: recv = [sp_world][bytes], rank order,
+    // and return 0 (anything else aborts the forward). Null = the context's own transport (dist.h: RCCL or the host transport).
     int sp_rank = 0, sp_world = 1;
-    void (*sp_gather)(void* user, const void* send, void* recv, long bytes) = nullptr;
+    int (*sp_gather)(void* user, const void* send, void* recv, long bytes) = nullptr;
     void* sp_user = nullptr;
 };
 void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a);

@@ -1,8 +1,15 @@
 // pipeline.cpp - see pipeline.h.
 #include "pipeline.h"
 
+#include "dist.h"
 #include "dit.h"
 #include "elementwise.h"
+
+// Cache keys of the projected text context (dit.cpp prepare_context matches entries on (key, B, S)). Every pass of this loop
+// derives its key the same way from the caller's version, in a namespace of its own (top bit set), so that no two passes with
+// different contents can meet on one key whatever small counters a caller uses: kind 0 = the [neg,pos] batch, 1 = the negative
+// context alone, 2 = the positive context alone (plain forward, sharded positive branch and the STG pass share this entry).
+static uint64_t ctx_key(uint64_t ver, int kind) { return ver ? (0x8000000000000000ull | ((ver << 2) + (uint64_t)kind)) : 0; }
 
 void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
     DiTModel* m = ctx->dit;
@@ -13,18 +20,31 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
     const int T = p.F * p.H * p.W;
     const long n = (long)C * T;
     const bool use_cfg = p.cfg_scale > 1.0f;
-    const bool sharded = use_cfg && p.cfg_branch >= 0 && p.exchange;
-    const int B = (use_cfg && !sharded) ? 2 : 1;
+    const int world = dist_world(ctx), rank = dist_rank(ctx);
+    LTX_REQUIRE(p.shard == SHARD_NONE || p.shard == SHARD_CFG || p.shard == SHARD_SEQUENCE, "denoise: unknown shard mode %d", p.shard);
+    LTX_REQUIRE(p.shard == SHARD_NONE || ctx->dist, "denoise: a sharded loop needs ltx_dist_init / ltx_dist_set_transport on this context");
+    const bool cfg_sharded = p.shard == SHARD_CFG && use_cfg;
+    if (p.shard == SHARD_CFG) {
+        LTX_REQUIRE(use_cfg, "denoise: CFG sharding needs cfg_scale > 1 (got %g)", (double)p.cfg_scale);
+        LTX_REQUIRE(world == 2 || (world == 3 && p.stg_scale > 0.f),
+                    "denoise: the CFG pair shards over 2 ranks (3 with an STG pass); this context's group has %d", world);
+    }
+    const bool seq = p.shard == SHARD_SEQUENCE && world > 1;
+    if (seq) LTX_REQUIRE(T % world == 0 && (T / world) % 8 == 0, "denoise: %d tokens do not split over %d ranks into multiples of 8", T, world);
+    const int Tn = seq ? T / world : T;
+    const int tok0 = seq ? rank * Tn : 0;
+    const int B = (use_cfg && !cfg_sharded && !seq) ? 2 : 1;
     hipStream_t st = ctx->stream;
     const long cap = m->cfg.caption_channels;
 
     ctx->dn_tokens.ensure((size_t)2 * n * 2);
     ctx->dn_vel_tok.ensure((size_t)2 * n * 4);
-    ctx->dn_vel.ensure((size_t)2 * n * 4);
+    ctx->dn_vel.ensure((size_t)3 * n * 4);
     ctx->dn_vel2.ensure((size_t)n * 4);
     ctx->dn_vel3.ensure((size_t)n * 4);
     ctx->dn_prev.ensure((size_t)n * 4);
     ctx->dn_ts.ensure(8 * 4);
+    if (seq) ctx->dn_vel_slice.ensure((size_t)Tn * C * 4);
     const bool i2v = p.cond_latent != nullptr;
     const int HW = p.H * p.W;
     const int G = i2v ? 2 : 1;  // timestep groups per batch element: 0 = sigma, 1 = frame-0 tokens at 0
@@ -37,9 +57,9 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
     ctx->dn_stats.ensure(16 * 4);
     bf16_t* tokens = ctx->dn_tokens.as<bf16_t>();
     float* vel_tok = ctx->dn_vel_tok.as<float>();
-    float* vel = ctx->dn_vel.as<float>();   // [B][C][T]
+    float* vel = ctx->dn_vel.as<float>();   // [2 or 3][C][T]: negative, positive (, STG-perturbed)
     float* v = ctx->dn_vel2.as<float>();    // guided velocity
-    float* vp = ctx->dn_vel3.as<float>();   // STG perturbed velocity
+    float* vp = ctx->dn_vel3.as<float>();   // STG perturbed velocity / this rank's branch before the exchange
     float* prev = ctx->dn_prev.as<float>();
     bool have_prev = false;
 
@@ -48,21 +68,41 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
     const int32_t* mask_pos = (use_cfg && p.mask) ? p.mask + p.S : p.mask;
     const uint64_t ver = p.ctx_version;
 
-    auto forward = [&](const bf16_t* tok, const bf16_t* c, const int32_t* mk, int b, uint64_t version, float* out_tok) {
+    auto forward = [&](const bf16_t* tok, const bf16_t* c, const int32_t* mk, int b, uint64_t key, float* out_tok) {
         DiTForwardArgs a;
-        a.latent = tok;
         a.context = c;
         a.timesteps = ctx->dn_ts.as<float>();
         a.mask = mk;
         a.mask_all_ones = p.mask_all_ones;
         a.B = b; a.F = p.F; a.H = p.H; a.W = p.W; a.S = p.S;
-        a.ctx_version = version;
-        a.velocity = out_tok;
+        a.ctx_version = key;
         if (i2v) {
             a.n_groups = G;
-            a.row_map = ctx->dn_rowmap.as<int32_t>();
+            a.row_map = ctx->dn_rowmap.as<int32_t>() + tok0;
         }
+        if (!seq) {
+            a.latent = tok;
+            a.velocity = out_tok;
+            dit_forward(ctx, m, a);
+            return;
+        }
+        // this rank's token rows only; the [T/N][C] velocity slices of all ranks land in global token order
+        a.latent = tok + (size_t)tok0 * C;
+        a.velocity = ctx->dn_vel_slice.as<float>();
+        a.sp_rank = rank;
+        a.sp_world = world;
         dit_forward(ctx, m, a);
+        dist_allgather(ctx, a.velocity, out_tok, (long)Tn * C * 4);
+    };
+    auto set_stg = [&](bool on) {
+        if (on) {
+            for (int j = 0; j < p.n_stg; ++j) {
+                const int i = p.stg_blocks[j];
+                if (i >= 0 && i < m->L) m->blocks[i].skip_attn = true;
+            }
+        } else {
+            for (auto& b : m->blocks) b.skip_attn = b.skip_ff = false;  // clearSTGSkipFlags
+        }
     };
 
     const int steps = p.n_sigmas - 1;
@@ -85,18 +125,31 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
         launch_patchify_bf16(p.latent, tokens, 1, C, T, st);
         if (B == 2) HIP_CHECK(hipMemcpyAsync(tokens + n, tokens, (size_t)n * 2, hipMemcpyDeviceToDevice, st));
 
+        bool have_stg = false;  // vel + 2n already holds the STG-perturbed velocity (three-rank group)
         if (!use_cfg) {
-            forward(tokens, p.context, p.mask, 1, ver, vel_tok);
+            forward(tokens, p.context, p.mask, 1, ctx_key(ver, 2), vel_tok);
             launch_unpatchify_f32(vel_tok, v, 1, C, T, st);
         } else {
-            if (sharded) {
-                // this rank's branch only; velocities are exchanged over xGMI (RCCL) by the caller's hook
-                const bool pos = p.cfg_branch == 1;
-                forward(tokens, pos ? ctx_pos : p.context, pos ? mask_pos : p.mask, 1, ver ? ver * 4 + 1 + (pos ? 1 : 0) : 0, vel_tok);
+            if (cfg_sharded) {
+                // this rank's pass only; one all-gather per step brings the others' velocities over xGMI
+                if (rank == 0) {
+                    forward(tokens, p.context, p.mask, 1, ctx_key(ver, 1), vel_tok);
+                } else {
+                    if (rank == 2) set_stg(true);
+                    forward(tokens, ctx_pos, mask_pos, 1, ctx_key(ver, 2), vel_tok);
+                    if (rank == 2) set_stg(false);
+                }
                 launch_unpatchify_f32(vel_tok, vp, 1, C, T, st);
-                p.exchange(vel, vp, n, p.exchange_user);  // vel = [neg | pos]
+                dist_allgather(ctx, vp, vel, n * 4);  // vel = [neg | pos (| stg)]
+                have_stg = world == 3;
+            } else if (seq) {
+                // two sequence-parallel B=1 forwards (LTXPipeline.swift:829-848)
+                forward(tokens, p.context, p.mask, 1, ctx_key(ver, 1), vel_tok);
+                launch_unpatchify_f32(vel_tok, vel, 1, C, T, st);
+                forward(tokens, ctx_pos, mask_pos, 1, ctx_key(ver, 2), vel_tok);
+                launch_unpatchify_f32(vel_tok, vel + n, 1, C, T, st);
             } else {
-                forward(tokens, p.context, p.mask, 2, ver ? ver * 4 : 0, vel_tok);
+                forward(tokens, p.context, p.mask, 2, ctx_key(ver, 0), vel_tok);
                 launch_unpatchify_f32(vel_tok, vel, 2, C, T, st);
             }
             const float* uncond = vel;
@@ -111,14 +164,16 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
         }
         // STG: extra cond-only pass with self-attention skipped on stg_blocks (LTXPipeline.swift:897-921)
         if (p.stg_scale > 0.f) {
-            for (int j = 0; j < p.n_stg; ++j) {
-                const int i = p.stg_blocks[j];
-                if (i >= 0 && i < m->L) m->blocks[i].skip_attn = true;
+            const float* pert = vp;
+            if (have_stg) {
+                pert = vel + 2 * n;
+            } else {
+                set_stg(true);
+                forward(tokens, ctx_pos, mask_pos, 1, ctx_key(ver, 2), vel_tok);
+                set_stg(false);
+                launch_unpatchify_f32(vel_tok, vp, 1, C, T, st);
             }
-            forward(tokens, ctx_pos, mask_pos, 1, ver ? ver * 4 + 2 : 0, vel_tok);
-            for (auto& b : m->blocks) b.skip_attn = b.skip_ff = false;  // clearSTGSkipFlags
-            launch_unpatchify_f32(vel_tok, vp, 1, C, T, st);
-            launch_axpby(v, vp, p.stg_scale, 1.0f, v, n, st);  // v + s*(v - vp)
+            launch_axpby(v, pert, p.stg_scale, 1.0f, v, n, st);  // v + s*(v - vp)
         }
         // GE velocity correction (LTXPipeline.swift:924-927): v = g*(v - prev) + prev ; prev <- v
         if (p.ge_gamma > 0.f && have_prev) launch_ge(v, prev, p.ge_gamma, v, n, st);

@@ -31,12 +31,17 @@ struct DenoiseParams {
     const float* cond_noise = nullptr;  // device f32 [n_sigmas-1][C][1][H][W] N(0,1) draws, or null (no injection)
     ltx_progress_fn progress = nullptr;
     void* user = nullptr;
-    // multi-GPU CFG sharding hook (config 3): when set, this rank evaluates only branch `cfg_branch`
-    // (0 = negative, 1 = positive) and `exchange` must return both velocities (device f32 [2][C*T]) - bench/dist
-    // layer provides it via RCCL all-gather. Null = single-GPU batched CFG.
-    int cfg_branch = -1;
-    void (*exchange)(float* both /*[2][n]*/, const float* mine /*[n]*/, long n, void* user) = nullptr;
-    void* exchange_user = nullptr;
+    // multi-GPU sharding of this loop over the context's ranks (dist.h; the reference is single-device):
+    //   SHARD_CFG: the CFG pair (LTXPipeline.swift:820-865 two B=1 forwards, :2235-2283 one B=2 forward) is split over the ranks -
+    //     rank 0 evaluates the negative branch, rank 1 the positive one (rank 2, when the group has three, the STG-perturbed pass);
+    //     ONE all-gather of the [C*T] f32 velocities per step, then every rank applies CFG / rescale / STG / GE / Euler redundantly
+    //     with the library's own kernels, so the ranks' latents stay bit-identical without a second collective.
+    //   SHARD_SEQUENCE: one sample's tokens are split over the ranks (dit_forward's sequence parallelism); one all-gather of the
+    //     [T/N][C] velocity slices per forward; scheduler arithmetic redundant on every rank. CFG runs as two sequential B=1
+    //     forwards, as generateVideo does (LTXPipeline.swift:829-848).
+    int shard = 0;
 };
+
+enum { SHARD_NONE = 0, SHARD_CFG = 1, SHARD_SEQUENCE = 2 };
 
 void denoise_run(ltx_ctx* ctx, const DenoiseParams& p);

@@ -87,6 +87,7 @@ struct VaeModel;
 struct ConnectorModel;
 struct VaeEncoderModel;
 struct UpscalerModel;
+struct DistState;
 
 // ---- live per-kernel timing (HIP events recorded on the launch stream around each launch of a kernel family) ----
 // Used by bench.py for the roofline numbers: achieved = algorithmic work of the launches / their summed duration.
@@ -133,6 +134,7 @@ struct ltx_ctx {
     UpscalerModel* upscaler = nullptr;
     ConnectorModel* connector = nullptr;
     VaeEncoderModel* vae_encoder = nullptr;
+    DistState* dist = nullptr;  // multi-GPU state (dist.h); null = single GPU
     // staging buffers for host-pointer entry points
     DevBuf h2d[8];
     // load report of the last *_load call (mirrors the reference's "unmatched/missing" debug logs)
@@ -141,6 +143,7 @@ struct ltx_ctx {
     // denoise-loop scratch (device)
     DevBuf dn_tokens, dn_vel_tok, dn_vel, dn_vel2, dn_vel3, dn_prev, dn_ts, dn_stats, dn_lat2;
     DevBuf dn_rowmap;  // I2V token -> timestep-group map
+    DevBuf dn_vel_slice;  // sequence-sharded loop: this rank's [T/N][C] velocity rows before the all-gather
     DevBuf i2v_cond, i2v_noise;  // staged image latent / re-noising draws of the host-pointer denoise entry
     DevBuf op_ws;  // split-K workspace of the kernel-level test hook
 };

@@ -2,6 +2,8 @@
 // tile + decodeVideo / decodeWithTemporalTiling (VideoDecoder.swift:466-602).
 #include "vae.h"
 
+#include "dist.h"
+
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -347,22 +349,15 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
 
 }  // namespace
 
-void vae_decode(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a) {
-    LTX_REQUIRE(a.latent && a.frames && a.F >= 1 && a.H >= 2 && a.W >= 2, "vae_decode: bad arguments (F=%d H=%d W=%d)", a.F, a.H, a.W);
-    LTX_REQUIRE(!a.has_timestep || a.noise, "vae_decode: timestep conditioning needs an explicit noise tensor");
-    const TilePlan plan = vae_tile_plan(a.F, a.tile, a.overlap);
-    LTX_REQUIRE(!plan.start.empty(), "vae_decode: temporal tile size %d must exceed overlap %d", a.tile, a.overlap);
-    hipStream_t st = ctx->stream;
-    const long HWpix = (long)a.H * 32 * a.W * 32 * 3;
-    LTX_REQUIRE(a.frames_cap >= (long)plan.out_frames * HWpix, "vae_decode: output buffer too small (%ld < %ld floats)",
-                a.frames_cap, (long)plan.out_frames * HWpix);
-    // workspace sized for the largest tile
+namespace {
+
+void ensure_decode_workspace(ltx_ctx* ctx, VaeModel* m, const TilePlan& plan, int H, int W) {
     int maxf = 0;
     for (size_t i = 0; i < plan.start.size(); ++i) maxf = std::max(maxf, plan.end[i] - plan.start[i]);
-    const long P3 = (long)(8 * (maxf - 1) + 1) * (a.H * 8) * (a.W * 8);
+    const long P3 = (long)(8 * (maxf - 1) + 1) * (H * 8) * (W * 8);
     const long elems = P3 * 128;
     if (elems > m->ws_elems) {
-        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
         m->xa.ensure((size_t)elems * 4);
         m->xb.ensure((size_t)elems * 4);
         m->t1.ensure((size_t)elems * 4);
@@ -372,36 +367,134 @@ void vae_decode(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a) {
     }
     m->mods.ensure((size_t)(20 * 4 * 1024 + 256) * 4);
     m->temb.ensure((size_t)(8192 + 64) * 4);
+}
+
+TilePlan checked_plan(const VaeDecodeArgs& a) {
+    LTX_REQUIRE(a.latent && a.F >= 1 && a.H >= 2 && a.W >= 2, "vae_decode: bad arguments (F=%d H=%d W=%d)", a.F, a.H, a.W);
+    LTX_REQUIRE(!a.has_timestep || a.noise, "vae_decode: timestep conditioning needs an explicit noise tensor");
+    const TilePlan plan = vae_tile_plan(a.F, a.tile, a.overlap);
+    LTX_REQUIRE(!plan.start.empty(), "vae_decode: temporal tile size %d must exceed overlap %d", a.tile, a.overlap);
+    return plan;
+}
+
+// raw frames of tile i of the plan -> dst; returns its frame count
+int decode_plan_tile(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a, const TilePlan& plan, int i, float* dst, int apply_clip) {
     const long chan_stride = (long)a.F * a.H * a.W;
     const long hw = (long)a.H * a.W;
-    if (plan.start.size() == 1) {
-        const int nf = decode_tile(ctx, m, a.latent, chan_stride, a.noise, a.has_timestep, a.timestep, Dims{a.F, a.H, a.W}, a.frames, 1);
-        if (a.n_frames_out) *a.n_frames_out = nf;
-        return;
-    }
-    // temporal tiling with linear blending of 8*overlap pixel frames (VideoDecoder.swift:517-602)
-    const int po = 8 * a.overlap;
-    m->tile_frames.ensure((size_t)(8 * (maxf - 1) + 1) * HWpix * 4);
+    const int s = plan.start[i], e = plan.end[i];
+    return decode_tile(ctx, m, a.latent + s * hw, chan_stride, a.noise ? a.noise + s * hw : nullptr, a.has_timestep, a.timestep,
+                       Dims{e - s, a.H, a.W}, dst, apply_clip);
+}
+
+}  // namespace
+
+int vae_decode_tile(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a, int tile_index) {
+    const TilePlan plan = checked_plan(a);
+    LTX_REQUIRE(tile_index >= 0 && tile_index < (int)plan.start.size(), "vae_decode_tile: tile %d of %d", tile_index, (int)plan.start.size());
+    LTX_REQUIRE(a.frames, "vae_decode_tile: null output");
+    const long HWpix = (long)a.H * 32 * a.W * 32 * 3;
+    const int nf = 8 * (plan.end[tile_index] - plan.start[tile_index] - 1) + 1;
+    LTX_REQUIRE(a.frames_cap >= (long)nf * HWpix, "vae_decode_tile: output buffer too small (%ld < %ld floats)", a.frames_cap, (long)nf * HWpix);
+    ensure_decode_workspace(ctx, m, plan, a.H, a.W);
+    const int got = decode_plan_tile(ctx, m, a, plan, tile_index, a.frames, 0);
+    if (a.n_frames_out) *a.n_frames_out = got;
+    return got;
+}
+
+int vae_blend_tiles(ltx_ctx* ctx, const float* const* tiles, const int* tile_frames, int n_tiles, int overlap, int H, int W, float* frames,
+                    long frames_cap) {
+    LTX_REQUIRE(tiles && tile_frames && n_tiles >= 1 && frames && overlap >= 0, "vae_blend_tiles: bad arguments");
+    hipStream_t st = ctx->stream;
+    const long HWpix = (long)H * 32 * W * 32 * 3;
+    const int po = 8 * overlap;
+    // frame count first (the walk of VideoDecoder.swift:561-592), so that a short buffer is refused before anything is written
+    long total = tile_frames[0];
+    for (int i = 1; i < n_tiles; ++i) total += (po > 0 && po < total && po < tile_frames[i]) ? tile_frames[i] - po : tile_frames[i];
+    LTX_REQUIRE(frames_cap >= total * HWpix, "vae_blend_tiles: output buffer too small (%ld < %ld floats)", frames_cap, total * HWpix);
     long cur = 0;
-    for (size_t i = 0; i < plan.start.size(); ++i) {
-        const int s = plan.start[i], e = plan.end[i];
-        float* dst = (i == 0) ? a.frames : m->tile_frames.as<float>();
-        const int nf = decode_tile(ctx, m, a.latent + s * hw, chan_stride, a.noise ? a.noise + s * hw : nullptr, a.has_timestep,
-                                   a.timestep, Dims{e - s, a.H, a.W}, dst, 0);
+    for (int i = 0; i < n_tiles; ++i) {
+        const float* src = tiles[i];
+        const int nf = tile_frames[i];
+        LTX_REQUIRE(src && nf >= 1, "vae_blend_tiles: tile %d is empty", i);
         if (i == 0) {
+            if (src != frames) HIP_CHECK(hipMemcpyAsync(frames, src, (size_t)nf * HWpix * 4, hipMemcpyDeviceToDevice, st));
             cur = nf;
             continue;
         }
         if (po > 0 && po < cur && po < nf) {
-            launch_blend_frames(a.frames + (cur - po) * HWpix, m->tile_frames.as<float>(), po, HWpix, st);
-            HIP_CHECK(hipMemcpyAsync(a.frames + cur * HWpix, m->tile_frames.as<float>() + (long)po * HWpix,
-                                     (size_t)(nf - po) * HWpix * 4, hipMemcpyDeviceToDevice, st));
+            launch_blend_frames(frames + (cur - po) * HWpix, src, po, HWpix, st);
+            HIP_CHECK(hipMemcpyAsync(frames + cur * HWpix, src + (long)po * HWpix, (size_t)(nf - po) * HWpix * 4, hipMemcpyDeviceToDevice, st));
             cur += nf - po;
         } else {
-            HIP_CHECK(hipMemcpyAsync(a.frames + cur * HWpix, m->tile_frames.as<float>(), (size_t)nf * HWpix * 4, hipMemcpyDeviceToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(frames + cur * HWpix, src, (size_t)nf * HWpix * 4, hipMemcpyDeviceToDevice, st));
             cur += nf;
         }
     }
-    launch_clip01(a.frames, cur * HWpix, st);
-    if (a.n_frames_out) *a.n_frames_out = (int)cur;
+    launch_clip01(frames, cur * HWpix, st);  // ((x + 1) / 2 clipped to [0,1]) AFTER the blend (VideoDecoder.swift:501-505)
+    return (int)cur;
+}
+
+void vae_decode(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a) {
+    const TilePlan plan = checked_plan(a);
+    LTX_REQUIRE(a.frames, "vae_decode: null output");
+    hipStream_t st = ctx->stream;
+    const long HWpix = (long)a.H * 32 * a.W * 32 * 3;
+    LTX_REQUIRE(a.frames_cap >= (long)plan.out_frames * HWpix, "vae_decode: output buffer too small (%ld < %ld floats)",
+                a.frames_cap, (long)plan.out_frames * HWpix);
+    ensure_decode_workspace(ctx, m, plan, a.H, a.W);
+    const int n_tiles = (int)plan.start.size();
+    if (n_tiles == 1) {
+        const int nf = decode_plan_tile(ctx, m, a, plan, 0, a.frames, 1);
+        if (a.n_frames_out) *a.n_frames_out = nf;
+        return;
+    }
+    // temporal tiling with linear blending of 8*overlap pixel frames (VideoDecoder.swift:517-602)
+    const int world = a.shard ? dist_world(ctx) : 1, rank = a.shard ? dist_rank(ctx) : 0;
+    if (world == 1) {
+        // one tile buffer, blended into the output as it is produced
+        int maxf = 0;
+        for (int i = 0; i < n_tiles; ++i) maxf = std::max(maxf, 8 * (plan.end[i] - plan.start[i] - 1) + 1);
+        m->tile_frames.ensure((size_t)maxf * HWpix * 4);
+        const int po = 8 * a.overlap;
+        long cur = 0;
+        for (int i = 0; i < n_tiles; ++i) {
+            float* dst = (i == 0) ? a.frames : m->tile_frames.as<float>();
+            const int nf = decode_plan_tile(ctx, m, a, plan, i, dst, 0);
+            if (i == 0) {
+                cur = nf;
+                continue;
+            }
+            if (po > 0 && po < cur && po < nf) {
+                launch_blend_frames(a.frames + (cur - po) * HWpix, m->tile_frames.as<float>(), po, HWpix, st);
+                HIP_CHECK(hipMemcpyAsync(a.frames + cur * HWpix, m->tile_frames.as<float>() + (long)po * HWpix,
+                                         (size_t)(nf - po) * HWpix * 4, hipMemcpyDeviceToDevice, st));
+                cur += nf - po;
+            } else {
+                HIP_CHECK(hipMemcpyAsync(a.frames + cur * HWpix, m->tile_frames.as<float>(), (size_t)nf * HWpix * 4, hipMemcpyDeviceToDevice, st));
+                cur += nf;
+            }
+        }
+        launch_clip01(a.frames, cur * HWpix, st);
+        if (a.n_frames_out) *a.n_frames_out = (int)cur;
+        return;
+    }
+    // tiles sharded over the ranks: tile i is decoded by rank i % world into its slot of one raw-tile
+    // buffer, each slot is broadcast from its owner over xGMI, and every rank blends the raw tiles in tile order - the blend is
+    // order-dependent and comes BEFORE the clip (VideoDecoder.swift:561-592, :501-505), so raw frames travel, not clipped ones.
+    std::vector<int> nfs(n_tiles);
+    std::vector<long> off(n_tiles + 1, 0);
+    for (int i = 0; i < n_tiles; ++i) {
+        nfs[i] = 8 * (plan.end[i] - plan.start[i] - 1) + 1;
+        off[i + 1] = off[i] + (long)nfs[i] * HWpix;
+    }
+    m->tile_frames.ensure((size_t)off[n_tiles] * 4);
+    float* raw = m->tile_frames.as<float>();
+    for (int i = rank; i < n_tiles; i += world) decode_plan_tile(ctx, m, a, plan, i, raw + off[i], 0);
+    std::vector<const float*> ptrs(n_tiles);
+    for (int i = 0; i < n_tiles; ++i) {
+        dist_broadcast(ctx, raw + off[i], (long)nfs[i] * HWpix * 4, i % world);
+        ptrs[i] = raw + off[i];
+    }
+    const int total = vae_blend_tiles(ctx, ptrs.data(), nfs.data(), n_tiles, a.overlap, a.H, a.W, a.frames, a.frames_cap);
+    if (a.n_frames_out) *a.n_frames_out = total;
 }

@@ -80,5 +80,14 @@ struct VaeDecodeArgs {
     float* frames = nullptr;  // device (n_frames, 32H, 32W, 3) f32
     long frames_cap = 0;      // capacity in floats
     int* n_frames_out = nullptr;
+    int shard = 0;  // 1: temporal tiles are decoded round-robin by the context's ranks (dist.h) and broadcast raw before the blend
 };
 void vae_decode(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a);
+// Building blocks of the tiled decode (decodeWithTemporalTiling, VideoDecoder.swift:517-602), exposed so that a host can place
+// tiles on GPUs itself: the RAW frames (before blend and clip) of tile `tile_index` of the plan (tile, overlap) -> a.frames;
+// returns the tile's frame count.
+int vae_decode_tile(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a, int tile_index);
+// Blend raw tiles in tile order over 8*overlap frames, then (x+1)/2 clipped to [0,1] (VideoDecoder.swift:561-592, :501-505).
+// tiles[i] (n_i, 32H, 32W, 3) device f32; tiles[0] may alias `frames`. Returns the blended frame count.
+int vae_blend_tiles(ltx_ctx* ctx, const float* const* tiles, const int* tile_frames, int n_tiles, int overlap, int H, int W, float* frames,
+                    long frames_cap);

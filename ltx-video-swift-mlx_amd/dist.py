@@ -1,26 +1,109 @@
-"""Multi-GPU layer of the path (one process per GPU, torch.distributed: backend "nccl" = RCCL over xGMI on the GPU
-box, "gloo" in CPU tests). The reference is single-device; this is new design:
+"""Process-group bootstrap for the library's multi-GPU layer (include/ltxhip.h "Multi-GPU", csrc/dist.cpp).
 
-* replicas (independent samples): no data-path collective; only `broadcast_context` once per prompt.
-* CFG pair sharding (config 3): rank r evaluates branch r (0 = negative, 1 = positive), the two 786 KB velocities are
-  exchanged with ONE all-gather per step and every rank applies CFG + Euler redundantly, so ranks stay bit-identical
-  without a second collective. Messages are < 1 MB: latency-bound, so a direct exchange (all_gather over 2 ranks =
-  one xGMI hop) rather than a ring.
-* VAE temporal tiles (config 5): tiles are independent decoder calls -> round-robin over ranks, gathered to rank 0
-  and blended there in tile order (the blend is order-dependent, VideoDecoder.swift:561-592).
-* one sample on several GPUs (sequence parallelism): tokens are split into equal contiguous slices; all
-  per-token work (projections, norms, FFN, cross-attention against the replicated text keys) is local, each block's self-attention
-  all-gathers its K rows and V^T block (2 collectives per block, (T/N)*4096*2 B each per rank), and one all-gather of the velocity
-  slices per step lets every rank run the scheduler redundantly. `hip_forward_fn_sp`.
+The sharded paths themselves - CFG-pair denoise, sequence-parallel forward / denoise, tile-sharded VAE decode - live in
+libltxhip.so and call RCCL directly; nothing in this file is on the data path. What a host has to do, and what this file does for
+the Python hosts (tests, bench.py), is membership: decide which ranks form a group, carry the 128-byte RCCL id from the group's
+first rank to the others, and call ``ltx_dist_init`` on every rank. torch.distributed is used only as that side channel (and as
+the barrier / max-over-ranks of bench.py); a Swift host would use whatever channel it has.
 
-`forward_fn(tokens_bf16_f32, branch, step)` abstracts the DiT forward so the same loop runs on the HIP path
-(Context.dit_forward_dev) and, in CPU tests, on a stand-in; the arithmetic around it (CFG, rescale, Euler) is done with
-torch ops on whatever device the tensors live on.
+* ``bootstrap(ctx, group)``        native RCCL group = the ranks of a torch.distributed group (default: all ranks).
+* ``attach_gloo_transport(ctx)``   the same membership with the all-gather done over gloo through host memory, for world-size-2
+                                   tests where RCCL cannot run (two processes sharing the test box's one GPU).
+* ``pair_groups()``                ranks (0,1), (2,3), ... as separate groups: one CFG pair per two GPUs (BASELINE config 3 on 2,
+                                   4 pairs on an 8-GPU node).
+
+The functions under "protocol model" restate the exchange protocol of the sharded loops with torch ops on CPU tensors. They are
+test infrastructure for the world-size-2 gloo tests that run without a GPU (tests/test_dist_cpu.py); the product never calls them.
 """
 import torch
 import torch.distributed as dist
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# membership
+# ---------------------------------------------------------------------------------------------------------------
+def bootstrap(ctx, group=None):
+    """RCCL communicator of `ctx` over the ranks of `group`: the id is created by the library on the group's first rank
+    (ltx_dist_unique_id), carried to the others over torch.distributed, and every rank calls ltx_dist_init."""
+    import importlib
+
+    ltx = importlib.import_module(__package__)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [ltx.dist_unique_id() if rank == 0 else None]
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=group)
+    ctx.dist_init(rank, world, box[0])
+    return rank, world
+
+
+def pair_groups():
+    """One torch.distributed group per consecutive rank pair; returns (my_group, pair_index). Every rank must call it."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    assert world % 2 == 0, "CFG pairs need an even number of ranks"
+    mine = None
+    for p in range(world // 2):
+        g = dist.new_group(ranks=[2 * p, 2 * p + 1])
+        if rank // 2 == p:
+            mine = g
+    return mine, rank // 2
+
+
+class _DevMem:
+    """Zero-copy view of raw device memory for torch (CUDA array interface)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def gloo_allgather_fn(device, group=None):
+    """`gather(send_ptr, recv_ptr, nbytes)` over a gloo group: device -> host, all_gather on the CPU, host -> device, with the
+    stream synchronised on both sides (the library's contract for a transport that does not enqueue on the context's stream)."""
+    world = dist.get_world_size(group)
+
+    def gather(send_ptr, recv_ptr, nbytes):
+        send = torch.as_tensor(_DevMem(send_ptr, nbytes), device=device)
+        recv = torch.as_tensor(_DevMem(recv_ptr, nbytes * world), device=device)
+        parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, send.cpu(), group=group)  # .cpu() synchronises the current stream
+        recv.copy_(torch.cat(parts).to(device))
+        torch.cuda.current_stream(device).synchronize()
+
+    return gather
+
+
+def attach_gloo_transport(ctx, device, group=None):
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ctx.dist_set_transport(rank, world, gloo_allgather_fn(device, group))
+    return rank, world
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# partition rules (pure host logic; the library applies the same rules internally)
+# ---------------------------------------------------------------------------------------------------------------
+def cfg_branch_for_rank(rank=None):
+    rank = dist.get_rank() if rank is None else rank
+    return rank % 2  # 0 = negative (uncond), 1 = positive (cond): batch order [neg, pos] (LTXPipeline.swift:715-716)
+
+
+def shard_tiles(n_tiles, rank=None, world=None):
+    """Round-robin assignment of VAE temporal tiles to ranks (tile i on rank i % world)."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    return list(range(rank, n_tiles, world))
+
+
+def sp_token_slice(T, rank=None, world=None):
+    """Token range [t0, t1) of a rank: contiguous, equal, in global token order (token t = (f*H + h)*W + w)."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    assert T % world == 0 and (T // world) % 8 == 0, f"{T} tokens do not split into {world} equal multiples of 8"
+    n = T // world
+    return rank * n, (rank + 1) * n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# protocol model (CPU tests only)
+# ---------------------------------------------------------------------------------------------------------------
 def broadcast_context(context, mask=None, src=0):
     """One-time broadcast of the text context ([nb,S,3840] bf16 = 7.9 MB per prompt) and its mask."""
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -28,11 +111,6 @@ def broadcast_context(context, mask=None, src=0):
         if mask is not None:
             dist.broadcast(mask, src=src)
     return context, mask
-
-
-def cfg_branch_for_rank(rank=None):
-    rank = dist.get_rank() if rank is None else rank
-    return rank % 2  # 0 = negative (uncond), 1 = positive (cond): batch order [neg, pos] (LTXPipeline.swift:715-716)
 
 
 def exchange_velocities(mine, group=None):
@@ -67,10 +145,8 @@ def euler_step(latent, velocity, sigma, sigma_next):
 
 
 def denoise_cfg_sharded(latent, sigmas, forward_fn, cfg_scale, rescale=0.0, group=None):
-    """CFG denoise loop with the pair sharded over 2 ranks. Every rank returns the same final latent.
-
-    forward_fn(latent_f32 [1,C,F,H,W], sigma, branch) -> velocity f32 [1,C,F,H,W] for that branch's context.
-    """
+    """The protocol of LTX_SHARD_CFG: rank r evaluates branch r, ONE all-gather per step, the update applied redundantly.
+    forward_fn(latent_f32 [1,C,F,H,W], sigma, branch) -> velocity f32 [1,C,F,H,W] for that branch's context."""
     branch = cfg_branch_for_rank(dist.get_rank(group))
     for i in range(len(sigmas) - 1):
         s, sn = float(sigmas[i]), float(sigmas[i + 1])
@@ -83,7 +159,7 @@ def denoise_cfg_sharded(latent, sigmas, forward_fn, cfg_scale, rescale=0.0, grou
 
 
 def denoise_cfg_single(latent, sigmas, forward_fn, cfg_scale, rescale=0.0):
-    """Same loop on one process (both branches locally) - the reference the sharded form must reproduce."""
+    """Same loop on one process (both branches locally) - what the sharded form must reproduce."""
     for i in range(len(sigmas) - 1):
         s, sn = float(sigmas[i]), float(sigmas[i + 1])
         uncond, cond = forward_fn(latent, s, 0), forward_fn(latent, s, 1)
@@ -91,13 +167,6 @@ def denoise_cfg_single(latent, sigmas, forward_fn, cfg_scale, rescale=0.0):
         v = guidance_rescale(v, cond, rescale)
         latent = euler_step(latent, v, s, sn)
     return latent
-
-
-def shard_tiles(n_tiles, rank=None, world=None):
-    """Round-robin assignment of VAE temporal tiles to ranks."""
-    rank = dist.get_rank() if rank is None else rank
-    world = dist.get_world_size() if world is None else world
-    return list(range(rank, n_tiles, world))
 
 
 def gather_tiles_to_rank0(local_tiles, n_tiles, tile_shapes, device, group=None):
@@ -134,94 +203,9 @@ def blend_tiles(chunks, overlap):
     return torch.clamp((result + 1.0) / 2.0, 0.0, 1.0)
 
 
-class _DevMem:
-    """Zero-copy view of raw device memory for torch (CUDA array interface)."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-
-
-def sp_allgather_fn(device, group=None):
-    """The `gather(send_ptr, recv_ptr, nbytes)` callback of Context.dit_forward_sp_dev over torch.distributed.
-
-    backend nccl (= RCCL): the all-gather is enqueued behind the library's kernels - the context runs on torch's current stream and
-    ProcessGroupNCCL orders its own stream after / before it with events, no host synchronisation. backend gloo (tests): device ->
-    host, all_gather on the CPU, host -> device, synchronising the stream on both sides."""
-    world = dist.get_world_size(group)
-    backend = dist.get_backend(group)
-
-    def gather(send_ptr, recv_ptr, nbytes):
-        send = torch.as_tensor(_DevMem(send_ptr, nbytes), device=device)
-        recv = torch.as_tensor(_DevMem(recv_ptr, nbytes * world), device=device)
-        if backend == "gloo":
-            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
-            dist.all_gather(parts, send.cpu(), group=group)  # .cpu() synchronises the current stream
-            recv.copy_(torch.cat(parts).to(device))
-            torch.cuda.current_stream(device).synchronize()
-        else:
-            dist.all_gather_into_tensor(recv, send, group=group)
-
-    return gather
-
-
-def sp_token_slice(T, rank=None, world=None):
-    """Token range [t0, t1) of a rank: contiguous, equal, in global token order (token t = (f*H + h)*W + w)."""
-    rank = dist.get_rank() if rank is None else rank
-    world = dist.get_world_size() if world is None else world
-    assert T % world == 0 and (T // world) % 8 == 0, f"{T} tokens do not split into {world} equal multiples of 8"
-    n = T // world
-    return rank * n, (rank + 1) * n
-
-
 def sp_gather_velocity(vel_local, group=None):
-    """[Tn, C] f32 slice of every rank -> [T, C] in global token order on every rank (one all-gather per denoise step)."""
+    """[Tn, C] f32 slice of every rank -> [T, C] in global token order on every rank (one all-gather per forward)."""
     world = dist.get_world_size(group)
-    if dist.get_backend(group) == "gloo" and vel_local.is_cuda:
-        parts = [torch.empty(vel_local.shape, dtype=vel_local.dtype) for _ in range(world)]
-        dist.all_gather(parts, vel_local.cpu(), group=group)
-        return torch.cat(parts).to(vel_local.device)
-    full = torch.empty((world * vel_local.shape[0],) + tuple(vel_local.shape[1:]), dtype=vel_local.dtype, device=vel_local.device)
-    dist.all_gather_into_tensor(full, vel_local.contiguous(), group=group)
-    return full
-
-
-def hip_forward_fn_sp(ctx, context, mask, F, H, W, mask_all_ones=False, group=None):
-    """`forward_fn` for ONE sample sharded by tokens over all ranks of `group`: every rank keeps the full latent (786 KB at
-    768x512x25), evaluates the DiT on its token slice (K / V^T all-gathered inside each block's self-attention), and one final
-    all-gather of the [Tn,128] f32 velocity slices gives every rank the full velocity, so the scheduler arithmetic around it runs
-    redundantly and ranks stay bit-identical without another collective. `context` [1,S,Cc] bf16, `mask` [1,S] int32 or None."""
-    T = F * H * W
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    t0, t1 = sp_token_slice(T, rank, world)
-    gather = sp_allgather_fn(context.device, group)
-
-    def fwd(latent, sigma, branch=0):
-        c = latent.shape[1]
-        tokens = latent.reshape(c, T).t()[t0:t1].contiguous().to(torch.bfloat16).reshape(1, t1 - t0, c)
-        ts = torch.full((1,), float(sigma), dtype=torch.float32, device=latent.device)
-        vel = torch.empty((1, t1 - t0, c), dtype=torch.float32, device=latent.device)
-        ctx.dit_forward_sp_dev(tokens, context, ts, mask, F, H, W, vel, rank, world, gather, ctx_version=201 + branch,
-                               mask_all_ones=mask_all_ones)
-        return sp_gather_velocity(vel[0], group).t().reshape(1, c, F, H, W).contiguous()
-
-    return fwd
-
-
-def hip_forward_fn(ctx, context, mask, F, H, W, mask_all_ones=False):
-    """`forward_fn` for the loops above on the HIP path: patchify -> bf16 -> Context.dit_forward_dev with this branch's slice of
-    the [neg, pos] context -> unpatchify. `ctx` is an ltx Context on this rank's GPU, `context` [2,S,Cc] bf16 / `mask` [2,S] int32
-    device tensors (broadcast once with `broadcast_context`). The projected context and the cross-attention K/V of each branch
-    are cached inside the library under a per-branch version key, so only the first step pays for them."""
-    T = F * H * W
-
-    def fwd(latent, sigma, branch):
-        c = latent.shape[1]
-        tokens = latent.reshape(c, T).t().contiguous().to(torch.bfloat16).reshape(1, T, c)  # patchify (LatentUtils.swift:40-59)
-        ts = torch.full((1,), float(sigma), dtype=torch.float32, device=latent.device)
-        vel = torch.empty((1, T, c), dtype=torch.float32, device=latent.device)
-        m = None if mask is None else mask[branch:branch + 1].contiguous()
-        ctx.dit_forward_dev(tokens, context[branch:branch + 1].contiguous(), ts, m, F, H, W, vel, ctx_version=101 + branch,
-                            mask_all_ones=mask_all_ones)
-        return vel.reshape(T, c).t().reshape(1, c, F, H, W).contiguous()  # unpatchify
-
-    return fwd
+    parts = [torch.empty(vel_local.shape, dtype=vel_local.dtype) for _ in range(world)]
+    dist.all_gather(parts, vel_local.cpu().contiguous(), group=group)
+    return torch.cat(parts).to(vel_local.device)

@@ -38,6 +38,9 @@ STAGE = 32768
 if "--bias" in __import__("sys").argv:
     FLOOR, ONES, NV = 220, 224, 228   # v195..199 belong to the bias values in this variant
 RA = 3  # fragment reads in flight ahead of their MFMAs (ring of 4 fragment registers)
+STAGE_OPS = 8  # LDS-DMA instructions per staged K / Vt tile (4 x 4 KB of K + 4 x 4 KB of Vt); Gen.stage() asserts it
+TILES_AHEAD = 1  # fills that may still be in flight when a step ends: the tile staged in this step (t+3) is first read two steps
+                 # later, the one staged a step earlier (t+2) is read by the next step's K.Q^T and must have landed
 
 
 def vr(base, n=4):
@@ -319,6 +322,7 @@ class Gen:
         for i in range(4):
             out.append([f"s_add_u32 m0, %[wlds], {slot * STAGE + 16384 + i * 4096}", "s_nop 0",
                         f"buffer_load_dwordx4 %[vo{i}], s[40:43], s45 offen lds"])
+        assert sum(ins.startswith("buffer_load") for grp in out for ins in grp) == STAGE_OPS
         return out
 
     def advance_stage_offsets(self):
@@ -377,7 +381,9 @@ class Gen:
         self.sm_check_and_rare_path(f"{uid}", nxt)
         self.advance_stage_offsets()
         st(3)
-        self.e("s_waitcnt vmcnt(8)")
+        # counted wait derived from the staging model (not a literal): everything but the youngest TILES_AHEAD fills has landed.
+        # check_wait_coverage() proves that every ring-slot read of the next steps is covered by this wait + barrier.
+        self.e(f"s_waitcnt vmcnt({STAGE_OPS * TILES_AHEAD})")
         self.e("s_barrier")
         st(4)
 
@@ -436,7 +442,7 @@ class Gen:
                     e(ins)
                     n_stage_ops += ins.startswith("buffer_load")
             self.advance_stage_offsets()
-        assert n_stage_ops == 24, n_stage_ops
+        assert n_stage_ops == 3 * STAGE_OPS, n_stage_ops
         for i in range(LACC + 12):
             e(f"v_accvgpr_write_b32 a{i}, 0")
         for qb in range(3):
@@ -508,6 +514,123 @@ class Gen:
         return self.lines
 
 
+class WaitCoverageError(AssertionError):
+    pass
+
+
+def check_wait_coverage(lines, iterations=3):
+    """Static proof that the emitted stream orders every LDS-DMA fill against the ds_reads of its ring slot.
+
+    The four waves of a workgroup run this same stream, so one wave's program order stands for all of them. Rules (MI355X guide,
+    'Read a staged buffer one phase AFTER the wait that retires it'; LDS-DMA is ordered for a ds_read only by the issuing waves'
+    counted vmcnt followed by a barrier the reader has passed):
+      RAW  a ds_read of ring region (slot, K|Vt) needs every LDS-DMA ever issued into that region to have been retired by an
+           `s_waitcnt vmcnt(n)` (in-order counter: all but the n youngest vector-memory operations are done) that is itself followed
+           by an `s_barrier`, both before the read in program order.
+      WAR  an LDS-DMA into a region needs every earlier ds_read of that region to have been retired by an `s_waitcnt lgkmcnt(n)`
+           and then an `s_barrier` - before the DMA is issued.
+    The stream is walked as prologue + `iterations` x loop body (+ epilogue), branches not taken: the rare path and the ragged-tail
+    code contain no memory operations, and the exit branch only skips code. Raises WaitCoverageError naming the first violation."""
+    import re
+
+    try:
+        i10 = lines.index("10:")
+        ibr = lines.index("s_branch 10b")
+    except ValueError as e:
+        raise WaitCoverageError("loop labels not found") from e
+    seq = lines[:i10] + lines[i10 + 1:ibr] * iterations + lines[ibr + 1:]
+    vm = []      # outstanding vector-memory operations in issue order: dicts {region|None, state}
+    lg = []      # outstanding LDS reads in issue order
+    fills = {}   # region -> list of DMA ops (all generations)
+    reads = {}   # region -> list of read ops
+    m0 = None
+    n_reads = n_dma = 0
+    for pos, ins in enumerate(seq):
+        mm = re.match(r"s_add_u32 m0, %\[wlds\], (\d+)", ins)
+        if mm:
+            m0 = int(mm.group(1))
+            continue
+        if ins.startswith("buffer_load_dwordx4") and ins.endswith("lds"):
+            if m0 is None:
+                raise WaitCoverageError(f"LDS-DMA without an m0 destination at {pos}: {ins}")
+            region = None
+            if m0 < 4 * STAGE:
+                region = (m0 // STAGE, "K" if (m0 % STAGE) < 16384 else "V")
+                for r in reads.get(region, []):
+                    if r["state"] != "fenced":
+                        raise WaitCoverageError(f"WAR: LDS-DMA into {region} at {pos} ({ins}) while a ds_read of it issued at "
+                                                f"{r['pos']} is only '{r['state']}' (needs lgkmcnt wait + barrier before the fill)")
+                reads[region] = []
+                n_dma += 1
+            elif m0 >= BIAS_LDS:
+                region = ("bias", "vector")   # staged once in the prologue, read by every step of the masked variant
+            op = {"region": region, "state": "inflight", "pos": pos}
+            vm.append(op)
+            if region is not None:
+                fills.setdefault(region, []).append(op)
+            m0 = None
+            continue
+        if re.match(r"(global_load|buffer_load|global_store|buffer_store)", ins):
+            vm.append({"region": None, "state": "inflight", "pos": pos})
+            continue
+        mm = re.match(r"ds_read_b128 v\[\d+:\d+\], (\S+) offset:(\d+)", ins) or re.match(r"ds_read_b128 v\[\d+:\d+\], (\S+)$", ins)
+        if mm:
+            addr = mm.group(1)
+            off = int(mm.group(2)) if mm.lastindex == 2 else 0
+            region = None
+            ka = re.match(r"%\[ka(\d)\]", addr)
+            va = re.match(r"%\[va(\d)\]", addr)
+            hv = re.match(r"v(\d+)$", addr)
+            if ka:
+                region = (off // STAGE, "K")
+            elif va:
+                region = (off // STAGE, "V")
+            elif hv and HI <= int(hv.group(1)) < HI + 6:
+                region = (2 + off // STAGE, "K" if int(hv.group(1)) < HI + 4 else "V")
+            elif hv and int(hv.group(1)) == BADDR:
+                region = ("bias", "vector")
+            op = {"region": region, "state": "issued", "pos": pos}
+            lg.append(op)
+            if region is not None:
+                n_reads += 1
+                if not fills.get(region):
+                    raise WaitCoverageError(f"RAW: ds_read of {region} at {pos} ({ins}) before anything was staged into it")
+                for f in fills[region]:
+                    if f["state"] != "visible":
+                        raise WaitCoverageError(f"RAW: ds_read of {region} at {pos} ({ins}) while the LDS-DMA issued at {f['pos']} is "
+                                                f"only '{f['state']}' (needs a covering vmcnt wait AND a barrier before the read)")
+                reads.setdefault(region, []).append(op)
+            continue
+        if ins.startswith("s_waitcnt"):
+            mv = re.search(r"vmcnt\((\d+)\)", ins)
+            ml = re.search(r"lgkmcnt\((\d+)\)", ins)
+            if mv:
+                keep = int(mv.group(1))
+                done, vm = (vm[:len(vm) - keep], vm[len(vm) - keep:]) if keep < len(vm) else ([], vm)
+                for op in done:
+                    op["state"] = "retired"
+            if ml:
+                keep = int(ml.group(1))
+                done, lg = (lg[:len(lg) - keep], lg[len(lg) - keep:]) if keep < len(lg) else ([], lg)
+                for op in done:
+                    op["state"] = "done"
+            continue
+        if ins == "s_barrier":
+            for ops in fills.values():
+                for op in ops:
+                    if op["state"] == "retired":
+                        op["state"] = "visible"
+            for ops in reads.values():
+                for op in ops:
+                    if op["state"] == "done":
+                        op["state"] = "fenced"
+            # generations that are fully visible and superseded need no further tracking, but keeping them is harmless
+            continue
+    if n_reads == 0 or n_dma == 0:
+        raise WaitCoverageError("checker saw no ring traffic - the stream format changed")
+    return {"ring_reads": n_reads, "ring_fills": n_dma, "instructions": len(seq)}
+
+
 def main():
     import sys
     stamps = "--stamps" in sys.argv
@@ -516,6 +639,21 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     name = "attention_w48_asm" + ("_bias" if BIAS else "") + ("_stamps" if stamps else "") + ".inc"
     out = os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", name)
+    if "--inject-prologue-race" in sys.argv:
+        # the race that shipped once (commit 7c76101): the prologue left tiles 1 and 2 in flight while step 0 reads slot 1
+        k = lines.index("s_waitcnt vmcnt(0)")
+        assert k < lines.index("10:")
+        lines[k] = f"s_waitcnt vmcnt({2 * STAGE_OPS})"
+    stats = None
+    if not (ABL - {""}):
+        stats = check_wait_coverage(lines)   # every generated stream is proven before it is written
+    if "--check" in sys.argv:
+        # CPU test entry: prove the stream and compare it with the committed file; writes nothing
+        body = ["// GENERATED by tools/gen_attn_w48.py - do not edit. gfx950 assembly body of attn_fwd_kernel_w48_asm (attention.hip).\n"]
+        body += ['"' + ln.replace('"', '\\"') + '\\n\\t"\n' for ln in lines]
+        same = os.path.exists(out) and open(out).read() == "".join(body)
+        print(f"wait coverage ok: {stats}; committed file {'matches' if same else 'DIFFERS'}")
+        sys.exit(0 if same or stamps else 4)
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. gfx950 assembly body of attn_fwd_kernel_w48_asm (attention.hip).\n")
         for ln in lines:
