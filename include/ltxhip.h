@@ -64,6 +64,8 @@ typedef struct ltx_transformer_config {
  * ---------------------------------------------------------------------------------------------------------- */
 /* LTXVideo.version (LTXVideo.swift, asserted by Tests/LTXVideoTests/LTXVideoTests.swift:9-11) */
 const char* ltx_version(void);
+/* "gfx950;experiments=0|1": whether this build carries the measured-but-not-selected kernels (-DLTX_EXPERIMENTS; the product does not). */
+const char* ltx_build_info(void);
 /* Filled with the reference defaults (LTXConfig.swift:83-177). */
 void ltx_transformer_config_default(ltx_transformer_config* cfg);
 /* Replaces `LTXPipeline.init` device/bookkeeping (LTXPipeline.swift:189-200). Fails with LTX_ERR_HIP when no

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "build", "libltxhip.so")
+# LTX_LIB selects another build of the same ABI (tools/ and the `experiments`-marked tests use csrc/build_exp/libltxhip_exp.so)
+SO_PATH = os.environ.get("LTX_LIB") or os.path.join(_HERE, "csrc", "build", "libltxhip.so")
 
 
 class LTXError(RuntimeError):
@@ -75,6 +76,7 @@ _ip = C.POINTER(C.c_int)
 # name -> (restype, argtypes); every symbol declared in include/ltxhip.h must appear here (tests check both ways)
 SIGNATURES = {
     "ltx_version": (C.c_char_p, []),
+    "ltx_build_info": (C.c_char_p, []),
     "ltx_transformer_config_default": (None, [C.POINTER(TransformerConfig)]),
     "ltx_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "ltx_ctx_destroy": (None, [_vp]),
@@ -169,3 +171,5 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header/library mismatch: fail loudly
     _fn.restype = _res
     _fn.argtypes = _args
+
+HAS_EXPERIMENTS = b"experiments=1" in lib.ltx_build_info()

@@ -88,6 +88,14 @@ extern "C" {
 
 const char* ltx_version(void) { return "0.1.0"; }
 
+const char* ltx_build_info(void) {
+#ifdef LTX_EXPERIMENTS
+    return "gfx950;experiments=1";
+#else
+    return "gfx950;experiments=0";
+#endif
+}
+
 void ltx_transformer_config_default(ltx_transformer_config* c) {
     if (!c) return;
     TransformerConfig t;

@@ -533,6 +533,7 @@ LTX_DEVFN W48Lane w48_lane(int lane, int wave, long ldk, long ldvt) {
 constexpr int w48_kblock_off(int kb) { return (32 * (kb >> 1) + 4 * (kb & 1)) * 256; }  // LDS offset of key block kb's row 0
 constexpr int w48_vblock_off(int db) { return db * 16 * 128; }
 
+#ifdef LTX_EXPERIMENTS  // plain-HIP layout reference of the 48-query kernel (LTX_ATTN_IMPL=3): pins the LDS images and the MFMA operand mapping
 __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_ref(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -616,6 +617,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_ref(const AttnArgs
         }
     }
 }
+#endif  // LTX_EXPERIMENTS
 
 
 #ifdef W48_STAMPS
@@ -715,12 +717,11 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
     LTX_REQUIRE(a.ldvt >= ((a.Tk + 63) / 64) * 64, "attention: Vt row stride %ld must cover Tk=%d rounded up to 64", a.ldvt, a.Tk);
     LTX_REQUIRE(((uintptr_t)a.Q & 15) == 0 && ((uintptr_t)a.K & 15) == 0 && ((uintptr_t)a.Vt & 15) == 0 && ((uintptr_t)a.O & 7) == 0,
                 "attention: pointer alignment");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    attr_set.run([&] {
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
-        attr_set = true;
-    }
+    });
     ProfScope prof(PROF_ATTN, 4.0 * a.B * a.H * (double)a.Tq * a.Tk * 128, stream);
     // Kernel choice by grid fill. Tile-step costs measured on MI355X at T=6144: 2.3 us with two 128-query workgroups on a CU,
     // 1.5 us with one; 2.18 us for one 256-query ping-pong workgroup; 1.25 us for one 192-query workgroup of the 48-query
@@ -743,29 +744,29 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
         bool use_pp = forced ? impl[0] == '2' : (!a.bias && costpp < cost4);
         // the 48-query kernels cover unmasked launches whose query count is a multiple of 192 and key count a multiple of 256
         const bool w48_ok = !a.bias && a.Tq % W48_Q == 0 && a.Tk % (4 * KV_TILE) == 0;
+#ifdef LTX_EXPERIMENTS
         if (impl && impl[0] == '3') {
             LTX_REQUIRE(w48_ok, "attention: LTX_ATTN_IMPL=3 needs Tq %% 192 == 0, Tk %% 256 == 0 and no mask (Tq=%d Tk=%d)", a.Tq, a.Tk);
-            static bool attr3_set = false;
-            if (!attr3_set) {
+            static PerDeviceOnce attr3_set;
+            attr3_set.run([&] {
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_ref, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
-                attr3_set = true;
-            }
+            });
             hipLaunchKernelGGL(attn_fwd_kernel_w48_ref, dim3(a.Tq / W48_Q, a.H, a.B), dim3(256), W48_LDS, stream, a);
             HIP_CHECK(hipGetLastError());
             return;
         }
+#endif
         const long wg48 = (long)((a.Tq + W48_Q - 1) / W48_Q) * a.H * a.B;
         const double cost48 = (double)((wg48 + 255) / 256) * 1.25;
         const bool asm_ok = !a.bias || a.Tk <= 4096;  // any Tq, Tk (ragged tails in the kernel); masked: the bias vector must fit 16 KB of LDS
         const bool use_asm = forced ? impl[0] == '4' : (asm_ok && cost48 < cost4 && cost48 < costpp);
         if (use_asm) {
             LTX_REQUIRE(asm_ok, "attention: LTX_ATTN_IMPL=4 takes masked launches up to 4096 keys only (Tq=%d Tk=%d)", a.Tq, a.Tk);
-            static bool attr4_set = false;
-            if (!attr4_set) {
+            static PerDeviceOnce attr4_set;
+            attr4_set.run([&] {
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS + 16384));
-                attr4_set = true;
-            }
+            });
             const dim3 grid4((a.Tq + W48_Q - 1) / W48_Q, a.H, a.B);
             if (a.bias)
                 hipLaunchKernelGGL(attn_fwd_kernel_w48_asm<true>, grid4, dim3(256), W48_LDS + 16384, stream, a);
@@ -775,12 +776,11 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
             return;
         }
         if (use_pp) {
-            static bool attr2_set = false;
-            if (!attr2_set) {
+            static PerDeviceOnce attr2_set;
+            attr2_set.run([&] {
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_pp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_pp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
-                attr2_set = true;
-            }
+            });
             dim3 grid_pp((a.Tq + PP_Q - 1) / PP_Q, a.H, a.B);
             if (a.bias)
                 hipLaunchKernelGGL((attn_fwd_kernel_pp<true>), grid_pp, dim3(512), PP_LDS, stream, a);

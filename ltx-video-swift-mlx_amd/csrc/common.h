@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <mutex>
 #include <string>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
@@ -143,3 +145,22 @@ struct LtxError {
     do {                                                         \
         if (!(cond)) LTX_THROW(LTXS_INVALID_CONFIGURATION, __VA_ARGS__); \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only, and one process may hold contexts on several
+// GPUs (ltx_ctx_create(device)): a process-wide "done" flag would leave the second device's first launch of a > 64 KB LDS kernel
+// without its attribute. One bit per device, set under a lock so that a second thread cannot launch between check and set.
+struct PerDeviceOnce {
+    std::atomic<uint64_t> done{0};
+    std::mutex mu;
+    template <class F>
+    void run(F&& f) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (done.load(std::memory_order_relaxed) & bit) return;
+        f();
+        done.fetch_or(bit, std::memory_order_release);
+    }
+};

@@ -877,224 +877,10 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// v4: phased "ping-pong" kernel for the wide DiT GEMMs (fused q/k, FFN up): BMx256 output tile (BM = 192 or 256),
-// BK = 64, 8 waves as 2(M) x 4(N). The two waves that share a SIMD (wave w and w+4: wave rows 0 and 1) run half a
-// phase apart: while one is inside its MFMA cluster (priority 1) the other stages LDS-DMA pieces and waits; two
-// workgroup barriers per phase hand the roles over. Per K-tile a wave walks its WMx64 output in four quadrants, each
-// re-using one operand half held in registers; the fragments of the NEXT quadrant are read from LDS inside the
-// current MFMA cluster (one ds_read per MFMA), so no LDS latency sits between the barriers.
-//   even tile: (a0,b0) (a0,b1) (a1,b1) (a1,b0)      odd tile: (a0,b1) (a0,b0) (a1,b0) (a1,b1)   [serpentine: the first
-//   quadrant of a tile needs only register sets the last quadrant of the previous tile does not use]
-// LDS: 2 slots (K-tile parity) x [A image BM rows | B image 256 rows] x 128 B, rows ordered [half][wave row/col][..]
-// so that an operand half is a contiguous row range; 16-B chunk c of LDS row r sits at chunk c ^ ((r >> 1) & 7).
-// Staging: one wave-instruction = 8 rows; unit u of an operand = LDS rows [64u, 64u+64) over the 8 waves.
-// Hazards (wave group 1 runs one barrier behind group 0; L(p)/M(p) = the load / MFMA section of phase p):
-//   RAW: data read in M(p) must have been waited for (vmcnt) in L(p-1) or earlier by every wave.
-//   WAR: a buffer last read in M(q) may be re-staged from L(q+2) on.
-// Schedule for tile T (Bf/Bs = the B half its first / second quadrant pair needs):
-//   staged:  Bf(T) in L(P2(T-2))   Bs(T) in L(P3(T-2))   A half 0 in L(P4(T-2))   A half 1 in L(P1(T-1))
-//   read:    A half 0 + Bf(T) in M(P4(T-1))   Bs(T) in M(P1(T))   A half 1 in M(P2(T))
-//   waited:  start of L(P3(T-1)): everything but {A half 1 (T), Bf(T+1)} ; start of L(P1(T)): everything but the three
-//            groups of tile T+1 staged so far.  The weights (B, HBM-cold in the DiT) get 4-5 phases of flight.
-// ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-__global__ __launch_bounds__(512) void gemm_bf16_kernel_v4(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    static_assert(BN == 256 && (BM == 192 || BM == 256), "v4 tile shapes");
-    constexpr int WGM = 2, WGN = 4;
-    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16, MIH = MI / 2, NIH = NI / 2;
-    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, SLOT = A_BYTES + B_BYTES;
-    constexpr int AU = BM / 64, BU = BN / 64;  // staging units (= LDS-DMA instructions per wave) per K-tile
-    constexpr int HM = BM / 2, HN = BN / 2, QM = WM / 2, QN = WN / 2;
-    // LDS-DMA instructions per wave of the four staging groups
-    constexpr int G_BF = 2, G_BS = 2, G_A0 = 2, G_A1 = (BM == 256) ? 2 : 1;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WGN, wc = wave % WGN;
-
-    const int tiles_m = (g.M + BM - 1) / BM;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    tile_coords(g, bid, tiles_m, BN, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- staging sources: LDS row -> tile row through the [half][wave row][quarter rows] ordering
-    const int srow = lane >> 3, pch = lane & 7;
-    const bf16_t* a_src[AU];
-    const bf16_t* b_src[BU];
-#pragma unroll
-    for (int u = 0; u < AU; ++u) {
-        const int lr = 64 * u + 8 * wave + srow;
-        const int h = lr / HM, rem = lr - h * HM, w_ = rem / QM, i = rem - w_ * QM;
-        int gm = m0 + w_ * WM + h * QM + i;
-        gm = gm < g.M ? gm : g.M - 1;
-        a_src[u] = g.A + (long)gm * g.lda + ((pch ^ ((lr >> 1) & 7)) << 3);
-    }
-#pragma unroll
-    for (int u = 0; u < BU; ++u) {
-        const int lr = 64 * u + 8 * wave + srow;
-        const int h = lr / HN, rem = lr - h * HN, w_ = rem / QN, j = rem - w_ * QN;
-        int gn = n0 + w_ * WN + h * QN + j;
-        gn = gn < g.N ? gn : g.N - 1;
-        b_src[u] = g.B + (long)gn * g.ldb + ((pch ^ ((lr >> 1) & 7)) << 3);
-    }
-    auto stage_a = [&](int slot, int u, int kt) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[u] + (long)kt * BK),
-                                         (__attribute__((address_space(3))) void*)(smem + slot * SLOT + (8 * u + wave) * 1024),
-                                         16, 0, 0);
-    };
-    auto stage_b = [&](int slot, int u, int kt) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[u] + (long)kt * BK),
-                                         (__attribute__((address_space(3))) void*)(smem + slot * SLOT + A_BYTES + (8 * u + wave) * 1024),
-                                         16, 0, 0);
-    };
-    // B half h = units 2h, 2h+1. A half 0 = units 0,1 (BM=256) / 0 and the first half of 1 (BM=192: unit 1 straddles);
-    // A half 1 = units 2,3 / 2. The straddling unit is staged with half 0: its half-1 rows are free by then (last read M(P2)).
-    auto stage_bh = [&](int slot, int h, int kt) { stage_b(slot, 2 * h, kt); stage_b(slot, 2 * h + 1, kt); };
-    auto stage_a0 = [&](int slot, int kt) { stage_a(slot, 0, kt); stage_a(slot, 1, kt); };
-    auto stage_a1 = [&](int slot, int kt) {
-        stage_a(slot, 2, kt);
-        if constexpr (BM == 256) stage_a(slot, 3, kt);
-    };
-
-    // ---- fragment reads
-    const int frow = lane & 15, fsw = (lane >> 1) & 7;
-    const int fch0 = (((lane >> 4) + 0) ^ fsw) << 4, fch1 = (((lane >> 4) + 4) ^ fsw) << 4;
-    const int a_off = (wr * QM + frow) * ROW_BYTES;            // + h*HM*128 + i*16*128 + chunk
-    const int b_off = A_BYTES + (wc * QN + frow) * ROW_BYTES;  // + h*HN*128 + j*16*128 + chunk
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    s16x8 fa0[MIH][2], fa1[MIH][2], fb0[NIH][2], fb1[NIH][2];
-
-    auto read_a = [&](int slot, int h, s16x8(&fa)[MIH][2]) {
-        const char* base = smem + slot * SLOT + a_off + h * HM * ROW_BYTES;
-#pragma unroll
-        for (int i = 0; i < MIH; ++i) {
-            fa[i][0] = *(const s16x8*)(base + i * 16 * ROW_BYTES + fch0);
-            fa[i][1] = *(const s16x8*)(base + i * 16 * ROW_BYTES + fch1);
-        }
-    };
-    auto read_b = [&](int slot, int h, s16x8(&fb)[NIH][2]) {
-        const char* base = smem + slot * SLOT + b_off + h * HN * ROW_BYTES;
-#pragma unroll
-        for (int j = 0; j < NIH; ++j) {
-            fb[j][0] = *(const s16x8*)(base + j * 16 * ROW_BYTES + fch0);
-            fb[j][1] = *(const s16x8*)(base + j * 16 * ROW_BYTES + fch1);
-        }
-    };
-    // MFMA section of one phase: quadrant (hm, hn) from the given register sets; `reads()` issues the ds_reads of the next
-    // quadrant's missing operand(s) (NR of them), interleaved one per MFMA behind the first product.
-    auto cluster = [&](auto hm_tag, auto hn_tag, const s16x8(&fa)[MIH][2], const s16x8(&fb)[NIH][2], auto nr_tag, auto&& reads) {
-        constexpr int hm = decltype(hm_tag)::value, hn = decltype(hn_tag)::value, NR = decltype(nr_tag)::value;
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        acc[hm * MIH][hn * NIH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[0][0]),
-                                                                           __builtin_bit_cast(bf16x8_t, fb[0][0]), acc[hm * MIH][hn * NIH], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        reads();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < MIH; ++i)
-#pragma unroll
-                for (int j = 0; j < NIH; ++j)
-                    if (ks + i + j > 0)
-                        acc[hm * MIH + i][hn * NIH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8_t, fa[i][ks]), __builtin_bit_cast(bf16x8_t, fb[j][ks]),
-                            acc[hm * MIH + i][hn * NIH + j], 0, 0, 0);
-        constexpr int NM = 2 * MIH * NIH - 1;
-        constexpr int NI_ = NR < NM ? NR : NM;
-#pragma unroll
-        for (int q = 0; q < NI_; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one ds_read
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NM - NI_, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(0);
-        raw_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using RA = std::integral_constant<int, 2 * MIH>;            // reads of one A half
-    using RB = std::integral_constant<int, 2 * NIH>;            // reads of one B half
-    using RAB = std::integral_constant<int, 2 * MIH + 2 * NIH>;
-    auto no_reads = [] {};
-
-    const int nk = g.K / BK;  // >= 2 (launcher)
-    // prologue: tile 0 complete; tile 1: Bf = B half 1, Bs = B half 0, A half 0 (its A half 1 is staged in P1 of tile 0)
-    stage_bh(0, 0, 0); stage_bh(0, 1, 0); stage_a0(0, 0); stage_a1(0, 0);
-    stage_bh(1, 1, 1); stage_bh(1, 0, 1); stage_a0(1, 1);
-    wait_vmcnt_barrier<G_BF + G_BS + G_A0>();
-    read_a(0, 0, fa0);
-    read_b(0, 0, fb0);
-    if (wr == 1) raw_barrier();  // wave row 1 runs one barrier behind wave row 0 from here on
-
-    // One K-tile = four phases; PAR = tile parity (slot, quadrant order). MODE 0: tile t+2 exists (full staging);
-    // 1: t+1 is the last tile; 2: t is the last tile.
-    auto ktile = [&](int t, auto par_tag, auto mode_tag) {
-        constexpr int S = decltype(par_tag)::value, MODE = decltype(mode_tag)::value;
-        constexpr int FH = S;      // B half of the tile's first quadrant pair (even tile: 0, odd tile: 1)
-        constexpr int SH = S ^ 1;  // B half of the second pair
-        auto& fbf = (FH == 0) ? fb0 : fb1;  // registers of Bf / Bs
-        auto& fbs = (FH == 0) ? fb1 : fb0;
-        // ---- P1: (a0, Bf); next quadrant needs Bs
-        if constexpr (MODE <= 1) {
-            wait_lgkm_vmcnt<G_BF + G_BS + G_A0>();  // A half 1 of this tile has landed (for every wave after the barrier)
-            stage_a1(S ^ 1, t + 1);
-        } else {
-            wait_lgkm_vmcnt<0>();
-        }
-        raw_barrier();
-        cluster(I0{}, std::integral_constant<int, FH>{}, fa0, fbf, RB{}, [&] { read_b(S, SH, fbs); });
-        // ---- P2: (a0, Bs); next quadrant needs a1
-        if constexpr (MODE == 0) stage_bh(S, (S == 0) ? 0 : 1, t + 2);  // Bf(t+2): same parity -> same half as this tile's Bf
-        wait_lgkm_barrier();
-        cluster(I0{}, std::integral_constant<int, SH>{}, fa0, fbs, RA{}, [&] { read_a(S, 1, fa1); });
-        // ---- P3: (a1, Bs); nothing new to read for P4 = (a1, Bf)
-        if constexpr (MODE == 0) {
-            wait_lgkm_vmcnt<G_A1 + G_BF>();  // A half 0 and Bf of tile t+1 have landed
-            stage_bh(S, (S == 0) ? 1 : 0, t + 2);  // Bs(t+2)
-        } else {
-            wait_lgkm_vmcnt<0>();
-        }
-        raw_barrier();
-        cluster(I1{}, std::integral_constant<int, SH>{}, fa1, fbs, I0{}, no_reads);
-        // ---- P4: (a1, Bf); next tile's first quadrant needs a0 and ITS Bf (= the half this tile calls Bs)
-        if constexpr (MODE == 0) stage_a0(S, t + 2);
-        wait_lgkm_barrier();
-        if constexpr (MODE <= 1)
-            cluster(I1{}, std::integral_constant<int, FH>{}, fa1, fbf, RAB{}, [&] { read_a(S ^ 1, 0, fa0); read_b(S ^ 1, SH, fbs); });
-        else
-            cluster(I1{}, std::integral_constant<int, FH>{}, fa1, fbf, I0{}, no_reads);
-    };
-    int t = 0;
-    for (; t + 3 < nk; t += 2) {
-        ktile(t, I0{}, I0{});
-        ktile(t + 1, I1{}, I0{});
-    }
-    // 2 or 3 tiles left, t even
-    if (t + 3 == nk) {
-        ktile(t, I0{}, I0{});
-        ktile(t + 1, I1{}, I1{});
-        ktile(t + 2, I0{}, I2{});
-    } else {
-        ktile(t, I0{}, I1{});
-        ktile(t + 1, I1{}, I2{});
-    }
-    if (wr == 0) raw_barrier();  // re-align the two wave rows
-    __syncthreads();
-    gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem);
-}
+#ifdef LTX_EXPERIMENTS
+#define LTX_GEMM_EXPERIMENTS_PART 1
+#include "gemm_experiments.inc"
+#endif
 
 // split-K finish: out = epilogue(sum_z ws[z]) - every epilogue option except the depth-to-space stores; partials are summed in
 // ascending z, so the result does not depend on scheduling.
@@ -1143,211 +929,24 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 template <int BM, int BN, bool CONV>
 void launch_one(const GemmArgs& a, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    attr_set.run([&] {
         HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, CONV>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    });
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, CONV>), dim3(tiles), dim3(256), smem, stream, a);
     HIP_CHECK(hipGetLastError());
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// One wave per SIMD, assembly main loop (generated by tools/gen_gemm_asm.py; schedule and register map in that script's header).
-// Workgroup tile 192 x 256, four waves as 2 x 2 (96 x 128 per wave), dense A.B^T only, M % 192 == 0, N % 256 == 0, K % 64 == 0.
-// C++ prepares the per-lane offsets / LDS addresses (the ring kernel's LDS image) and runs the shared epilogue on the accumulators
-// the assembly leaves in a[0:191].
-// ---------------------------------------------------------------------------------------------------------------
-template <int BN, int RING = 0>  // RING: 0 register-staged (71/72), 1 LDS-DMA ring (73), 2 A through the ring + B straight to registers (74)
-__global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_asm(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    static_assert(BN == 256 || BN == 128, "generated main loops exist for 192x256 and 192x128");
-    static_assert(RING == 0 || BN == 128, "the LDS-DMA ring variants exist for 192x128");
-    constexpr int BM = 192, WGM = 2, WGN = 2, NW = 4;
-    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
-    constexpr int A_BYTES = BM * ROW_BYTES;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WGN, wc = wave % WGN;
-    const int tiles_m = g.M / BM;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    tile_coords(g, bid, tiles_m, BN, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    // piece i of this wave = rows (wave + 4 i) * 8 .. +7 of the tile: the per-lane part of its address (row inside the piece, swizzled
-    // 16-byte column) does not depend on i ((row >> 1) & 7 is the same for rows 32 apart), the i part is a scalar offset
-    const int srow = lane >> 3, pch = lane & 7;
-    const int row0 = wave * 8 + srow;
-    const int ao = (row0 * (int)g.lda + ((pch ^ ((row0 >> 1) & 7)) << 3)) * 2;
-    const int bo = (row0 * (int)g.ldb + ((pch ^ ((row0 >> 1) & 7)) << 3)) * 2;
-    const uint32_t sa = (uint32_t)(32 * g.lda * 2), sb = (uint32_t)(32 * g.ldb * 2);
-    const bf16_t* At = g.A + (long)m0 * g.lda;
-    const bf16_t* Bt = g.B + (long)n0 * g.ldb;
-    const uint32_t alo = (uint32_t)(uintptr_t)At, ahi = (uint32_t)((uintptr_t)At >> 32);
-    const uint32_t blo = (uint32_t)(uintptr_t)Bt, bhi = (uint32_t)((uintptr_t)Bt >> 32);
-    const uint32_t arec = (uint32_t)(((long)(BM - 1) * g.lda + g.K) * 2), brec = (uint32_t)(((long)(BN - 1) * g.ldb + g.K) * 2);
-    const uint32_t nk = (uint32_t)(g.K / BK);
-    const int wb = wave * 1024 + lane * 16;
-    const int frow = lane & 15, fsw = (lane >> 1) & 7;
-    const int foff0 = frow * ROW_BYTES + ((((lane >> 4) + 0) ^ fsw) << 4);
-    const int foff1 = frow * ROW_BYTES + ((((lane >> 4) + 4) ^ fsw) << 4);
-    const int a_wave_off = (wr * WM) * ROW_BYTES, b_wave_off = A_BYTES + (wc * WN) * ROW_BYTES;
-    const int fa0 = a_wave_off + foff0, fa1 = a_wave_off + foff1, fb0 = b_wave_off + foff0, fb1 = b_wave_off + foff1;
-#ifdef GEMM_ASM_STAMPS  // tools/ubench/gemm_stamps.hip
-    unsigned long long* dbg = (blockIdx.x == 7) ? &g_gemm_stamps[wave][0] : &g_gemm_stamps[4][0];
-    const unsigned long long t_before = __builtin_readcyclecounter();
-#endif
-#define GEMM_ASM_OPERANDS                                                                                                           \
-    [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk), [sa] "s"(sa), \
-        [sb] "s"(sb), [ao] "v"(ao), [bo] "v"(bo), [wb] "v"(wb), [fa0] "v"(fa0), [fa1] "v"(fa1), [fb0] "v"(fb0), [fb1] "v"(fb1)
-    if constexpr (RING == 2) {
-        // tile_cfg 74: A by LDS-DMA into four 24 KB slots, B never touches LDS: each lane loads its 16 bytes of every B fragment
-        // (row 16 ni + (lane & 15) of this wave's 64 columns, k = 8 (lane >> 4) ..+7 of the k-step) four K-tiles ahead
-        // (tools/gen_gemm_asm_ring.py --bdirect)
-        const uint32_t wlds = (uint32_t)wave * 1024u;
-#ifdef GEMM_HYBRID_PACKED_TIMING  // tools/ubench/gemm_stamps.hip: address pattern of fragment-ordered weights (timing only, wrong results)
-        const int bfo = wc * 8192 + lane * 16;
-        const uint32_t sb16 = 2048u;
-#else
-        const int bfo = ((wc * WN + (lane & 15)) * (int)g.ldb + 8 * (lane >> 4)) * 2;
-        const uint32_t sb16 = (uint32_t)(16 * g.ldb * 2);
-#endif
-        asm volatile(
-#ifdef GEMM_HYBRID_PACKED_TIMING
-#include "gemm_asm_hybrid_192x128_stamps.inc"
-#else
-#include "gemm_asm_hybrid_192x128.inc"
-#endif
-            :
-            : [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk),
-              [sa] "s"(sa), [sb16] "s"(sb16), [wlds] "s"(wlds), [ao] "v"(ao), [bfo] "v"(bfo), [fa0] "v"(fa0), [fa1] "v"(fa1)
-            :
-#include "gemm_asm_hybrid_192x128_clobbers.inc"
-        );
-    } else if constexpr (RING == 1) {
-        // tile_cfg 73: the same wave tile, K-tiles staged by LDS-DMA into four 40 KB slots (tools/gen_gemm_asm_ring.py)
-        const uint32_t wlds = (uint32_t)wave * 1024u;
-        asm volatile(
-#ifdef GEMM_ASM_STAMPS
-#include "gemm_asm_ring_192x128_stamps.inc"
-#else
-#include "gemm_asm_ring_192x128.inc"
-#endif
-            :
-            : [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk),
-              [sa] "s"(sa), [sb] "s"(sb), [wlds] "s"(wlds), [ao] "v"(ao), [bo] "v"(bo), [fa0] "v"(fa0), [fa1] "v"(fa1),
-              [fb0] "v"(fb0), [fb1] "v"(fb1)
-#ifdef GEMM_ASM_STAMPS
-              , [dbg] "s"(dbg)
-#endif
-            :
-#include "gemm_asm_ring_192x128_clobbers.inc"
-        );
-    } else if constexpr (BN == 256) {
-        asm volatile(
-#ifdef GEMM_ASM_STAMPS
-#include "gemm_asm_192x256_stamps.inc"
-#else
-#include "gemm_asm_192x256.inc"
-#endif
-            :
-            : GEMM_ASM_OPERANDS
-#ifdef GEMM_ASM_STAMPS
-              , [dbg] "s"(dbg)
-#endif
-            :
-#include "gemm_asm_192x256_clobbers.inc"
-        );
-    } else {
-        asm volatile(
-#include "gemm_asm_192x128.inc"
-            :
-            : GEMM_ASM_OPERANDS
-            :
-#include "gemm_asm_192x128_clobbers.inc"
-        );
-    }
-#undef GEMM_ASM_OPERANDS
-#ifdef GEMM_ASM_STAMPS
-    const unsigned long long t_after = __builtin_readcyclecounter();
-#endif
-    __syncthreads();  // every wave is done with the K-tile slots before the epilogue scratch reuses them
-    // Epilogue: 32 rows x WN columns at a time through the wave's LDS scratch (assembly dump, see the generator), then a rolled loop:
-    // one 16-byte column group per lane, 256 / WN rows per iteration.
-    constexpr int LPR = WN / 4, RPI = 64 / LPR;  // lanes per row, rows per iteration
-    float* scr = (float*)(smem + wave * (32 * WN * 4));
-    // LDS byte address of this lane's first scratch element (the dynamic LDS of this kernel starts at 0, as the main loop assumes)
-    const unsigned scr_lane = (unsigned)(wave * (32 * WN * 4) + ((((lane >> 4) * 4) * WN + (lane & 15)) * 4));
-    const GemmEpilogue& ep = g.ep;
-    const int gn = n0 + wc * WN + (lane % LPR) * 4;
-    const f32x4 bias = ep.bias_n ? *(const f32x4*)(ep.bias_n + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* rbase = ep.resid_src ? ep.resid_src : ep.out_f32;
-    const long rld = ep.resid_src ? ep.ld_resid : ep.ld_f32;
-    static_for<0, 3>([&](auto grp_c) {
-        constexpr int grp = decltype(grp_c)::value;
-        if constexpr (BN == 256) {
-#include "gemm_asm_192x256_dump.inc"
-        } else {
-#include "gemm_asm_192x128_dump.inc"
-        }
-#pragma unroll 2
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int row = it * RPI + lane / LPR;
-            const int gm = m0 + wr * WM + grp * 32 + row;
-            f32x4 v = *(const f32x4*)(scr + row * WN + (lane % LPR) * 4);
-            v += bias;
-            if (ep.bias_m) {
-                const float bm = ep.bias_m[gm];
-                v += f32x4{bm, bm, bm, bm};
-            }
-            if (ep.act == LTX_ACT_GELU_TANH) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-            } else if (ep.act == LTX_ACT_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-            }
-            if (ep.round_bf16) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
-            }
-            if (ep.resid) {
-                const f32x4 rs = *(const f32x4*)(rbase + (long)gm * rld + gn);
-                f32x4 gt = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
-                if (ep.gate) gt = *(const f32x4*)(ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[gm] : gm / ep.rows_per_batch) * ep.gate_bstride + gn);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
-            }
-            if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn) = v;
-            if (ep.out_bf16) {
-                uint2 pk;
-                pk.x = pack_bf16x2(v[0], v[1]);
-                pk.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn) = pk;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the scratch is rewritten by the next dump
-    });
-#ifdef GEMM_ASM_STAMPS
-    if (blockIdx.x == 7 && lane == 0) {
-        g_gemm_stamps[wave][6] = t_after - t_before;
-        g_gemm_stamps[wave][7] = __builtin_readcyclecounter() - t_after;
-    }
-#endif
-}
-
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2>
 void launch_v2(const GemmArgs& a, hipStream_t stream) {
     constexpr int smem = NSTAGE * (BM + BN) * ROW_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    attr_set.run([&] {
         HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    });
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     if (a.split_k > 1) {
         const GemmEpilogue& e = a.ep;
@@ -1363,22 +962,6 @@ void launch_v2(const GemmArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
         HIP_CHECK(hipGetLastError());
     }
-}
-
-template <int BM, int BN>
-void launch_v4(const GemmArgs& a, hipStream_t stream) {
-    constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
-    static_assert(smem >= 8 * 16 * (BN / 4) * 4, "epilogue scratch must fit in the ring");
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_v4<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
-    LTX_REQUIRE(!a.conv, "gemm v4: dense operands only");
-    LTX_REQUIRE(a.K % BK == 0 && a.K >= 2 * BK, "gemm v4: K=%d must be a multiple of %d and >= %d", a.K, BK, 2 * BK);
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel_v4<BM, BN>), dim3(tiles), dim3(512), smem, stream, a);
-    HIP_CHECK(hipGetLastError());
 }
 
 void validate(const GemmArgs& a) {
@@ -1410,6 +993,7 @@ void validate(const GemmArgs& a) {
 
 }  // namespace
 
+#ifdef LTX_EXPERIMENTS
 template <int BN>
 static bool gemm_asm_takes(const GemmArgs& a) {
     return !a.conv && a.split_k <= 1 && a.M % 192 == 0 && a.N % BN == 0 && a.K % 64 == 0 && a.K >= 64 && !a.ep.d2s;
@@ -1419,14 +1003,15 @@ static void launch_asm(const GemmArgs& a, hipStream_t stream) {
     LTX_REQUIRE(gemm_asm_takes<BN>(a), "gemm: the assembly kernel needs a dense A.B^T with M %% 192 == 0, N %% %d == 0, K %% 64 == 0 (M=%d N=%d K=%d)",
                 BN, a.M, a.N, a.K);
     constexpr int smem = RING == 2 ? 4 * 192 * ROW_BYTES : (RING ? 4 : 2) * (192 + BN) * ROW_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    attr_set.run([&] {
         HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_asm<BN, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL((gemm_bf16_kernel_asm<BN, RING>), dim3((a.M / 192) * (a.N / BN)), dim3(256), smem, stream, a);
     HIP_CHECK(hipGetLastError());
 }
+
+#endif
 
 void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     if (a.ep.out_bf16_t) {
@@ -1461,12 +1046,14 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 22: { GemmArgs b = a; b.group_m = 0; launch_v2<192, 128, 4, false, 4, 2>(b, stream); break; }  // A/B: column-major order
             case 23: launch_v2<256, 128, 3, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
+#ifdef LTX_EXPERIMENTS  // measured, not selected (gemm_experiments.inc)
             case 71: launch_asm<256>(a, stream); break;      // one wave per SIMD, assembly main loop, 192x256
             case 72: launch_asm<128>(a, stream); break;      // the same, 192x128
             case 73: launch_asm<128, 1>(a, stream); break;  // 192x128, one wave per SIMD, LDS-DMA ring of four slots
             case 74: launch_asm<128, 2>(a, stream); break;  // the same with B as fragment-layout loads straight to registers
             case 41: launch_v4<192, 256>(a, stream); break;  // ping-pong, 8 waves (2x4), per-wave 96x64
             case 42: launch_v4<256, 256>(a, stream); break;  // ping-pong, per-wave 128x64
+#endif
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
         }
     }
@@ -1531,6 +1118,7 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         launch_gemm_bf16(b, stream);
         return;
     }
+#ifdef LTX_EXPERIMENTS
     // The assembly kernel (tile_cfg 71: 192 x 256 tile, one wave per SIMD, generated main loop) is NOT in the default choice.
     // Measured on MI355X, HBM-cold weights, random data, same process (tools/bench_gemm.py --cold --cfgs=-1,21,1,71), TFLOP/s:
     // 1536x16384x4096 1057 vs 1009 (two-stage) / 987 (ring); 6144x4096x4096 1069 vs 1053 / 1015; 1536x8192x4096 895 vs 930 (ring);
@@ -1546,13 +1134,18 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
             return;
         }
     }
+#endif
     // A/B hook for in-pipeline tile experiments: LTX_GEMM_FORCE="8192:21,16384:21" forces a tile cfg for dense launches by N
     if (const char* f = getenv("LTX_GEMM_FORCE")) {
         for (const char* q = f; *q;) {
             const long n = strtol(q, (char**)&q, 10);
             if (*q != ':') break;
             const long c = strtol(q + 1, (char**)&q, 10);
+#ifdef LTX_EXPERIMENTS
             const bool takes = c == 71 ? gemm_asm_takes<256>(a) : (c >= 72 && c <= 74) ? gemm_asm_takes<128>(a) : true;
+#else
+            const bool takes = c < 41;
+#endif
             if (n == a.N && takes) {
                 launch_gemm_bf16_cfg(a, (int)c, stream);
                 return;

@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experiments: kernels outside the product library; needs the -DLTX_EXPERIMENTS build (LTX_LIB) and a GPU")
 
 
 def _ensure_built():
