@@ -36,13 +36,14 @@ def bootstrap(ctx, group=None):
     return rank, world
 
 
-def pair_groups():
-    """One torch.distributed group per consecutive rank pair; returns (my_group, pair_index). Every rank must call it."""
+def pair_groups(backend="gloo"):
+    """One torch.distributed group per consecutive rank pair (a side channel for the id exchange: gloo, so that creating it makes
+    no RCCL communicator of torch's); returns (my_group, pair_index). Every rank must call it."""
     world, rank = dist.get_world_size(), dist.get_rank()
     assert world % 2 == 0, "CFG pairs need an even number of ranks"
     mine = None
     for p in range(world // 2):
-        g = dist.new_group(ranks=[2 * p, 2 * p + 1])
+        g = dist.new_group(ranks=[2 * p, 2 * p + 1], backend=backend)
         if rank // 2 == p:
             mine = g
     return mine, rank // 2

@@ -1,0 +1,38 @@
+"""bench.py's launcher contract, without a GPU (`--launch-check`: ranks rendezvous over gloo and count themselves):
+`python bench.py --gpus N` with no launcher in the environment must start N ranks itself - a silent single-rank run that prints
+n_gpus 1 is what a scaling run must never get - and a WORLD_SIZE that disagrees with --gpus must fail."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def test_plain_invocation_spawns_the_ranks_itself():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], capture_output=True, text=True, env=_clean_env(), timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2
+
+
+def test_world_size_mismatch_is_an_error():
+    env = _clean_env()
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--launch-check"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_single_rank_launch_check():
+    r = subprocess.run([sys.executable, BENCH, "--launch-check"], capture_output=True, text=True, env=_clean_env(), timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["n_ranks_seen"] == 1
