@@ -443,7 +443,9 @@ int ltx_op_gemm_bf16_gated_residual(ltx_ctx* ctx, const uint16_t* A, long lda, c
 int ltx_op_gemv_f32(ltx_ctx* ctx, const float* a, long lda, const uint16_t* W, long ldw, const float* bias, float* out,
                     long ldo, int M, int N, int K, int in_act);
 /* O = softmax(Q K^T * scale + bias) V ; Q [B][Tq][H*128], K [B][Tk][H*128], Vt [B][H*128][ldvt] (keys contiguous,
- * ldvt >= roundup(Tk,64)), bias [B][Tk] f32 or NULL, O [B][Tq][H*128] ; all bf16 */
+ * ldvt >= roundup(Tk,64)), bias [B][Tk] f32 or NULL, O [B][Tq][H*128] ; all bf16. scale <= 0: Q already carries
+ * (1/sqrt(128)) * log2(e) - what the DiT's q-norm + RoPE pass writes, one rounding to bf16 - and the scores are base-2 exponents:
+ * O = softmax_2(Q K^T + bias * log2(e)) V. */
 int ltx_op_attention(ltx_ctx* ctx, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, long ldvt,
                      const float* bias, int B, int H, int Tq, int Tk, float scale, uint16_t* O);
 /* adaLN: out = norm(x) * (1+scale) + shift -> bf16 ; norm_kind 0 RMS, 1 LayerNorm; scale/shift [D] or NULL */

@@ -1019,6 +1019,7 @@ int ltx_op_attention(ltx_ctx* ctx, const uint16_t* Q, const uint16_t* K, const u
         a.O = O; a.ldo = D; a.o_bstride = (long)Tq * D;
         a.bias = bias; a.bias_bstride = Tk;
         a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale;
+        a.q_prescaled = scale <= 0.f ? 1 : 0;  // Q already carries scale * log2(e): scores are base-2 exponents
         launch_attention(a, ctx->stream);
     });
 }

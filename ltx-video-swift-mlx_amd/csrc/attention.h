@@ -15,6 +15,12 @@ struct AttnArgs {
     long bias_bstride = 0;
     int B = 0, H = 0, Tq = 0, Tk = 0;
     float scale = 0.08838834764831845f;  // 1/sqrt(128)
+    // 1: Q already carries scale * log2(e) (written so by qknorm_rope's out_scale, one rounding to bf16): the scores ARE the base-2
+    // exponents and `scale` is ignored. The assembly kernel then runs a stream without its 48 v_mul per key tile; the other
+    // kernels run with scale = ln 2. The bias stays in the reference's units (added to score * scale).
+    int q_prescaled = 0;
 };
+// what a producer multiplies q by for q_prescaled: (1 / sqrt(128)) * log2(e)
+constexpr float kAttnQueryPrescale = 0.08838834764831845f * 1.4426950408889634f;
 
 void launch_attention(const AttnArgs& args, hipStream_t stream);

@@ -625,7 +625,7 @@ __device__ unsigned long long g_w48_stamps[8][32];
 #endif
 // The same kernel with the main loop in assembly (generated by tools/gen_attn_w48.py from the layout above; register map and
 // schedule in that script's header). C++ only prepares the per-lane offsets and the uniform operands.
-template <bool HAS_BIAS>
+template <bool HAS_BIAS, bool PRESCALED = false>
 __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -661,14 +661,15 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     const uint32_t vblo = (uint32_t)(uintptr_t)Vb, vbhi = (uint32_t)((uintptr_t)Vb >> 32);
     const uint32_t krec = (uint32_t)(((long)(a.Tk - 1) * a.ldk + 128) * 2), vrec = (uint32_t)((long)128 * a.ldvt * 2);
     const uint32_t ktb = (uint32_t)(KV_TILE * a.ldk * 2);
-    const float c = a.scale * 1.4426950408889634f;
+    // PRESCALED: Q carries scale * log2(e) already, the scores are base-2 exponents (c = 1, the stream has no multiplies)
+    const float c = PRESCALED ? 1.0f : a.scale * 1.4426950408889634f;
     const uint32_t wlds = (uint32_t)wave * 1024u;
     const float tau = 8.0f / c;  // raw-score threshold: the reference maximum of a query is raised only when exp2((s - ref)*c) > 2^8
     // masked variant: the bias vector of this batch element goes to LDS once (16 KB after the ring, Tk <= 4096); a lane's 16 values
     // of a tile sit at ba + 256 * tile
     const float* biasb = HAS_BIAS ? a.bias + (long)b * a.bias_bstride : nullptr;
     const uint32_t bilo = (uint32_t)(uintptr_t)biasb, bihi = (uint32_t)((uintptr_t)biasb >> 32), birec = (uint32_t)(a.Tk * 4);
-    const float isc = 1.0f / a.scale;
+    const float isc = PRESCALED ? 1.4426950408889634f : 1.0f / a.scale;  // bias (post-scale, natural log) -> score units
     const int bvo = lane * 16;
     const int ba = W48_LDS + g * 32;
 #ifdef W48_STAMPS  // tools/ubench/attn_stamps.hip: per-wave s_memtime stamps of one tile step -> g_w48_stamps[wave][5]
@@ -682,12 +683,30 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
         [vo0] "v"(L.voff[0]), [vo1] "v"(L.voff[1]), [vo2] "v"(L.voff[2]), [vo3] "v"(L.voff[3]), [ka0] "v"(L.kaddr[0]),                  \
         [ka1] "v"(L.kaddr[1]), [ka2] "v"(L.kaddr[2]), [ka3] "v"(L.kaddr[3]), [va0] "v"(L.vaddr[0]), [va1] "v"(L.vaddr[1])
     if constexpr (HAS_BIAS) {
-        asm volatile(
-#include "attention_w48_asm_bias.inc"
-            :
-            : W48_OPERANDS, [bilo] "s"(bilo), [bihi] "s"(bihi), [birec] "s"(birec), [isc] "s"(isc), [bvo] "v"(bvo), [ba] "v"(ba)
-            :
+        if constexpr (PRESCALED) {
+            asm volatile(
+#include "attention_w48_asm_bias_ps.inc"
+                :
+                : W48_OPERANDS, [bilo] "s"(bilo), [bihi] "s"(bihi), [birec] "s"(birec), [isc] "s"(isc), [bvo] "v"(bvo), [ba] "v"(ba)
+                :
 #include "attention_w48_bias_clobbers.inc"
+            );
+        } else {
+            asm volatile(
+#include "attention_w48_asm_bias.inc"
+                :
+                : W48_OPERANDS, [bilo] "s"(bilo), [bihi] "s"(bihi), [birec] "s"(birec), [isc] "s"(isc), [bvo] "v"(bvo), [ba] "v"(ba)
+                :
+#include "attention_w48_bias_clobbers.inc"
+            );
+        }
+    } else if constexpr (PRESCALED) {
+        asm volatile(
+#include "attention_w48_asm_ps.inc"
+            :
+            : W48_OPERANDS
+            :
+#include "attention_w48_clobbers.inc"
         );
     } else {
         asm volatile(
@@ -711,7 +730,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
 
 }  // namespace
 
-void launch_attention(const AttnArgs& a, hipStream_t stream) {
+void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
+    AttnArgs a = a_in;
+    // q_prescaled: every kernel but the prescaled assembly stream computes exp2(score * scale * log2(e)); with Q carrying
+    // scale * log2(e) already that factor must be 1, i.e. scale = ln 2
+    if (a.q_prescaled) a.scale = 0.6931471805599453f;
     LTX_REQUIRE(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "attention: empty problem");
     LTX_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 4 == 0, "attention: leading dims");
     LTX_REQUIRE(a.ldvt >= ((a.Tk + 63) / 64) * 64, "attention: Vt row stride %ld must cover Tk=%d rounded up to 64", a.ldvt, a.Tk);
@@ -766,12 +789,18 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
             attr4_set.run([&] {
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS + 16384));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS + 16384));
             });
             const dim3 grid4((a.Tq + W48_Q - 1) / W48_Q, a.H, a.B);
-            if (a.bias)
-                hipLaunchKernelGGL(attn_fwd_kernel_w48_asm<true>, grid4, dim3(256), W48_LDS + 16384, stream, a);
+            if (a.bias && a.q_prescaled)
+                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<true, true>), grid4, dim3(256), W48_LDS + 16384, stream, a);
+            else if (a.bias)
+                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<true, false>), grid4, dim3(256), W48_LDS + 16384, stream, a);
+            else if (a.q_prescaled)
+                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<false, true>), grid4, dim3(256), W48_LDS, stream, a);
             else
-                hipLaunchKernelGGL(attn_fwd_kernel_w48_asm<false>, grid4, dim3(256), W48_LDS, stream, a);
+                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<false, false>), grid4, dim3(256), W48_LDS, stream, a);
             HIP_CHECK(hipGetLastError());
             return;
         }

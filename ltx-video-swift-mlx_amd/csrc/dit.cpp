@@ -411,7 +411,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             eqk.out_f32 = qk;
             eqk.ld_f32 = 2 * D;
             gemm_linear(xn, D, blk.qk1, (int)rows, eqk, st, sk);
-            launch_qknorm_rope2(qk, blk.qn1, q, qk + D, blk.kn1, k, 2 * D, D, rope_c, rope_s, T, (int)rows, D, eps, st);
+            launch_qknorm_rope2(qk, blk.qn1, q, qk + D, blk.kn1, k, 2 * D, D, rope_c, rope_s, T, (int)rows, D, eps, st, kAttnQueryPrescale);
             AttnArgs at;
             if (NW == 1) {
                 for (int b = 0; b < B; ++b) gemm_vt(xn + (size_t)b * T * D, D, T, blk.v1, vt + (size_t)b * D * Tpad, Tpad, st, sk);
@@ -433,6 +433,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             at.ldk = D;
             at.O = ao; at.ldo = D; at.o_bstride = (long)T * D;
             at.B = B; at.H = m->cfg.num_heads; at.Tq = T;
+            at.q_prescaled = 1;
             launch_attention(at, st);
             GemmEpilogue eo;
             eo.out_f32 = x;
@@ -454,7 +455,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             eq.out_f32 = qc;
             eq.ld_f32 = D;
             gemm_linear(xb, D, blk.q2, (int)rows, eq, st, sk);
-            launch_qknorm_rope(qc, D, blk.qn2, nullptr, nullptr, T, q, D, (int)rows, D, eps, st);
+            launch_qknorm_rope(qc, D, blk.qn2, nullptr, nullptr, T, q, D, (int)rows, D, eps, st, kAttnQueryPrescale);
             AttnArgs at;
             at.Q = q; at.ldq = D; at.q_bstride = (long)T * D;
             at.K = cc->k.as<bf16_t>() + (size_t)l * B * S * D; at.ldk = D; at.k_bstride = (long)S * D;
@@ -463,6 +464,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             at.bias = cc->has_bias ? cc->bias.as<float>() : nullptr;
             at.bias_bstride = S;
             at.B = B; at.H = m->cfg.num_heads; at.Tq = T; at.Tk = S;
+            at.q_prescaled = 1;
             launch_attention(at, st);
             GemmEpilogue eo;
             eo.out_f32 = x;

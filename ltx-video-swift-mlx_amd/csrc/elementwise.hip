@@ -3,6 +3,8 @@
 // wave shuffles + one LDS hop. Roofline for each is HBM bytes / 8 TB/s; none of them is reshaped into a GEMM.
 #include "elementwise.h"
 
+#include "runtime.h"
+
 namespace {
 
 constexpr int MAXV = 8;  // float4 chunks per thread kept in registers by the row kernels (D <= 8192)
@@ -114,6 +116,7 @@ struct QkJob {
     const float* w;
     bf16_t* out;
     long ldx, ldo;
+    float out_scale;  // multiplies the normed (and rotated) row before its ONE rounding to bf16 (1 = plain)
 };
 template <int NP>
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkJob j0, QkJob j1, const float* __restrict__ cosT,
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkJob j0, QkJob j1, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) s2 += va[j][e] * va[j][e] + vb[j][e] * vb[j][e];
     const float rstd = rsqrtf(block_reduce_sum(s2, red) / (float)D + eps);
+    const float osc = job.out_scale;
     bf16_t* orow = job.out + (long)row * job.ldo;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -180,10 +184,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkJob j0, QkJob j1, co
                 }
             }
             uint2 pa, pb;
-            pa.x = pack_bf16x2(a[0], a[1]);
-            pa.y = pack_bf16x2(a[2], a[3]);
-            pb.x = pack_bf16x2(b[0], b[1]);
-            pb.y = pack_bf16x2(b[2], b[3]);
+            pa.x = pack_bf16x2(a[0] * osc, a[1] * osc);
+            pa.y = pack_bf16x2(a[2] * osc, a[3] * osc);
+            pb.x = pack_bf16x2(b[0] * osc, b[1] * osc);
+            pb.y = pack_bf16x2(b[2] * osc, b[3] * osc);
             *(uint2*)(orow + col) = pa;
             *(uint2*)(orow + col + 64) = pb;
         }
@@ -546,6 +550,7 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
     LTX_REQUIRE(D % 4 == 0 && D <= MAXV * 1024 && ldx % 4 == 0 && ldo % 4 == 0, "norm_mod: D=%d ldx=%ld ldo=%ld", D, ldx, ldo);
     LTX_REQUIRE((scale == nullptr) == (shift == nullptr), "norm_mod: scale/shift must both be set or both null");
     const int rpb = rows_per_batch < 1 ? 1 : rows_per_batch;
+    ProfScope prof(PROF_ELEM, (double)rows * D * (4 + 2), stream);  // algorithmic bytes: f32 row in, bf16 row out
 #define LTX_NORM_LAUNCH(NV)                                                                                              \
     hipLaunchKernelGGL(norm_mod_kernel<NV>, dim3(rows), dim3(256), 0, stream, x, ldx, scale, shift, mod_bstride, rpb, out, \
                        ldo, D, norm_kind, eps, round_norm_bf16, row_map)
@@ -559,9 +564,11 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
 
 void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const float* x1, const float* w1, bf16_t* out1,
                          long ldx, long ldo, const float* cosT, const float* sinT, int T, int rows, int D, float eps,
-                         hipStream_t stream) {
+                         hipStream_t stream, float out_scale0) {
     LTX_REQUIRE(D % 128 == 0 && D <= MAXV * 1024 && ldx % 4 == 0 && ldo % 4 == 0, "qknorm_rope: D=%d", D);
-    const QkJob j0{x0, w0, out0, ldx, ldo}, j1{x1, w1, out1, ldx, ldo};
+    const QkJob j0{x0, w0, out0, ldx, ldo, out_scale0}, j1{x1, w1, out1, ldx, ldo, 1.0f};
+    // algorithmic bytes: the f32 rows in, the bf16 rows out, cos/sin rows once per job
+    ProfScope prof(PROF_ELEM, (double)rows * D * (x1 ? 2 : 1) * (4 + 2 + (cosT ? 4 : 0)), stream);
     const dim3 grid(rows, x1 ? 2 : 1);
     const int t = T < 1 ? 1 : T;
     if (D <= 2048) hipLaunchKernelGGL(qknorm_rope_kernel<1>, grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
@@ -571,8 +578,8 @@ void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const f
 }
 
 void launch_qknorm_rope(const float* x, long ldx, const float* w, const float* cosT, const float* sinT, int T,
-                        bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t stream) {
-    launch_qknorm_rope2(x, w, out, nullptr, nullptr, nullptr, ldx, ldo, cosT, sinT, T, rows, D, eps, stream);
+                        bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t stream, float out_scale) {
+    launch_qknorm_rope2(x, w, out, nullptr, nullptr, nullptr, ldx, ldo, cosT, sinT, T, rows, D, eps, stream, out_scale);
 }
 
 void launch_cast_f32_bf16(const float* x, bf16_t* out, long n, hipStream_t stream) {

@@ -42,6 +42,9 @@ struct GemmEpilogue {
     // (VideoDecoder.swift:201-251); 2: per-frame pixel shuffle (1,2,2) of the latent upscaler
     // (SpatialUpscaler.swift:116-131). Conv output channels are stored sub-position-major (permuted at load).
     int d2s = 0;
+    // cache policy of the interior-column epilogue's output stores: 0 plain (write-back: dirty lines are flushed at the kernel
+    // boundary), 16 = sc1 (write-through), 2 = nt. A/B knob (LTX_GEMM_STORE_AUX); see DESIGN.md section 4.
+    int store_aux = 0;
 };
 
 // Geometry of an implicit-GEMM conv3d A operand: x is [F][H][W][C] bf16 (channels-last), 3x3x3 taps,

@@ -244,12 +244,19 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
 #else
                 if (gm < g.M) {
 #endif
-                    if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn_w + c4) = v;
-                    if (ep.out_bf16) {
-                        uint2 pk;
-                        pk.x = pack_bf16x2(v[0], v[1]);
-                        pk.y = pack_bf16x2(v[2], v[3]);
-                        *(uint2*)(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn_w + c4) = pk;
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    if (ep.store_aux == 16) {
+                        // write-through: the bytes leave L2 as they are produced instead of in one flush at the kernel boundary
+                        if (ep.out_f32) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ep.out_f32 + (long)gm * ep.ld_f32 + gn_w + c4), "v"(v) : "memory");
+                        if (ep.out_bf16) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn_w + c4), "v"(pk) : "memory");
+                    } else if (ep.store_aux == 2) {
+                        if (ep.out_f32) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ep.out_f32 + (long)gm * ep.ld_f32 + gn_w + c4), "v"(v) : "memory");
+                        if (ep.out_bf16) asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 1" ::"v"(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn_w + c4), "v"(pk) : "memory");
+                    } else {
+                        if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn_w + c4) = v;
+                        if (ep.out_bf16) *(uint2*)(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn_w + c4) = pk;
                     }
                 }
             }
@@ -939,6 +946,111 @@ void launch_one(const GemmArgs& a, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 192 x 256 tile, ONE wave per SIMD, assembly main loop generated by tools/gen_gemm_asm_dtl.py (schedule, register map and the
+// static proof of its LDS-DMA / ds_read ordering are in that script). The wide DiT GEMMs (fused q|k: N = 8192, FFN up: N = 16384)
+// at 1536 tokens are exactly one / two rounds of 256 such tiles, where 192 x 128 tiles need two / four rounds and pay the fixed
+// cost of a round (ring fill, epilogue with every workgroup storing at once) twice as often. A 56 KB K-tile leaves room for two
+// LDS slots only, so both k-steps' fragments are held in registers and the LDS-DMA of tile t+2 reuses the slot of tile t as soon
+// as every wave has read it. Dense A.B^T only, M % 192 == 0, N % 256 == 0, K % 64 == 0. C++ prepares the per-lane offsets / LDS
+// addresses and runs the epilogue on the accumulators the assembly leaves in a[0:191].
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_dtl(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 192, BN = 256, WGN = 2;
+    constexpr int WM = 96, WN = 128;
+    constexpr int A_BYTES = BM * ROW_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int tiles_m = g.M / BM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(g, bid, tiles_m, BN, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    // piece i of this wave = rows (wave + 4 i) * 8 .. +7 of the tile: the per-lane part of its source address (row inside the piece,
+    // swizzled 16-byte chunk) does not depend on i ((row >> 1) & 7 is the same for rows 32 apart), the i part is a scalar offset
+    const int srow = lane >> 3, pch = lane & 7;
+    const int row0 = wave * 8 + srow;
+    const int ao = (row0 * (int)g.lda + ((pch ^ ((row0 >> 1) & 7)) << 3)) * 2;
+    const int bo = (row0 * (int)g.ldb + ((pch ^ ((row0 >> 1) & 7)) << 3)) * 2;
+    const uint32_t sa = (uint32_t)(32 * g.lda * 2), sb = (uint32_t)(32 * g.ldb * 2);
+    const bf16_t* At = g.A + (long)m0 * g.lda;
+    const bf16_t* Bt = g.B + (long)n0 * g.ldb;
+    const uint32_t alo = (uint32_t)(uintptr_t)At, ahi = (uint32_t)((uintptr_t)At >> 32);
+    const uint32_t blo = (uint32_t)(uintptr_t)Bt, bhi = (uint32_t)((uintptr_t)Bt >> 32);
+    const uint32_t arec = (uint32_t)(((long)(BM - 1) * g.lda + g.K) * 2), brec = (uint32_t)(((long)(BN - 1) * g.ldb + g.K) * 2);
+    const uint32_t nk = (uint32_t)(g.K / BK);
+    const uint32_t wlds = (uint32_t)wave * 1024u;
+    const int frow = lane & 15, fsw = (lane >> 1) & 7;
+    const int foff0 = frow * ROW_BYTES + ((((lane >> 4) + 0) ^ fsw) << 4);
+    const int foff1 = frow * ROW_BYTES + ((((lane >> 4) + 4) ^ fsw) << 4);
+    const int a_wave_off = (wr * WM) * ROW_BYTES, b_wave_off = A_BYTES + (wc * WN) * ROW_BYTES;
+    const int fa0 = a_wave_off + foff0, fa1 = a_wave_off + foff1, fb0 = b_wave_off + foff0, fb1 = b_wave_off + foff1;
+    asm volatile(
+#include "gemm_dtl_192x256.inc"
+        :
+        : [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk), [sa] "s"(sa),
+          [sb] "s"(sb), [wlds] "s"(wlds), [ao] "v"(ao), [bo] "v"(bo), [fa0] "v"(fa0), [fa1] "v"(fa1), [fb0] "v"(fb0), [fb1] "v"(fb1)
+        :
+#include "gemm_dtl_192x256_clobbers.inc"
+    );
+    __syncthreads();  // every wave is done with the K-tile slots before the epilogue scratch reuses them
+    // Epilogue: 32 rows x 128 columns at a time through the wave's LDS scratch (assembly dump shared with tools/gen_gemm_asm.py:
+    // same accumulator map), then a rolled loop: one 16-byte column group per lane, two rows per iteration.
+    constexpr int LPR = WN / 4, RPI = 64 / LPR;  // lanes per row, rows per iteration
+    float* scr = (float*)(smem + wave * (32 * WN * 4));
+    // LDS byte address of this lane's first scratch element (the dynamic LDS of this kernel starts at 0, as the main loop assumes)
+    const unsigned scr_lane = (unsigned)(wave * (32 * WN * 4) + ((((lane >> 4) * 4) * WN + (lane & 15)) * 4));
+    const GemmEpilogue& ep = g.ep;
+    const int gn = n0 + wc * WN + (lane % LPR) * 4;
+    const f32x4 bias = ep.bias_n ? *(const f32x4*)(ep.bias_n + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* rbase = ep.resid_src ? ep.resid_src : ep.out_f32;
+    const long rld = ep.resid_src ? ep.ld_resid : ep.ld_f32;
+    static_for<0, 3>([&](auto grp_c) {
+        constexpr int grp = decltype(grp_c)::value;
+#include "gemm_asm_192x256_dump.inc"
+#pragma unroll 2
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + lane / LPR;
+            const int gm = m0 + wr * WM + grp * 32 + row;
+            f32x4 v = *(const f32x4*)(scr + row * WN + (lane % LPR) * 4);
+            v += bias;
+            if (ep.bias_m) {
+                const float bm = ep.bias_m[gm];
+                v += f32x4{bm, bm, bm, bm};
+            }
+            if (ep.act == LTX_ACT_GELU_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+            } else if (ep.act == LTX_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+            }
+            if (ep.round_bf16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
+            }
+            if (ep.resid) {
+                const f32x4 rs = *(const f32x4*)(rbase + (long)gm * rld + gn);
+                f32x4 gt = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
+                if (ep.gate) gt = *(const f32x4*)(ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[gm] : gm / ep.rows_per_batch) * ep.gate_bstride + gn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
+            }
+            if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn) = v;
+            if (ep.out_bf16) {
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn) = pk;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the scratch is rewritten by the next dump
+    });
+}
+
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2>
 void launch_v2(const GemmArgs& a, hipStream_t stream) {
     constexpr int smem = NSTAGE * (BM + BN) * ROW_BYTES;
@@ -1013,11 +1125,24 @@ static void launch_asm(const GemmArgs& a, hipStream_t stream) {
 
 #endif
 
+static bool gemm_dtl_takes(const GemmArgs& a) {
+    return !a.conv && a.split_k <= 1 && a.M % 192 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 64 && !a.ep.d2s && !a.ep.out_bf16_t;
+}
+static void launch_dtl(const GemmArgs& a, hipStream_t stream) {
+    LTX_REQUIRE(gemm_dtl_takes(a), "gemm: the 192x256 kernel needs a dense A.B^T with M %% 192 == 0, N %% 256 == 0, K %% 64 == 0 (M=%d N=%d K=%d)",
+                a.M, a.N, a.K);
+    constexpr int smem = 2 * (192 + 256) * ROW_BYTES;
+    static PerDeviceOnce attr_set;
+    attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_dtl, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
+    hipLaunchKernelGGL(gemm_bf16_kernel_dtl, dim3((a.M / 192) * (a.N / 256)), dim3(256), smem, stream, a);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     if (a.ep.out_bf16_t) {
         const GemmEpilogue& e = a.ep;
         LTX_REQUIRE(!e.out_f32 && !e.out_bf16 && !e.resid && !e.d2s && !e.bias_m && e.act == LTX_ACT_NONE && !e.round_bf16 && a.split_k <= 1 &&
-                        !a.split_ws && e.ld_bf16_t % 4 == 0 && e.ld_bf16_t >= a.M && (cfg < 41 || cfg > 74),
+                        !a.split_ws && e.ld_bf16_t % 4 == 0 && e.ld_bf16_t >= a.M && cfg < 41,
                     "gemm: the transposed bf16 output takes bias_n only, no split-K, ld %% 4 == 0 (ld=%ld M=%d cfg=%d)", e.ld_bf16_t, a.M, cfg);
     }
     validate(a);
@@ -1046,6 +1171,7 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 22: { GemmArgs b = a; b.group_m = 0; launch_v2<192, 128, 4, false, 4, 2>(b, stream); break; }  // A/B: column-major order
             case 23: launch_v2<256, 128, 3, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
+            case 75: launch_dtl(a, stream); break;  // 192x256, one wave per SIMD, two LDS slots, fragments of a whole K-tile in registers
 #ifdef LTX_EXPERIMENTS  // measured, not selected (gemm_experiments.inc)
             case 71: launch_asm<256>(a, stream); break;      // one wave per SIMD, assembly main loop, 192x256
             case 72: launch_asm<128>(a, stream); break;      // the same, 192x128
@@ -1072,6 +1198,8 @@ int gemm_suggest_split_k(int M, int N, int K) {
 void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     // A/B hook: LTX_GEMM_GROUP_M="N:g,..." overrides the supertile height of dense launches with that N (tile_coords)
     GemmArgs a = a_in;
+    static const int store_aux = getenv("LTX_GEMM_STORE_AUX") ? atoi(getenv("LTX_GEMM_STORE_AUX")) : 0;
+    if (!a.conv && !a.ep.store_aux) a.ep.store_aux = store_aux;
     if (const char* f = getenv("LTX_GEMM_GROUP_M")) {
         for (const char* q = f; *q;) {
             const long n = strtol(q, (char**)&q, 10);
@@ -1091,8 +1219,11 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     //   M=1536 N=4096 K=4096 : cfg21 944 | cfg0 754 | cfg1 608      N=8192: cfg1 1026 | cfg21 949
     //   N=16384: cfg1 1049 | cfg21 991         K=16384: cfg21 1094 | cfg0 864       M=4096 N=1536: cfg25 876 | cfg0 629
     struct Cand { int cfg, bm, bn, slots; double f; };
-    static const Cand cands[] = {{1, 192, 128, 512, 1.00}, {21, 192, 128, 256, 0.95}, {25, 128, 192, 256, 0.90},
-                                 {0, 128, 128, 512, 0.80}, {3, 96, 128, 512, 0.72},   {4, 128, 96, 512, 0.72}};
+    //   cfg 75: 192x256 tile, one wave per SIMD, assembly main loop (tools/gen_gemm_asm_dtl.py): half the rounds of a 192x128 tile.
+    //   Same measurement, round 2 (profiles/r02_gemm_microbench.txt): N=8192: cfg75 1165 | library GEMM 1116 | cfg1 936 | cfg21 959;
+    //   N=16384: 1274 | 1294 | 1054 | 1009; 6144x4096x4096: 1290 | 1325 | 1093 | 1033; 1536x4096x4096 (128 tiles): 740 -> not chosen.
+    static const Cand cands[] = {{75, 192, 256, 256, 1.22}, {1, 192, 128, 512, 1.00}, {21, 192, 128, 256, 0.95}, {25, 128, 192, 256, 0.90},
+                                 {0, 128, 128, 512, 0.80},  {3, 96, 128, 512, 0.72},  {4, 128, 96, 512, 0.72}};
     if (a.conv) {
         // implicit-GEMM convs: the per-tap gather arithmetic must hide under MFMAs (8-wave ring kernels interleave it;
         // the two-stage 4-wave kernel serialises it and ran the 256-channel VAE stage at 150 TFLOP/s). M is huge, so
@@ -1142,9 +1273,9 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
             if (*q != ':') break;
             const long c = strtol(q + 1, (char**)&q, 10);
 #ifdef LTX_EXPERIMENTS
-            const bool takes = c == 71 ? gemm_asm_takes<256>(a) : (c >= 72 && c <= 74) ? gemm_asm_takes<128>(a) : true;
+            const bool takes = c == 71 ? gemm_asm_takes<256>(a) : (c >= 72 && c <= 74) ? gemm_asm_takes<128>(a) : c == 75 ? gemm_dtl_takes(a) : true;
 #else
-            const bool takes = c < 41;
+            const bool takes = c < 41 || (c == 75 && gemm_dtl_takes(a));
 #endif
             if (n == a.N && takes) {
                 launch_gemm_bf16_cfg(a, (int)c, stream);
@@ -1156,6 +1287,7 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     int best = 0;
     double be = -1;
     for (const Cand& c : cands) {
+        if (c.cfg == 75 && !gemm_dtl_takes(a)) continue;
         const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
         const long rounds = (tiles + c.slots - 1) / c.slots;
         const double fill = ((double)a.M * a.N) / ((double)tiles * c.bm * c.bn);  // ragged edges waste MFMA work

@@ -50,3 +50,17 @@ def test_checker_rejects_a_refill_without_a_barrier_behind_the_reads():
     early = fill + ["s_barrier", "s_waitcnt vmcnt(0)", "10:"] + read + ["s_branch 10b"]   # wait AFTER the barrier: not visible
     with pytest.raises(g.WaitCoverageError, match="RAW"):
         g.check_wait_coverage(early)
+
+
+DTL = os.path.join(ROOT, "tools", "gen_gemm_asm_dtl.py")
+
+
+def test_gemm_192x256_stream_is_proven_and_matches_the_committed_file():
+    r = subprocess.run([sys.executable, DTL, "--check"], capture_output=True, text=True)
+    assert r.returncode == 0 and "matches" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("flag,kind", [("--inject-raw-race", "RAW"), ("--inject-war-race", "WAR")])
+def test_gemm_192x256_checker_rejects_injected_races(flag, kind):
+    r = subprocess.run([sys.executable, DTL, "--check", flag], capture_output=True, text=True)
+    assert r.returncode != 0 and "WaitCoverageError: " + kind in r.stderr, r.stderr[-400:]

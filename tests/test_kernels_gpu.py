@@ -61,6 +61,51 @@ def test_gemm_split_k_integer_exact(gpu_ctx, M, N, K, S, cfg):
     assert np.array_equal(as_f32(outb), torch.from_numpy(ref).to(torch.bfloat16).float().numpy())
 
 
+@pytest.mark.parametrize("M,N,K,reps", [(192, 256, 64, 1), (192, 256, 128, 1), (192, 256, 192, 1), (384, 512, 448, 1), (192, 768, 7 * 64, 1),
+                                        (576, 256, 13 * 64, 2), (1536, 2048, 4096, 4), (768, 4096, 1024, 3), (1536, 8192, 4096, 2)])
+def test_gemm_192x256_kernel_integer_exact(gpu_ctx, M, N, K, reps):
+    """tile_cfg 75 (tools/gen_gemm_asm_dtl.py): 192x256 tile, one wave per SIMD, two LDS slots, both k-steps' fragments in registers,
+    LDS-DMA of tile t+2 into the slot of tile t. Bit-exact on integer data for 1, 2, 3, 7, 13, 16 and 64 K-tiles (both exits of the
+    two-tile loop body, either slot last) with bias, an f32 and a bf16 output; the large shapes are repeated with fresh operands
+    to screen the slot reuse for races (a stale or early-read tile shows as a wrong integer)."""
+    for r in range(reps):
+        rng = np.random.default_rng(M + N + K + 75 + 1000 * r)
+        A = rng.integers(-3, 4, (M, K)).astype(np.float32)
+        B = rng.integers(-3, 4, (N, K)).astype(np.float32)
+        bias = rng.integers(-5, 6, (N,)).astype(np.float32)
+        out = torch.empty((M, N), device="cuda")
+        outb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+        gpu_ctx.op_gemm(dev_bf16(A), dev_bf16(B), dev_f32(bias), tile_cfg=75, out_f32=out, out_bf16=outb)
+        torch.cuda.synchronize()
+        ref = A @ B.T + bias
+        got = as_f32(out)
+        assert np.array_equal(got, ref), f"rep {r}: {np.count_nonzero(got != ref)} wrong, max diff {np.abs(got - ref).max()}"
+        assert np.array_equal(as_f32(outb), torch.from_numpy(ref).to(torch.bfloat16).float().numpy())
+
+
+def test_gemm_192x256_kernel_epilogue_matches_ring_kernel(gpu_ctx, ltx):
+    """GELU-tanh + bias + bf16 output (the FFN's first GEMM) and an f32 output with bias (the fused q|k projection): same products,
+    same f32 accumulation order per K-tile, same epilogue arithmetic as the ring kernel -> bit-identical; shapes it does not take
+    are refused."""
+    rng = np.random.default_rng(9)
+    M, N, K = 384, 512, 256
+    A = dev_bf16(rng.standard_normal((M, K)))
+    B = dev_bf16(rng.standard_normal((N, K)) * 0.1)
+    bias = dev_f32(rng.standard_normal((N,)))
+    o1 = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    o2 = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_gemm(A, B, bias, act=1, tile_cfg=21, out_bf16=o1)
+    gpu_ctx.op_gemm(A, B, bias, act=1, tile_cfg=75, out_bf16=o2)
+    f1 = torch.empty((M, N), device="cuda")
+    f2 = torch.empty((M, N), device="cuda")
+    gpu_ctx.op_gemm(A, B, bias, tile_cfg=21, out_f32=f1)
+    gpu_ctx.op_gemm(A, B, bias, tile_cfg=75, out_f32=f2)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(f1, f2)
+    with pytest.raises(ltx.LTXError):
+        gpu_ctx.op_gemm(A[:100], B, bias, tile_cfg=75, out_bf16=o2[:100])
+
+
 @pytest.mark.parametrize("M,N,K,act", [(1536, 512, 4096, 0), (300, 256, 1024, 1), (128, 4096, 256, 2)])
 def test_gemm_random_vs_f32(gpu_ctx, M, N, K, act):
     rng = np.random.default_rng(11)
@@ -281,6 +326,38 @@ def test_attention_assembly_kernel_any_shape(gpu_ctx, attn_impl, B, H, Tq, Tk):
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-2
     if B == 1:
         assert (as_f32(obuf[:, Tq:]) == 7.0).all(), "rows past Tq were written"
+
+
+@pytest.mark.parametrize("impl", [1, 2, 4, None])
+@pytest.mark.parametrize("B,H,Tq,Tk,masked", [(1, 2, 192, 256, False), (1, 4, 1536, 1024, False), (1, 2, 1536, 1536, False), (2, 2, 105, 77, True),
+                                              (1, 1, 500, 321, False), (1, 3, 300, 1024, True), (2, 1, 1536, 1024, True)])
+def test_attention_prescaled_query(gpu_ctx, attn_impl, impl, B, H, Tq, Tk, masked):
+    """q_prescaled (scale <= 0 at the ABI): Q carries (1/sqrt(128)) * log2(e), rounded to bf16 ONCE by its producer (the DiT's
+    q-norm + RoPE pass), and the scores are base-2 exponents - the assembly kernel then runs its stream without the 48 multiplies
+    per key tile, the other kernels run with scale = ln 2. Reference: f32 softmax of the SAME bf16 Q' with scale ln 2 (identical
+    math); the masked case includes a fully masked batch element (bias in the reference's post-scale units)."""
+    if impl == 2 and masked:
+        pytest.skip("the ping-pong kernel is not used for masked launches")
+    attn_impl(impl)
+    rng = np.random.default_rng(B * 13 + H + Tq + Tk)
+    c = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
+    D = H * 128
+    q = (rng.standard_normal((B, Tq, D)) * 1.5).astype(np.float32)
+    qd, kd, vd, vt = _attn_inputs(rng, B, H, Tq, Tk, q=q * np.float32(c))
+    bias = None
+    if masked:
+        m = (rng.random((B, Tk)) > 0.3).astype(np.float32)
+        m[:, 0] = 1
+        m[0, :] = 0  # every key masked: softmax(s - 10000) = softmax(s)
+        bias = dev_f32((1 - m) * -10000.0)
+    o = torch.empty((B, Tq, D), device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_attention(qd, kd, vt, bias, H, o, 0.0)
+    torch.cuda.synchronize()
+    ref = _attn_ref(qd.float().cpu(), kd.float().cpu(), vd.float().cpu(), H, None if bias is None else bias.cpu(), math.log(2.0)).numpy()
+    got = as_f32(o)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-2
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-2
 
 
 @pytest.mark.parametrize("impl", [1, 4])

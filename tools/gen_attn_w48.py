@@ -65,6 +65,10 @@ def vblock_off(db):
 
 
 BIAS = "--bias" in __import__("sys").argv   # masked variant: additive per-key bias (cross-attention text mask)
+# prescaled variant: Q arrives multiplied by scale * log2(e) (rounded to bf16 once, by the producer): the MFMA's scores are already
+# the base-2 exponents, so the 48 v_mul per tile (and the multiply of the rare path) disappear. %[c] is unused, %[tau] = 8.0,
+# %[isc] = log2(e) (the bias is given in the reference's post-scale natural-log units).
+PS = "--prescaled" in __import__("sys").argv
 ABL = set(os.environ.get("W48_ABLATE", "").split(","))  # timing experiments only (wrong results): nodma, noexp, nords, ra6
 
 
@@ -187,9 +191,10 @@ class Gen:
         for qb in range(3):
             tup = [s_reg(sbuf, 2 * half + hh, qb) for hh in range(2)]
             out = []
-            for b in tup:
-                for j in range(4):
-                    out.append(f"v_mul_f32 v{b + j}, %[c], v{b + j}")
+            if not PS:
+                for b in tup:
+                    for j in range(4):
+                        out.append(f"v_mul_f32 v{b + j}, %[c], v{b + j}")
             for b in tup:
                 for j in range(4):
                     out.append(f"v_exp_f32 v{b + j}, v{b + j}")
@@ -240,8 +245,11 @@ class Gen:
                 e("s_nop 1")
                 e(f"v_max_f32 v{t}, v{t}, v{RT}")
             e(f"v_max_f32 v{RT + 1}, v{t}, v{FLOOR}")             # delta
-            e(f"v_mul_f32 v{RT + 2}, %[c], v{RT + 1}")
-            e(f"v_sub_f32 v{RT + 2}, 0, v{RT + 2}")
+            if PS:
+                e(f"v_sub_f32 v{RT + 2}, 0, v{RT + 1}")            # scores are base-2 exponents already
+            else:
+                e(f"v_mul_f32 v{RT + 2}, %[c], v{RT + 1}")
+                e(f"v_sub_f32 v{RT + 2}, 0, v{RT + 2}")
             e(f"v_min_f32 v{RT + 2}, 0, v{RT + 2}")                # first tile: the reference may move DOWN (O = l = 0 then; a
             e(f"v_exp_f32 v{RT + 2}, v{RT + 2}")                   # fully masked row would give 2^14427 = inf, inf * 0 = NaN)
             for j in range(4):
@@ -451,7 +459,13 @@ class Gen:
         e(f"v_mov_b32 v{FLOOR}, 0xff800000")
         for j in range(4):
             e(f"v_mov_b32 v{ONES + j}, 0x3f803f80")
-        e("s_waitcnt vmcnt(0)")
+        # Counted waits derived from the issue order Q, [bias,] K0, V0, K1, V1, K2, V2 (in-order counter): the first K.Q^T product
+        # needs Q and K0 only, so it runs while V0 / K1 are still landing; the loop's first step reads K of slot 1 (part A works one
+        # tile ahead) and Vt of slot 0, so V1 and all of tile 2 may still be in flight when it starts - the counted wait + barrier at
+        # the end of step 0 retires them before step 1 reads them. check_wait_coverage() proves both (a prologue that left K1 in
+        # flight shipped once and raced: DESIGN.md).
+        half = STAGE_OPS // 2
+        e(f"s_waitcnt vmcnt({3 * STAGE_OPS - half})")     # everything up to K0 has landed
         e("s_barrier")
         for kind, text in self.qk_stream(SA, 0):
             e(text)
@@ -467,6 +481,8 @@ class Gen:
         for ins in self.sm_max(SA):
             e(ins)
         self.sm_check_and_rare_path("9", SA, force=True)
+        e(f"s_waitcnt vmcnt({STAGE_OPS + half})")          # V0 and K1 have landed; V1, K2, V2 may fly
+        e("s_barrier")
         self.kstamp(1)
         e("10:")
         self.step(0, SA, SB, 11)
@@ -637,11 +653,11 @@ def main():
     g = Gen(stamps)
     lines = g.build()
     here = os.path.dirname(os.path.abspath(__file__))
-    name = "attention_w48_asm" + ("_bias" if BIAS else "") + ("_stamps" if stamps else "") + ".inc"
+    name = "attention_w48_asm" + ("_bias" if BIAS else "") + ("_ps" if PS else "") + ("_stamps" if stamps else "") + ".inc"
     out = os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", name)
     if "--inject-prologue-race" in sys.argv:
         # the race that shipped once (commit 7c76101): the prologue left tiles 1 and 2 in flight while step 0 reads slot 1
-        k = lines.index("s_waitcnt vmcnt(0)")
+        k = lines.index(f"s_waitcnt vmcnt({STAGE_OPS + STAGE_OPS // 2})")
         assert k < lines.index("10:")
         lines[k] = f"s_waitcnt vmcnt({2 * STAGE_OPS})"
     stats = None
