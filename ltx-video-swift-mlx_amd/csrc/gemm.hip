@@ -567,7 +567,7 @@ LTX_DEVFN void wait_vmcnt_barrier() {
 // 128-B line, to hide the HBM latency of the once-streamed DiT weights. Same-process A/B on MI355X: 779 vs 963 TFLOP/s
 // cold and 932 vs 1040 warm at 1536x8192x4096 - every touched line crosses the CU's vector L1, +40 % bytes through the
 // texture path that this loop already saturates. The ring depth stays the only latency cover.)
-#if defined(GEMM_ASM_STAMPS) || defined(GEMM_V2_STAMPS)
+#if defined(GEMM_ASM_STAMPS) || defined(GEMM_V2_STAMPS) || defined(DTL_STAMPS)
 __device__ unsigned long long g_gemm_stamps[5][8];  // diagnostic builds only (tools/ubench/gemm_stamps.hip)
 #endif
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2>
@@ -950,9 +950,9 @@ void launch_one(const GemmArgs& a, hipStream_t stream) {
 // 192 x 256 tile, ONE wave per SIMD, assembly main loop generated by tools/gen_gemm_asm_dtl.py (schedule, register map and the
 // static proof of its LDS-DMA / ds_read ordering are in that script). The wide DiT GEMMs (fused q|k: N = 8192, FFN up: N = 16384)
 // at 1536 tokens are exactly one / two rounds of 256 such tiles, where 192 x 128 tiles need two / four rounds and pay the fixed
-// cost of a round (ring fill, epilogue with every workgroup storing at once) twice as often. A 56 KB K-tile leaves room for two
-// LDS slots only, so both k-steps' fragments are held in registers and the LDS-DMA of tile t+2 reuses the slot of tile t as soon
-// as every wave has read it. Dense A.B^T only, M % 192 == 0, N % 256 == 0, K % 64 == 0. C++ prepares the per-lane offsets / LDS
+// cost of a round (ring fill, epilogue with every workgroup storing at once) twice as often. A 24 + 32 KB K-tile leaves room for
+// two activation slots and three weight slots, so both k-steps' fragments are held in registers and the LDS-DMA of A tile t+2 /
+// B tile t+3 reuses the slots of tile t as soon as every wave has read them (the loop runs at bytes in flight / HBM latency). Dense A.B^T only, M % 192 == 0, N % 256 == 0, K % 64 == 0. C++ prepares the per-lane offsets / LDS
 // addresses and runs the epilogue on the accumulators the assembly leaves in a[0:191].
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_dtl(const GemmArgs g) {
@@ -986,13 +986,24 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_dtl(const GemmArgs g)
     const int frow = lane & 15, fsw = (lane >> 1) & 7;
     const int foff0 = frow * ROW_BYTES + ((((lane >> 4) + 0) ^ fsw) << 4);
     const int foff1 = frow * ROW_BYTES + ((((lane >> 4) + 4) ^ fsw) << 4);
-    const int a_wave_off = (wr * WM) * ROW_BYTES, b_wave_off = A_BYTES + (wc * WN) * ROW_BYTES;
+    // LDS: [A slot 0][A slot 1][B slot 0][B slot 1][B slot 2] (tools/gen_gemm_asm_dtl.py)
+    const int a_wave_off = (wr * WM) * ROW_BYTES, b_wave_off = 2 * A_BYTES + (wc * WN) * ROW_BYTES;
     const int fa0 = a_wave_off + foff0, fa1 = a_wave_off + foff1, fb0 = b_wave_off + foff0, fb1 = b_wave_off + foff1;
+#ifdef DTL_STAMPS  // tools/ubench/gemm_dtl_stamps.hip
+    unsigned long long* dbg = (blockIdx.x == 7) ? &g_gemm_stamps[wave][0] : &g_gemm_stamps[4][0];
+#endif
     asm volatile(
+#ifdef DTL_STAMPS
+#include "gemm_dtl_192x256_stamps.inc"
+#else
 #include "gemm_dtl_192x256.inc"
+#endif
         :
         : [alo] "s"(alo), [ahi] "s"(ahi), [arec] "s"(arec), [blo] "s"(blo), [bhi] "s"(bhi), [brec] "s"(brec), [nk] "s"(nk), [sa] "s"(sa),
           [sb] "s"(sb), [wlds] "s"(wlds), [ao] "v"(ao), [bo] "v"(bo), [fa0] "v"(fa0), [fa1] "v"(fa1), [fb0] "v"(fb0), [fb1] "v"(fb1)
+#ifdef DTL_STAMPS
+          , [dbg] "s"(dbg)
+#endif
         :
 #include "gemm_dtl_192x256_clobbers.inc"
     );
@@ -1131,7 +1142,7 @@ static bool gemm_dtl_takes(const GemmArgs& a) {
 static void launch_dtl(const GemmArgs& a, hipStream_t stream) {
     LTX_REQUIRE(gemm_dtl_takes(a), "gemm: the 192x256 kernel needs a dense A.B^T with M %% 192 == 0, N %% 256 == 0, K %% 64 == 0 (M=%d N=%d K=%d)",
                 a.M, a.N, a.K);
-    constexpr int smem = 2 * (192 + 256) * ROW_BYTES;
+    constexpr int smem = (2 * 192 + 3 * 256) * ROW_BYTES;  // two activation slots, three weight slots
     static PerDeviceOnce attr_set;
     attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_dtl, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
     hipLaunchKernelGGL(gemm_bf16_kernel_dtl, dim3((a.M / 192) * (a.N / 256)), dim3(256), smem, stream, a);
