@@ -80,14 +80,16 @@ DiTModel* dit_create(const TransformerConfig& cfg) {
         lin(p + "ff.project_in.proj", b.ff1, 4 * D, D);
         lin(p + "ff.project_out", b.ff2, D, 4 * D);
     }
-    size_t total = 0;
-    for (auto& q : pend) total += DeviceArena::padded(slot_bytes(q.kind, q.rows * (q.cols ? q.cols : 1)));
-    m->weight_bytes = total;
+    size_t total = 0, total_w = 0;
+    for (auto& q : pend) (q.kind == SLOT_BF16 ? total_w : total) += DeviceArena::padded(slot_bytes(q.kind, q.rows * (q.cols ? q.cols : 1)));
+    m->weight_bytes = total + total_w;
     m->arena.reserve(total + 256);
+    m->warena.reserve(total_w + 256);   // the Linear weights on their own: dit_quantize releases exactly these
     HIP_CHECK(hipMemset(m->arena.buf.p, 0, m->arena.buf.bytes));
+    HIP_CHECK(hipMemset(m->warena.buf.p, 0, m->warena.buf.bytes));
     for (auto& q : pend) {
         const long numel = q.rows * (q.cols ? q.cols : 1);
-        *q.dst = m->arena.take(slot_bytes(q.kind, numel));
+        *q.dst = (q.kind == SLOT_BF16 ? m->warena : m->arena).take(slot_bytes(q.kind, numel));
         ParamSlot s;
         s.dst = *q.dst;
         s.kind = q.kind;
@@ -130,6 +132,7 @@ DiTModel* dit_create(const TransformerConfig& cfg) {
 void dit_destroy(DiTModel* m) { delete m; }
 
 void dit_load_safetensors(ltx_ctx* ctx, DiTModel* m, const std::string& path) {
+    LTX_REQUIRE(m->quant_bits == 16, "weights cannot be loaded into a quantised model");
     SafeTensors st;
     st.open(path);
     ctx->n_loaded = ctx->n_missing = ctx->n_unmatched = 0;
@@ -191,8 +194,16 @@ void dit_init_synthetic(ltx_ctx* ctx, DiTModel* m, uint64_t seed) {
 }
 
 void dit_export_slot(ltx_ctx* ctx, DiTModel* m, const ParamSlot& s, float* out) {
-    (void)ctx;
-    (void)m;
+    if (s.q) {  // quantised Linear weight: the value the GEMMs use, bf16(q * scale + bias)
+        DevBuf tmp;
+        tmp.ensure((size_t)s.numel * 2);
+        launch_dequant(s.q, s.qs, s.qb, s.rows, s.cols, m->quant_bits, tmp.as<bf16_t>(), ctx->stream);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        std::vector<bf16_t> h((size_t)s.numel);
+        HIP_CHECK(hipMemcpy(h.data(), tmp.p, (size_t)s.numel * 2, hipMemcpyDeviceToHost));
+        for (long i = 0; i < s.numel; ++i) out[i] = host_bf16_to_f32(h[i]);
+        return;
+    }
     if (s.kind == SLOT_F32) {
         HIP_CHECK(hipMemcpy(out, s.dst, (size_t)s.numel * 4, hipMemcpyDeviceToHost));
         return;
@@ -389,9 +400,9 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     }
     // 2. timestep path in f32 activations x bf16 weights (LTXTimestepEmbedding.swift:62-124)
     launch_timestep_embedding(a.timesteps, m->cfg.timestep_scale_multiplier, m->ws_emb256.as<float>(), BG, 256, st);
-    launch_gemv_f32(m->ws_emb256.as<float>(), 256, m->ada_l1.w, 256, m->ada_l1.b, m->ws_h1.as<float>(), D, BG, D, 256, LTX_ACT_NONE, st);
-    launch_gemv_f32(m->ws_h1.as<float>(), D, m->ada_l2.w, D, m->ada_l2.b, m->ws_embts.as<float>(), D, BG, D, D, LTX_ACT_SILU, st);
-    launch_gemv_f32(m->ws_embts.as<float>(), D, m->ada_lin.w, D, m->ada_lin.b, m->ws_ada.as<float>(), 6 * D, BG, 6 * D, D, LTX_ACT_SILU, st);
+    launch_gemv_f32(m->ws_emb256.as<float>(), 256, dit_linear_weights(m->ada_l1, st), 256, m->ada_l1.b, m->ws_h1.as<float>(), D, BG, D, 256, LTX_ACT_NONE, st);
+    launch_gemv_f32(m->ws_h1.as<float>(), D, dit_linear_weights(m->ada_l2, st), D, m->ada_l2.b, m->ws_embts.as<float>(), D, BG, D, D, LTX_ACT_SILU, st);
+    launch_gemv_f32(m->ws_embts.as<float>(), D, dit_linear_weights(m->ada_lin, st), D, m->ada_lin.b, m->ws_ada.as<float>(), 6 * D, BG, 6 * D, D, LTX_ACT_SILU, st);
     launch_make_mod(m->sst_blocks, m->ws_ada.as<float>(), mod, BG, L, 6, D, st);
     // output modulation: shift = SST_out[0] + emb_ts, scale = SST_out[1] + emb_ts (LTXTransformer.swift:208-224)
     for (int j = 0; j < 2; ++j) {

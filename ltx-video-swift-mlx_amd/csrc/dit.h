@@ -11,10 +11,22 @@
 #include "hostmath.h"
 #include "runtime.h"
 
+// One scratch matrix for the weights of the GEMM that is about to run on a quantised model (largest Linear: 16384 x 4096 bf16).
+struct DequantScratch {
+    DevBuf buf;
+};
+
 struct LinearW {
-    bf16_t* w = nullptr;  // [out][in] bf16
+    bf16_t* w = nullptr;  // [out][in] bf16; null once the model is quantised (dit_quantize releases the bf16 weights)
     float* b = nullptr;   // [out] f32 (bf16-representable values)
     int out = 0, in = 0;
+    // affine group quantisation (LTXQuantizationConfig.swift:19-62; MLX layout: codes + per-group scale and bias, group = 64 along
+    // `in`): w'[o][i] = bf16(q[o][i] * scale[o][i/64] + bias[o][i/64]). qbits 8: one code per byte; 4: two per byte, low nibble first.
+    const uint8_t* q = nullptr;
+    const bf16_t* qs = nullptr;
+    const bf16_t* qb = nullptr;
+    int qbits = 0;
+    DequantScratch* dq = nullptr;
 };
 
 struct DiTBlock {
@@ -32,6 +44,11 @@ struct DiTBlock {
 
 enum SlotKind { SLOT_BF16 = 0, SLOT_F32 = 1 };
 struct ParamSlot {
+    // quantised model: the slot of a Linear weight points at its codes / scales / biases instead of dst (rows of a fused matrix
+    // are row offsets into all three)
+    uint8_t* q = nullptr;
+    bf16_t* qs = nullptr;
+    bf16_t* qb = nullptr;
     void* dst = nullptr;
     int kind = SLOT_BF16;
     long numel = 0;
@@ -43,7 +60,10 @@ struct ParamSlot {
 struct DiTModel {
     TransformerConfig cfg;
     int D = 0, L = 0;
-    DeviceArena arena;
+    DeviceArena arena;    // biases, norm weights, scale-shift tables (f32)
+    DeviceArena warena;   // Linear weights, bf16 (26.07 GB at the reference architecture); released by dit_quantize
+    DeviceArena qarena;   // after dit_quantize: codes + group scales / biases (13.9 GB at 8 bits, 7.3 GB at 4)
+    DequantScratch dq;
     LinearW patchify, ada_l1, ada_l2, ada_lin, cap_l1, cap_l2, proj_out;
     float* sst_blocks = nullptr;  // [L][6][D]
     float* sst_out = nullptr;     // [2][D]
@@ -116,6 +136,11 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a);
 // (LoRALoader.swift:63-111,162-178; LoRAAdapter.swift:64-166). Returns the number of fused layers.
 int dit_fuse_lora(ltx_ctx* ctx, DiTModel* m, const std::string& path, float scale);
 // R21: on-the-fly affine quantisation of every Linear weight, group size 64 along `in`, 8 or 4 bits
-// (LTXQuantizationConfig.swift:19-62, LTXPipeline.swift:323-333). Weights are replaced by their de-quantised
-// values (HBM capacity is not the constraint on MI355X; the MFMA path stays bf16).
+// (LTXQuantizationConfig.swift:19-62, LTXPipeline.swift:323-333). The bf16 weights are REPLACED by codes + bf16 group scale / bias
+// (the layout MLX's QuantizedLinear holds) and their 26 GB are released. Consumers: GEMMs with few rows (the HBM-bound regime,
+// e.g. 256x256x9 = 128 tokens) read the 8-bit codes directly and de-quantise in the B stage; GEMMs with many rows (MFMA-bound)
+// get the weight matrix of the launch de-quantised into one scratch matrix first (a streaming pass worth 2-3 % of such a GEMM).
 void dit_quantize(ltx_ctx* ctx, DiTModel* m, int bits, int group);
+// bf16 weights of a Linear for a launch on `stream`: the resident matrix, or the scratch matrix filled from the codes
+const bf16_t* dit_linear_weights(const LinearW& w, hipStream_t stream);
+void launch_dequant(const uint8_t* q, const bf16_t* qs, const bf16_t* qb, long out, long in, int bits, bf16_t* dst, hipStream_t stream);

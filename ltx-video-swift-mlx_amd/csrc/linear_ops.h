@@ -14,7 +14,7 @@ inline void gemm_linear(const bf16_t* A, long lda, const LinearW& w, int M, Gemm
     GemmArgs g;
     g.A = A;
     g.lda = lda;
-    g.B = w.w;
+    g.B = dit_linear_weights(w, s);
     g.ldb = w.in;
     g.M = M;
     g.N = w.out;
@@ -37,7 +37,7 @@ inline void gemm_vt(const bf16_t* X, long ldx, int tokens, const LinearW& wv, bf
         GemmArgs g;
         g.A = X;
         g.lda = ldx;
-        g.B = wv.w;
+        g.B = dit_linear_weights(wv, s);
         g.ldb = wv.in;
         g.M = tokens;
         g.N = wv.out;
@@ -49,7 +49,7 @@ inline void gemm_vt(const bf16_t* X, long ldx, int tokens, const LinearW& wv, bf
         return;
     }
     GemmArgs g;
-    g.A = wv.w;
+    g.A = dit_linear_weights(wv, s);
     g.lda = wv.in;
     g.B = X;
     g.ldb = ldx;

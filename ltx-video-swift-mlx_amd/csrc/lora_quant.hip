@@ -28,7 +28,9 @@ __global__ void lora_add_kernel(bf16_t* __restrict__ W, const bf16_t* __restrict
 //   scale = mask ? scale : -scale; edge = mask ? w_min : w_max; q0 = round(edge/scale)
 //   scale = q0 != 0 ? edge/q0 : scale; bias = q0 == 0 ? 0 : edge
 //   q = clip(round((w - bias)/scale), 0, 2^b-1);  w' = q*scale + bias   (scale, bias stored in bf16)
-__global__ __launch_bounds__(256) void fake_quant_kernel(bf16_t* __restrict__ W, long n_groups, int bits) {
+// Output: the codes (8 bits: one per byte; 4 bits: two per byte, even element in the low nibble) and the group's scale / bias.
+__global__ __launch_bounds__(256) void quant_encode_kernel(const bf16_t* __restrict__ W, long n_groups, int bits, uint8_t* __restrict__ codes,
+                                                           bf16_t* __restrict__ scales, bf16_t* __restrict__ biases) {
     const int lane = threadIdx.x & 63;
     long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long gstride = (long)gridDim.x * 4;
@@ -44,12 +46,65 @@ __global__ __launch_bounds__(256) void fake_quant_kernel(bf16_t* __restrict__ W,
         const float q0 = rintf(edge / scale);
         scale = (q0 != 0.f) ? edge / q0 : scale;
         float bias = (q0 == 0.f) ? 0.f : edge;
-        scale = bf16_to_f32(f32_to_bf16(scale));
-        bias = bf16_to_f32(f32_to_bf16(bias));
+        const bf16_t sb = f32_to_bf16(scale), bb = f32_to_bf16(bias);
+        scale = bf16_to_f32(sb);
+        bias = bf16_to_f32(bb);
         float q = rintf((w - bias) / scale);
         q = fminf(fmaxf(q, 0.f), n_bins);
-        W[g * 64 + lane] = f32_to_bf16(q * scale + bias);
+        const unsigned qi = (unsigned)q;
+        if (bits == 8) {
+            codes[g * 64 + lane] = (uint8_t)qi;
+        } else {
+            const unsigned hi = __shfl_down(qi, 1, 64);
+            if ((lane & 1) == 0) codes[g * 32 + (lane >> 1)] = (uint8_t)(qi | (hi << 4));
+        }
+        if (lane == 0) {
+            scales[g] = sb;
+            biases[g] = bb;
+        }
     }
+}
+
+// codes -> bf16 weights, w' = bf16(q * scale + bias): 16 codes (8 bits) or 32 codes (4 bits) = 16 bytes per thread, whole groups only
+// (64 elements = 4 or 2 threads). The same arithmetic as the encoder's own reconstruction.
+template <int BITS>
+__global__ __launch_bounds__(256) void quant_decode_kernel(const uint8_t* __restrict__ codes, const bf16_t* __restrict__ scales,
+                                                           const bf16_t* __restrict__ biases, long n_chunks, bf16_t* __restrict__ W) {
+    constexpr int PER = BITS == 8 ? 16 : 32;  // elements per 16-byte chunk
+    for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < n_chunks; c += (long)gridDim.x * 256) {
+        const uint4 raw = *(const uint4*)(codes + c * 16);
+        const long g = (c * PER) >> 6;
+        const float scale = bf16_to_f32(scales[g]), bias = bf16_to_f32(biases[g]);
+        const uint32_t wd[4] = {raw.x, raw.y, raw.z, raw.w};
+        uint32_t out[PER / 2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (BITS == 8) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float q0 = (float)((wd[i] >> (16 * j)) & 0xffu), q1 = (float)((wd[i] >> (16 * j + 8)) & 0xffu);
+                    out[i * 2 + j] = pack_bf16x2(q0 * scale + bias, q1 * scale + bias);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float q0 = (float)((wd[i] >> (8 * j)) & 0xfu), q1 = (float)((wd[i] >> (8 * j + 4)) & 0xfu);
+                    out[i * 4 + j] = pack_bf16x2(q0 * scale + bias, q1 * scale + bias);
+                }
+            }
+        }
+        uint4* dst = (uint4*)(W + c * PER);
+#pragma unroll
+        for (int i = 0; i < PER / 8; ++i) dst[i] = uint4{out[i * 4], out[i * 4 + 1], out[i * 4 + 2], out[i * 4 + 3]};
+    }
+}
+
+void launch_encode(const bf16_t* W, long out, long in, int bits, uint8_t* codes, bf16_t* scales, bf16_t* biases, hipStream_t stream) {
+    const long groups = out * in / 64;
+    long grid = (groups + 3) / 4;
+    if (grid > 65535 * 4) grid = 65535 * 4;
+    hipLaunchKernelGGL(quant_encode_kernel, dim3((unsigned)grid), dim3(256), 0, stream, W, groups, bits, codes, scales, biases);
+    HIP_CHECK(hipGetLastError());
 }
 
 bool ends_with(const std::string& s, const char* suf) {
@@ -63,26 +118,75 @@ void replace_first(std::string& s, const char* from, const char* to) {
 
 }  // namespace
 
+void launch_dequant(const uint8_t* q, const bf16_t* qs, const bf16_t* qb, long out, long in, int bits, bf16_t* dst, hipStream_t stream) {
+    const long n_chunks = out * in * bits / 8 / 16;
+    long grid = (n_chunks + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    if (bits == 8)
+        hipLaunchKernelGGL(quant_decode_kernel<8>, dim3((unsigned)grid), dim3(256), 0, stream, q, qs, qb, n_chunks, dst);
+    else
+        hipLaunchKernelGGL(quant_decode_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, q, qs, qb, n_chunks, dst);
+    HIP_CHECK(hipGetLastError());
+}
+
+const bf16_t* dit_linear_weights(const LinearW& w, hipStream_t stream) {
+    if (w.w) return w.w;
+    if (!w.q || !w.dq) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model component not loaded: Linear weights (%d x %d)", w.out, w.in);
+    // the GEMM that consumes the scratch runs behind this pass on the same stream, and the next pass behind that GEMM
+    w.dq->buf.ensure((size_t)w.out * w.in * 2);
+    launch_dequant(w.q, w.qs, w.qb, w.out, w.in, w.qbits, w.dq->buf.as<bf16_t>(), stream);
+    return w.dq->buf.as<bf16_t>();
+}
+
 void dit_quantize(ltx_ctx* ctx, DiTModel* m, int bits, int group) {
     LTX_REQUIRE(bits == 8 || bits == 4, "transformer quantization: %d bits not supported (bf16, qint8, int4)", bits);
     LTX_REQUIRE(group == 64, "transformer quantization: group size %d not supported (64)", group);
+    LTX_REQUIRE(m->quant_bits == 16, "the transformer is already quantised (%d bits)", m->quant_bits);
     // every Linear of the model (MLXNN.quantize(model:groupSize:bits:), LTXPipeline.swift:329)
-    std::set<const void*> done;
-    auto q = [&](const LinearW& l) {
-        if (!l.w || done.count(l.w)) return;
-        done.insert(l.w);
-        LTX_REQUIRE(l.in % 64 == 0, "quantize: in-features %d not a multiple of 64", l.in);
-        const long groups = (long)l.out * l.in / 64;
-        long grid = (groups + 3) / 4;
-        if (grid > 65535 * 4) grid = 65535 * 4;
-        hipLaunchKernelGGL(fake_quant_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, l.w, groups, bits);
-        HIP_CHECK(hipGetLastError());
-    };
-    q(m->patchify); q(m->ada_l1); q(m->ada_l2); q(m->ada_lin); q(m->cap_l1); q(m->cap_l2); q(m->proj_out);
-    for (auto& b : m->blocks) {
-        q(b.qk1); q(b.v1); q(b.o1); q(b.q2); q(b.k2); q(b.v2); q(b.o2); q(b.ff1); q(b.ff2);
+    std::vector<LinearW*> lins = {&m->patchify, &m->ada_l1, &m->ada_l2, &m->ada_lin, &m->cap_l1, &m->cap_l2, &m->proj_out};
+    for (auto& b : m->blocks)
+        for (LinearW* l : {&b.qk1, &b.v1, &b.o1, &b.q2, &b.k2, &b.v2, &b.o2, &b.ff1, &b.ff2}) lins.push_back(l);
+    size_t total = 0, largest = 0;
+    for (LinearW* l : lins) {
+        LTX_REQUIRE(l->w && l->in % 64 == 0, "quantize: in-features %d not a multiple of 64", l->in);
+        const size_t n = (size_t)l->out * l->in;
+        total += DeviceArena::padded(n * bits / 8) + 2 * DeviceArena::padded(n / 64 * 2);
+        largest = std::max(largest, n);
+    }
+    m->qarena.reserve(total + 256);
+    m->dq.buf.ensure(largest * 2);
+    std::map<const bf16_t*, LinearW*> by_w;
+    for (LinearW* l : lins) {
+        const size_t n = (size_t)l->out * l->in;
+        uint8_t* codes = (uint8_t*)m->qarena.take(n * bits / 8);
+        bf16_t* qs = (bf16_t*)m->qarena.take(n / 64 * 2);
+        bf16_t* qb = (bf16_t*)m->qarena.take(n / 64 * 2);
+        launch_encode(l->w, l->out, l->in, bits, codes, qs, qb, ctx->stream);
+        l->q = codes;
+        l->qs = qs;
+        l->qb = qb;
+        l->qbits = bits;
+        l->dq = &m->dq;
+        by_w[l->w] = l;
+    }
+    // parameter slots of the weights (incl. the to_q / to_k row views of the fused matrix) now name codes / scales / biases
+    for (auto& kv : m->slots) {
+        ParamSlot& sl = kv.second;
+        if (sl.kind != SLOT_BF16) continue;
+        auto it = by_w.upper_bound((const bf16_t*)sl.dst);
+        LTX_REQUIRE(it != by_w.begin(), "quantize: parameter %s has no Linear", kv.first.c_str());
+        --it;
+        LinearW* l = it->second;
+        const long off = (const bf16_t*)sl.dst - l->w;  // elements from the start of the (fused) matrix: whole rows
+        LTX_REQUIRE(off >= 0 && off + sl.numel <= (long)l->out * l->in && off % l->in == 0, "quantize: parameter %s is not a row range", kv.first.c_str());
+        sl.q = (uint8_t*)l->q + off * bits / 8;
+        sl.qs = (bf16_t*)l->qs + off / 64;
+        sl.qb = (bf16_t*)l->qb + off / 64;
+        sl.dst = nullptr;
     }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (LinearW* l : lins) l->w = nullptr;
+    m->warena.buf.release();   // the bf16 weights are gone: 26 GB -> 13.9 GB (8 bits) / 7.3 GB (4 bits) resident
     m->quant_bits = bits;
     for (auto* c : m->ctx_cache) c->version = 0;
 }
@@ -97,7 +201,7 @@ int dit_fuse_lora(ltx_ctx* ctx, DiTModel* m, const std::string& path, float scal
     }
     hipStream_t stm = ctx->stream;
     int fused = 0;
-    DevBuf d_up, d_down, d_delta;
+    DevBuf d_up, d_down, d_delta, d_w;
     std::vector<bf16_t> h_up, h_down, h_downT;
     for (auto& kv : st.tensors) {
         const std::string& key = kv.first;
@@ -162,14 +266,15 @@ int dit_fuse_lora(ltx_ctx* ctx, DiTModel* m, const std::string& path, float scal
         const long n = (long)out * in;
         long grid = (n + 255) / 256;
         if (grid > 65535) grid = 65535;
-        hipLaunchKernelGGL(lora_add_kernel, dim3((unsigned)grid), dim3(256), 0, stm, (bf16_t*)slot.dst, d_delta.as<bf16_t>(), eff, n);
-        HIP_CHECK(hipGetLastError());
-        if (m->quant_bits == 8 || m->quant_bits == 4) {
-            // dequant -> merge -> requant (LoRAAdapter.swift:104-131)
-            const long groups = n / 64;
-            long qg = (groups + 3) / 4;
-            if (qg > 65535 * 4) qg = 65535 * 4;
-            hipLaunchKernelGGL(fake_quant_kernel, dim3((unsigned)qg), dim3(256), 0, stm, (bf16_t*)slot.dst, groups, m->quant_bits);
+        if (slot.q) {
+            // quantised model: dequant -> merge -> requant (LoRAAdapter.swift:104-131) through one scratch matrix
+            d_w.ensure((size_t)n * 2);
+            launch_dequant(slot.q, slot.qs, slot.qb, out, in, m->quant_bits, d_w.as<bf16_t>(), stm);
+            hipLaunchKernelGGL(lora_add_kernel, dim3((unsigned)grid), dim3(256), 0, stm, d_w.as<bf16_t>(), d_delta.as<bf16_t>(), eff, n);
+            HIP_CHECK(hipGetLastError());
+            launch_encode(d_w.as<bf16_t>(), out, in, m->quant_bits, slot.q, slot.qs, slot.qb, stm);
+        } else {
+            hipLaunchKernelGGL(lora_add_kernel, dim3((unsigned)grid), dim3(256), 0, stm, (bf16_t*)slot.dst, d_delta.as<bf16_t>(), eff, n);
             HIP_CHECK(hipGetLastError());
         }
         HIP_CHECK(hipStreamSynchronize(stm));  // host staging vectors are reused by the next layer
