@@ -31,6 +31,9 @@ public struct LTXVideoGenerationConfig {
     public var stgBlocks: [Int32] = [29]
     public var imageCondNoiseScale: Float = 0.0
     public var vaeTemporalTileSize = 0, vaeTemporalTileOverlap = 1
+    /// 0 = this GPU evaluates everything; 1 = CFG pair over the group (LTX_SHARD_CFG); 2 = one sample's tokens over the group
+    /// (LTX_SHARD_SEQUENCE). Needs `joinGroup` first; every rank of the group calls generateVideo with the same arguments.
+    public var shard = 0
     public init() {}
     public func validate() throws {
         var msg = [CChar](repeating: 0, count: 256)
@@ -77,6 +80,18 @@ public final class LTXPipelineHIP {
     }
     public func loadConnector(from unifiedWeights: String) throws { try check(ltx_connector_load(ctx, unifiedWeights, nil)) }
     public func loadVAEEncoder(from vaeWeights: String) throws { try check(ltx_vae_encoder_load(ctx, vaeWeights, 0)) }
+    /// One process per GPU: the RCCL communicator of this pipeline's group (include/ltxhip.h, "Multi-GPU"). `uniqueId` = the 128
+    /// bytes `LTXPipelineHIP.makeGroupId()` returned on the group's first rank, carried to the others by the host.
+    public static func makeGroupId() throws -> [UInt8] {
+        var id = [UInt8](repeating: 0, count: Int(LTX_DIST_ID_BYTES))
+        guard ltx_dist_unique_id(&id) == 0 else { throw LTXError.hip(String(cString: ltx_last_error(nil))) }
+        return id
+    }
+
+    public func joinGroup(rank: Int, size: Int, uniqueId: [UInt8]) throws {
+        try check(ltx_dist_init(ctx, Int32(rank), Int32(size), uniqueId))
+    }
+
     public func fuseLoRA(from path: String, scale: Float = 1.0) throws -> Int {
         var n: Int32 = 0
         try check(ltx_dit_fuse_lora(ctx, path, scale, &n))
@@ -124,7 +139,8 @@ public final class LTXPipelineHIP {
                                                   stg_blocks: stgPtr.baseAddress, n_stg_blocks: Int32(stgPtr.count), ge_gamma: config.geGamma,
                                                   cond_latent: imageLatent == nil ? nil : img.baseAddress,
                                                   image_cond_noise_scale: config.imageCondNoiseScale,
-                                                  cond_noise: injectionNoise == nil ? nil : inj.baseAddress)
+                                                  cond_noise: injectionNoise == nil ? nil : inj.baseAddress,
+                                                  shard: Int32(config.shard))
                     try check(ltx_denoise(ctx, &latent, f, h, w, sig, Int32(config.numSteps + 1), text.embeddings, text.mask,
                                           Int32(text.tokens), &opt, thunk, Unmanaged.passUnretained(box).toOpaque()))
                 }
