@@ -315,7 +315,7 @@ def run_replica(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side):
         if g["ms"] > 0:
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12
             traffic, src = pmc_traffic()
-            roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel{,_v2}", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+            roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel{_dtl,_v2,}", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
                         "sustained_peak_measured": SUSTAINED_BF16_TFLOPS, "frac_of_sustained": round(ach / SUSTAINED_BF16_TFLOPS, 4),
                         "launches": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2),
