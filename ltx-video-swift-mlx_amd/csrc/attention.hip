@@ -702,9 +702,16 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
         }
     } else if constexpr (PRESCALED) {
         asm volatile(
+#ifdef W48_STAMPS
+#include "attention_w48_asm_ps_stamps.inc"
+#else
 #include "attention_w48_asm_ps.inc"
+#endif
             :
             : W48_OPERANDS
+#ifdef W48_STAMPS
+              , [dbg] "s"(dbg)
+#endif
             :
 #include "attention_w48_clobbers.inc"
         );

@@ -132,3 +132,38 @@ def test_denoise_image_to_video(ltx, oracle, gpu_ctx, model, use_cfg, noise_scal
     assert rel_l2(got[:, :, 1:], ref[:, :, 1:]) <= 3e-2, rel_l2(got[:, :, 1:], ref[:, :, 1:])
     t2v = gpu_ctx.denoise(lat0, sig, ltx.f32_to_bf16_bits(ctx), None, F, H, W, **({"cfg_scale": 3.0} if use_cfg else {}))
     assert rel_l2(got[:, :, 1:], t2v[:, :, 1:]) > 1e-2  # conditioning is not a no-op
+
+
+def test_context_cache_keys_do_not_collide_across_modes(ltx, oracle, gpu_ctx, model):
+    """The projected text context is cached under keys derived from the caller's version per pass kind (batched [neg,pos], negative
+    alone, positive alone). A caller that reuses SMALL version numbers across prompts and modes (plain, CFG, CFG+STG) must never be
+    served another prompt's entry: every cached run must equal the same run with ctx_version = 0 (recompute), bit for bit."""
+    import torch
+
+    cfg, ocfg, w = model
+    F, H, W, S = 1, 4, 4, 24
+    rng = np.random.default_rng(77)
+    sig = ltx.sigmas(False, 2, F * H * W)
+
+    def run(ctxs, version, **kw):
+        lat = torch.from_numpy(np.ascontiguousarray(noise * sig[0])).cuda()
+        c = torch.from_numpy(ltx.f32_to_bf16_bits(ctxs).astype(np.int16)).cuda().view(torch.bfloat16)
+        gpu_ctx.denoise_dev(lat, sig, c, None, F, H, W, ctx_version=version, **kw)
+        torch.cuda.synchronize()
+        return lat.cpu().numpy()
+
+    noise = rng.standard_normal((1, 128, F, H, W)).astype(np.float32)
+    prompts = [oracle.bf16_round(rng.standard_normal((2, S, ocfg.caption_channels)).astype(np.float32)) for _ in range(3)]
+    modes = [dict(), dict(cfg_scale=3.0), dict(cfg_scale=3.0, stg_scale=0.7, stg_blocks=(1,)), dict(stg_scale=0.7, stg_blocks=(1,))]
+    want = {}
+    for p, ctxs in enumerate(prompts):
+        for m, kw in enumerate(modes):
+            c = ctxs if "cfg_scale" in kw else ctxs[1:2]
+            want[(p, m)] = run(c, 0, **kw)
+    # now with caching, versions 1..3 reused in an order that would collide under per-mode ad-hoc keys (e.g. 1*4+2 == 6)
+    order = [(0, 2, 1), (1, 0, 6), (2, 1, 1), (0, 0, 2), (1, 2, 2), (2, 3, 6), (0, 1, 6), (1, 1, 1), (2, 0, 5), (1, 3, 1)]
+    for p, m, version in order:
+        kw = modes[m]
+        c = prompts[p] if "cfg_scale" in kw else prompts[p][1:2]
+        got = run(c, version * 16 + p + 1, **kw)   # one version per prompt, small numbers
+        assert np.array_equal(got, want[(p, m)]), (p, m, version)

@@ -12,7 +12,8 @@ Register map (per wave):
   v[48:95]    S buffer A   s[kb][qb] (4 each)    s[36:39]  K buffer descriptor      s[40:43] Vt buffer descriptor
   v[96:143]   S buffer B                         s44 / s45 K / Vt scalar offset of the next tile to stage
   v[144:167]  P fragments  pf[qb][i]             s46       loop counter (groups of 4 tiles)
-  v[168:183]  fragment ring (4 x 4)              s[48:53]  compare masks of the reference check
+  v[168:183]  (free; the fragment ring moved)    s[48:53]  compare masks of the reference check
+  a[108:139]  K / Vt fragment ring (8 x 4): ds_read_b128 lands in AGPRs, the MFMAs read them as the A operand
   v[184:186]  per-lane maxima, v[187:194] rare-path temporaries, v195 floor, v[196:199] bf16 ones
   v[200:211]  -(reference max) per query block (x4: accumulator init of K.Q^T)        a[96:107] row sums l[qb]
   v[212:217]  fragment addresses + 64 KB (ring slots 2, 3)                              s[60:63] O buffer descriptor
@@ -37,7 +38,14 @@ BADDR = 221           # masked variant: LDS address of this lane's bias values o
 STAGE = 32768
 if "--bias" in __import__("sys").argv:
     FLOOR, ONES, NV = 220, 224, 228   # v195..199 belong to the bias values in this variant
-RA = 3  # fragment reads in flight ahead of their MFMAs (ring of 4 fragment registers)
+TM = 168             # v168, v169: temporaries of the ragged-tail mask (the old fragment ring's registers; the masked variant keeps
+                     # its bias values in v[184:199] from the start of a step, so the mask must not use the rare-path temporaries)
+ARING = LACC + 12   # a[108:139]: ring of RN K / Vt fragment registers (LDS reads land in AGPRs, MFMAs take them as their A operand)
+RN = 8
+RA = RN - 1  # fragment reads in flight ahead of their MFMAs. Stamps of the 4-register VGPR ring (RA = 3) showed every K.Q^T fragment
+             # costing ~73 cycles against 48 of MFMA issue: with four waves reading and the LDS-DMA writing, an LDS read takes ~220
+             # cycles to return, so the loop ran at RA reads per latency. Seven in flight cover it; the arch VGPRs have no room for
+             # a deeper ring (v0..v219 + ~36 operands), the accumulator file has 148 registers to spare.
 STAGE_OPS = 8  # LDS-DMA instructions per staged K / Vt tile (4 x 4 KB of K + 4 x 4 KB of Vt); Gen.stage() asserts it
 TILES_AHEAD = 1  # fills that may still be in flight when a step ends: the tile staged in this step (t+3) is first read two steps
                  # later, the one staged a step earlier (t+2) is read by the next step's K.Q^T and must have landed
@@ -87,54 +95,74 @@ class Gen:
         self.lines.append(s)
 
     # ---- fragment reads: slot 0/1 use the operand addresses, slot 2/3 the +64 KB copies ----
+    @staticmethod
+    def ring(i):
+        b = ARING + 4 * (i % RN)
+        return f"a[{b}:{b + 3}]"
+
     def k_read(self, ring, slot, kb, ks):
         addr = f"%[ka{ks}]" if slot < 2 else f"v{HI + ks}"
-        return f"ds_read_b128 {vr(RING + 4 * ring)}, {addr} offset:{(slot & 1) * STAGE + kblock_off(kb)}"
+        return f"ds_read_b128 {self.ring(ring)}, {addr} offset:{(slot & 1) * STAGE + kblock_off(kb)}"
 
     def v_read(self, ring, slot, db, i):
         addr = f"%[va{i}]" if slot < 2 else f"v{HI + 4 + i}"
-        return f"ds_read_b128 {vr(RING + 4 * ring)}, {addr} offset:{(slot & 1) * STAGE + vblock_off(db)}"
+        return f"ds_read_b128 {self.ring(ring)}, {addr} offset:{(slot & 1) * STAGE + vblock_off(db)}"
+
+    def step_stream(self, sbuf, kslot, vslot):
+        """One step's MFMA work as ONE read-ahead pipeline: S(next) = K Q^T from ring slot `kslot` (16 fragments), then O += Vt P from
+        `vslot` (16 fragments). Fragment F lands in ring entry F % RN, its read is issued RA fragments ahead, so the Vt reads start
+        under the last K.Q^T products and the LDS latency is exposed once per step (the first RA reads), not once per stream."""
+        # k-step outer, key block inner: the four k-steps of one key block accumulate into the SAME three S tuples, and with only
+        # three MFMAs between two links of that chain every fragment waited for the previous result (stamps: 75 cycles per fragment
+        # against 48 of issue, 1230 cycles for the 48 products). Twelve MFMAs apart the chain never stalls.
+        kf = [("k", kb, ks) for ks in range(4) for kb in range(4)]
+        vf = [("v", db, i) for i in range(2) for db in range(8)]   # k-step 0 of every d-block first: it only needs pf[.][0]
+        frags = kf + vf
+
+        def read(F):
+            kind, x, y = frags[F]
+            return ("ds", self.k_read(F, kslot, x, y) if kind == "k" else self.v_read(F, vslot, x, y))
+
+        out = [read(F) for F in range(RA)]
+        issued = RA
+        for F, (kind, x, y) in enumerate(frags):
+            out.append(("wait", f"s_waitcnt lgkmcnt({issued - F - 1})"))
+            for qb in range(3):
+                if kind == "k":
+                    d = vr(s_reg(sbuf, x, qb))
+                    c = vr(NMCT[qb]) if y == 0 else d   # scores arrive as q.k - m_ref: the accumulators start at -m_ref
+                    out.append(("mfma", f"v_mfma_f32_16x16x32_bf16 {d}, {self.ring(F)}, {vr(QF + (qb * 4 + y) * 4)}, {c}"))
+                else:
+                    a = f"a[{o_reg(x, qb)}:{o_reg(x, qb) + 3}]"
+                    out.append(("mfma", f"v_mfma_f32_16x16x32_bf16 {a}, {self.ring(F)}, {vr(PF + (qb * 2 + y) * 4)}, {a}"))
+            if F + RA < len(frags):
+                out.append(read(F + RA))
+                issued += 1
+            if kind == "v" and x == 7:  # end of a k-step: the same P against a block of ones = this k-step's row sums
+                for qb in range(3):
+                    a = f"a[{LACC + 4 * qb}:{LACC + 4 * qb + 3}]"
+                    out.append(("mfma", f"v_mfma_f32_16x16x32_bf16 {a}, {vr(ONES)}, {vr(PF + (qb * 2 + y) * 4)}, {a}"))
+        return out
 
     # ---- MFMA streams: list of groups, each group = [pre-instructions..., 3 MFMAs] per fragment ----
     def qk_stream(self, sbuf, slot):
         """S(next) = K Q^T from ring slot `slot` into S buffer `sbuf`. Returns a list of (kind, text); the first RA entries are
         the fragment reads issued ahead."""
         out = []
-        frags = [(kb, ks) for kb in range(4) for ks in range(4)]
+        frags = [(kb, ks) for ks in range(4) for kb in range(4)]   # k-step outer: see step_stream
         issued = 0
         for f in range(min(RA, 16)):
-            out.append(("ds", self.k_read(f % 4, slot, *frags[f])))
+            out.append(("ds", self.k_read(f, slot, *frags[f])))
             issued += 1
         for f, (kb, ks) in enumerate(frags):
             out.append(("wait", f"s_waitcnt lgkmcnt({issued - f - 1})"))
             for qb in range(3):
                 d = vr(s_reg(sbuf, kb, qb))
                 c = vr(NMCT[qb]) if ks == 0 else d   # scores arrive as q.k - m_ref: the accumulators start at -m_ref
-                out.append(("mfma", f"v_mfma_f32_16x16x32_bf16 {d}, {vr(RING + 4 * (f % 4))}, {vr(QF + (qb * 4 + ks) * 4)}, {c}"))
+                out.append(("mfma", f"v_mfma_f32_16x16x32_bf16 {d}, {self.ring(f)}, {vr(QF + (qb * 4 + ks) * 4)}, {c}"))
             if f + RA < 16:
-                out.append(("ds", self.k_read((f + RA) % 4, slot, *frags[f + RA])))
+                out.append(("ds", self.k_read(f + RA, slot, *frags[f + RA])))
                 issued += 1
-        return out
-
-    def pv_stream(self, slot):
-        out = []
-        frags = [(db, i) for i in range(2) for db in range(8)]  # k-step 0 of every d-block first: it only needs pf[.][0]
-        issued = 0
-        for f in range(RA):
-            out.append(("ds", self.v_read(f % 4, slot, *frags[f])))
-            issued += 1
-        for f, (db, i) in enumerate(frags):
-            out.append(("wait", f"s_waitcnt lgkmcnt({issued - f - 1})"))
-            for qb in range(3):
-                a = f"a[{o_reg(db, qb)}:{o_reg(db, qb) + 3}]"
-                out.append(("mfma", f"v_mfma_f32_16x16x32_bf16 {a}, {vr(RING + 4 * (f % 4))}, {vr(PF + (qb * 2 + i) * 4)}, {a}"))
-            if f + RA < 16:
-                out.append(("ds", self.v_read((f + RA) % 4, slot, *frags[f + RA])))
-                issued += 1
-            if db == 7:  # end of a k-step: the same P against a block of ones = this k-step's row sums
-                for qb in range(3):
-                    a = f"a[{LACC + 4 * qb}:{LACC + 4 * qb + 3}]"
-                    out.append(("mfma", f"v_mfma_f32_16x16x32_bf16 {a}, {vr(ONES)}, {vr(PF + (qb * 2 + i) * 4)}, {a}"))
         return out
 
     # ---- softmax of one S buffer (in place) ----
@@ -215,15 +243,15 @@ class Gen:
         e(f"s_cbranch_scc1 {label}f")
         e("s_nop 7")
         e("s_nop 7")
-        e(f"v_mov_b32 v{RT + 1}, 0xff800000")
+        e(f"v_mov_b32 v{TM + 1}, 0xff800000")
         for kb in range(4):
             for j in range(4):
-                e(f"v_and_b32 v{RT}, {1 << (kb * 4 + j)}, %[tmask]")
-                e(f"v_cmp_ne_u32_e64 s[48:49], 0, v{RT}")
+                e(f"v_and_b32 v{TM}, {1 << (kb * 4 + j)}, %[tmask]")
+                e(f"v_cmp_ne_u32_e64 s[48:49], 0, v{TM}")
                 e("s_nop 1")
                 for qb in range(3):
                     r = s_reg(sbuf, kb, qb, j)
-                    e(f"v_cndmask_b32_e64 v{r}, v{r}, v{RT + 1}, s[48:49]")
+                    e(f"v_cndmask_b32_e64 v{r}, v{r}, v{TM + 1}, s[48:49]")
         e(f"{label}:")
 
     def sm_check_and_rare_path(self, label, sbuf, force=False):
@@ -353,22 +381,22 @@ class Gen:
         mul_b = [x for x in vb if x.startswith("v_mul_f32")]
         vb = [x for x in vb if not x.startswith("v_mul_f32")]
         va = va + mul_b
-        qk = self.qk_stream(nxt, (slot + 1) & 3)
-        for kind, text in qk[:RA]:
+        allst = self.step_stream(nxt, (slot + 1) & 3, slot)
+        part_a, rest = self.split_stream(allst, 48)
+        head, tail = self.split_stream(rest, 24)
+        if BIAS:  # bias of tile t+1: its reads come first in the step (older than every fragment read, so the fragment waits cover
+            self.e(f"v_add_u32 v{BADDR}, 256, v{BADDR}")   # them; v184..199 are free here: maxima / rare-path temporaries are dead)
+            for ins in self.bias_reads():
+                self.e(ins)
+            vb = vb + self.bias_add(nxt)
+        for kind, text in part_a[:RA]:
             self.e(text)
         npre = min(6, len(va))
         for ins in va[:npre]:  # independent of the reads just issued: covers part of their latency
             self.e(ins)
-        self.spread(qk[RA:], [[x] for x in va[npre:]], 44)
+        self.spread(part_a[RA:], [[x] for x in va[npre:]], 44)
         self.tail_mask(f"{uid + 10}", nxt, 2)   # S(t+1) is the last, ragged tile
         st(1)
-        pv = self.pv_stream(slot)
-        head, tail = self.split_stream(pv, 24)
-        if BIAS:  # bias of tile t+1: reads first (older than every fragment read of this stream), adds after the exponentials
-            self.e(f"v_add_u32 v{BADDR}, 256, v{BADDR}")
-            for ins in self.bias_reads():
-                self.e(ins)
-            vb = vb + self.bias_add(nxt)
         self.spread(head, [[x] for x in vb], 22)
         st(2)
         dma = [] if "nodma" in ABL else self.stage((slot + 3) & 3)
@@ -589,7 +617,7 @@ def check_wait_coverage(lines, iterations=3):
         if re.match(r"(global_load|buffer_load|global_store|buffer_store)", ins):
             vm.append({"region": None, "state": "inflight", "pos": pos})
             continue
-        mm = re.match(r"ds_read_b128 v\[\d+:\d+\], (\S+) offset:(\d+)", ins) or re.match(r"ds_read_b128 v\[\d+:\d+\], (\S+)$", ins)
+        mm = re.match(r"ds_read_b128 [av]\[\d+:\d+\], (\S+) offset:(\d+)", ins) or re.match(r"ds_read_b128 [av]\[\d+:\d+\], (\S+)$", ins)
         if mm:
             addr = mm.group(1)
             off = int(mm.group(2)) if mm.lastindex == 2 else 0
@@ -674,7 +702,7 @@ def main():
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. gfx950 assembly body of attn_fwd_kernel_w48_asm (attention.hip).\n")
         for ln in lines:
             f.write('"' + ln.replace('"', '\\"') + '\\n\\t"\n')
-    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(LACC + 12)] + [f"s{i}" for i in range(36, 84)] + ["m0", "vcc", "scc", "memory"]
+    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(ARING + 4 * RN)] + [f"s{i}" for i in range(36, 84)] + ["m0", "vcc", "scc", "memory"]
     with open(os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", "attention_w48_bias_clobbers.inc" if BIAS else "attention_w48_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. Registers the assembly body assigns by hand.\n")
         for i in range(0, len(clob), 12):

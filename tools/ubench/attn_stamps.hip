@@ -24,10 +24,21 @@ int main() {
     AttnArgs a;
     a.Q = q; a.ldq = D; a.K = k; a.ldk = D; a.Vt = vt; a.ldvt = T; a.O = o; a.ldo = D;
     a.B = 1; a.H = H; a.Tq = T; a.Tk = T;
+    a.q_prescaled = getenv("ATTN_PS") ? 1 : 0;
 #ifdef W48_STAMPS
     setenv("LTX_ATTN_IMPL", "4", 1);
     for (int it = 0; it < 3; ++it) launch_attention(a, 0);
     hipDeviceSynchronize();
+    {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        for (int it = 0; it < 20; ++it) launch_attention(a, 0);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("T = %d, prescaled %d: %.1f us per launch (stamps build)\n", T, a.q_prescaled, ms * 1000 / 20);
+    }
     {
         unsigned long long st[8][32];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(g_w48_stamps), sizeof(st));
