@@ -160,10 +160,12 @@ def test_context_cache_keys_do_not_collide_across_modes(ltx, oracle, gpu_ctx, mo
         for m, kw in enumerate(modes):
             c = ctxs if "cfg_scale" in kw else ctxs[1:2]
             want[(p, m)] = run(c, 0, **kw)
-    # now with caching, versions 1..3 reused in an order that would collide under per-mode ad-hoc keys (e.g. 1*4+2 == 6)
-    order = [(0, 2, 1), (1, 0, 6), (2, 1, 1), (0, 0, 2), (1, 2, 2), (2, 3, 6), (0, 1, 6), (1, 1, 1), (2, 0, 5), (1, 3, 1)]
-    for p, m, version in order:
+    # now with caching: one small version per prompt, chosen so that ad-hoc per-mode keys (version * 4 + {0, 1, 2} for the CFG / STG
+    # passes, the bare version for the plain pass) WOULD meet: prompt 0 = 1, prompt 1 = 6 = 1 * 4 + 2, prompt 2 = 5 = 1 * 4 + 1
+    versions = [1, 6, 5]
+    order = [(0, 2), (1, 0), (2, 0), (0, 1), (1, 3), (2, 2), (0, 0), (1, 1), (2, 1), (0, 3), (1, 2), (2, 3), (1, 0), (0, 2)]
+    for p, m in order:
         kw = modes[m]
         c = prompts[p] if "cfg_scale" in kw else prompts[p][1:2]
-        got = run(c, version * 16 + p + 1, **kw)   # one version per prompt, small numbers
-        assert np.array_equal(got, want[(p, m)]), (p, m, version)
+        got = run(c, versions[p], **kw)
+        assert np.array_equal(got, want[(p, m)]), (p, m)
