@@ -425,7 +425,8 @@ int ltx_prof_collect(ltx_ctx* ctx, int kind, double* total_ms, long* launches, d
  * pin each one against the oracle; they are not needed by a pipeline caller.
  * ---------------------------------------------------------------------------------------------------------- */
 /* C[M,N] = A[M,K] . B[N,K]^T (+bias[N]) ; act: 0 none, 1 gelu-tanh, 2 silu; tile_cfg: -1 auto, else a forced tile configuration
- * (0,1,3,4: two-stage 4-wave tiles; 21,23,25: 8-wave LDS-ring tiles; 41,42: phased 8-wave tiles; S*100 + ring cfg: the
+ * (0,1,3,4: two-stage 4-wave tiles; 21,23,25: 8-wave LDS-ring tiles; 75: 192x256 one-wave-per-SIMD tile; 41,42,71-74,90
+ * only in the experiments build; S*100 + ring cfg: the
  * same with an S-way deterministic split of the K reduction, as the VAE's 1024-channel convolutions use).
  * Exactly one of out_f32/out_bf16 may be NULL. */
 int ltx_op_gemm_bf16(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb, const float* bias, int M,

@@ -74,7 +74,16 @@ struct GemmArgs {
     float* split_ws = nullptr;
     long split_ws_elems = 0;  // capacity of split_ws in floats (only read when split_k == 0)
     int group_m = 4;  // row-tiles per supertile of the workgroup order (0 = column-major tile order); see tile_coords()
+    // B as affine-quantised codes (experimental weight-streaming kernel only, M <= 128): 8-bit codes [N][K] (one per byte) and bf16 scale / bias
+    // per 64-wide group along K, [N][K/64]; w' = bf16(q * scale + bias). When set, B may be null.
+    const uint8_t* Bq = nullptr;
+    const bf16_t* Bqs = nullptr;
+    const bf16_t* Bqb = nullptr;
 };
+
+// tile_cfg 90 (experiments build only): a weight-streaming kernel for M <= 128 that loads MFMA fragments straight from global memory
+// (bf16 or 8-bit codes de-quantised in registers). Measured 1.4x SLOWER than the ring kernel's split-K path at 128 tokens (its four
+// waves each re-read the activations: 2 bytes of A per byte of W through the vector-memory path) - kept as a measured negative.
 
 // Number of K splits that fills the chip for a launch with few output tiles (1 = do not split). The caller provides
 // split_ws with room for split_k * M * N floats.

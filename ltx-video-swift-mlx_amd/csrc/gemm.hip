@@ -930,6 +930,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
             pk.y = pack_bf16x2(v[2], v[3]);
             *(uint2*)(ep.out_bf16 + m * ep.ld_bf16 + c) = pk;
         }
+        if (ep.out_bf16_t) {  // transposed output (V^T of a few-row launch): 2-byte stores, a few hundred KB in all
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ep.out_bf16_t[(long)(c + e) * ep.ld_bf16_t + m] = f32_to_bf16(v[e]);
+        }
     }
 }
 
@@ -1090,8 +1094,8 @@ void launch_v2(const GemmArgs& a, hipStream_t stream) {
 void validate(const GemmArgs& a) {
     LTX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     LTX_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
-    LTX_REQUIRE(a.A && a.B, "gemm: null operand");
-    LTX_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0, "gemm: operands must be 16-B aligned");
+    LTX_REQUIRE(a.A && (a.B || (a.Bq && a.Bqs && a.Bqb)), "gemm: null operand");
+    LTX_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0 && ((uintptr_t)a.Bq & 15) == 0, "gemm: operands must be 16-B aligned");
     LTX_REQUIRE(a.ldb % 8 == 0, "gemm: ldb=%ld must be a multiple of 8", a.ldb);
     if (a.conv) {
         LTX_REQUIRE(a.geom.kt == 1 || a.geom.kt == 3, "gemm/conv3d: kt=%d", a.geom.kt);
@@ -1149,15 +1153,59 @@ static void launch_dtl(const GemmArgs& a, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
 }
 
+#ifdef LTX_EXPERIMENTS
+bool gemm_stream_takes(const GemmArgs& a) {
+    const GemmEpilogue& e = a.ep;
+    return !a.conv && a.M >= 1 && a.M <= 128 && a.K % 64 == 0 && a.K >= 64 && a.N >= 16 && a.N % 4 == 0 && !e.d2s && a.lda % 8 == 0 &&
+           (a.Bq ? a.ldb % 16 == 0 : a.ldb % 8 == 0);
+}
+// K split of the weight-streaming kernel: aim at one to two workgroups per CU, each wave with >= 4 K-tiles
+static int stream_split_k(const GemmArgs& a) {
+    const int tiles_n = (a.N + 63) / 64, nk = a.K / BK;
+    int s = 1;
+    while (tiles_n * s * 2 <= 512 && nk / (s * 2) >= 16 && s < 8) s *= 2;
+    return s;
+}
+static void launch_stream(const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    LTX_REQUIRE(gemm_stream_takes(a), "gemm: the weight-streaming kernel needs M <= 128, K %% 64 == 0, N %% 4 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
+    if (a.split_k == 0) {  // workspace given, split left to the launcher
+        a.split_k = stream_split_k(a);
+        while (a.split_k > 1 && (long)a.split_k * a.M * a.N > a.split_ws_elems) a.split_k /= 2;
+    }
+    if (a.split_k < 1 || !a.split_ws) a.split_k = 1;
+    constexpr int smem = 4 * 8 * 4 * 64 * 16;  // the four waves' 128 x 64 f32 tiles
+    static PerDeviceOnce attr_set;
+    attr_set.run([&] {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_stream_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_stream_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    });
+    const dim3 grid((a.N + 63) / 64, a.split_k);
+    if (a.Bq)
+        hipLaunchKernelGGL(gemm_stream_kernel<8>, grid, dim3(256), smem, stream, a);
+    else
+        hipLaunchKernelGGL(gemm_stream_kernel<16>, grid, dim3(256), smem, stream, a);
+    HIP_CHECK(hipGetLastError());
+    if (a.split_k > 1) {
+        const long total = (long)a.M * (a.N / 4);
+        const int fgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(fgrid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+        HIP_CHECK(hipGetLastError());
+    }
+}
+
+#endif
+
 void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     if (a.ep.out_bf16_t) {
         const GemmEpilogue& e = a.ep;
-        LTX_REQUIRE(!e.out_f32 && !e.out_bf16 && !e.resid && !e.d2s && !e.bias_m && e.act == LTX_ACT_NONE && !e.round_bf16 && a.split_k <= 1 &&
-                        !a.split_ws && e.ld_bf16_t % 4 == 0 && e.ld_bf16_t >= a.M && cfg < 41,
+        LTX_REQUIRE(!e.out_f32 && !e.out_bf16 && !e.resid && !e.d2s && !e.bias_m && e.act == LTX_ACT_NONE && !e.round_bf16 &&
+                        (cfg == 90 || (a.split_k <= 1 && !a.split_ws)) && e.ld_bf16_t % 4 == 0 && e.ld_bf16_t >= a.M && (cfg < 41 || cfg == 90),
                     "gemm: the transposed bf16 output takes bias_n only, no split-K, ld %% 4 == 0 (ld=%ld M=%d cfg=%d)", e.ld_bf16_t, a.M, cfg);
     }
     validate(a);
-    LTX_REQUIRE(a.split_k <= 1 || (cfg >= 20 && cfg < 30), "gemm: split-K needs a ring kernel (tile cfg %d)", cfg);
+    LTX_REQUIRE(a.split_k <= 1 || (cfg >= 20 && cfg < 30) || cfg == 90, "gemm: split-K needs a ring kernel or the weight-streaming kernel (tile cfg %d)", cfg);
+    LTX_REQUIRE(!a.Bq || cfg == 90, "gemm: quantised codes are read by the weight-streaming kernel only (tile cfg %d)", cfg);
     ProfScope prof(a.conv ? PROF_CONV : PROF_GEMM, 2.0 * a.M * a.N * a.K, stream);
     // cfg 0..2: v1 (2-stage, one barrier + full drain per K-tile); cfg 10..: v2 (ring + counted vmcnt)
     if (a.conv) {
@@ -1182,8 +1230,9 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 22: { GemmArgs b = a; b.group_m = 0; launch_v2<192, 128, 4, false, 4, 2>(b, stream); break; }  // A/B: column-major order
             case 23: launch_v2<256, 128, 3, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
-            case 75: launch_dtl(a, stream); break;  // 192x256, one wave per SIMD, two LDS slots, fragments of a whole K-tile in registers
+            case 75: launch_dtl(a, stream); break;  // 192x256, one wave per SIMD, fragments of a whole K-tile in registers, 2 + 3 LDS slots
 #ifdef LTX_EXPERIMENTS  // measured, not selected (gemm_experiments.inc)
+            case 90: launch_stream(a, stream); break;  // weight-streaming kernel for M <= 128 (bf16 weights or 8-bit codes): 1.4x slower than the ring split-K path
             case 71: launch_asm<256>(a, stream); break;      // one wave per SIMD, assembly main loop, 192x256
             case 72: launch_asm<128>(a, stream); break;      // the same, 192x128
             case 73: launch_asm<128, 1>(a, stream); break;  // 192x128, one wave per SIMD, LDS-DMA ring of four slots
@@ -1245,14 +1294,27 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         launch_gemm_bf16_cfg(a, (cc && a.split_k <= 1) ? atoi(cc) : conv_default, stream);
         return;
     }
+    LTX_REQUIRE(!a.Bq, "gemm: quantised codes are only read by the experimental weight-streaming kernel");
     if (a.split_ws && a.split_k == 0) {
         // caller-provided workspace, split count left to the launcher: few output tiles and a long reduction (the DiT at
         // small token counts, e.g. 256x256x9 -> 128 tokens: 32 tiles of weights to stream with 256 CUs) -> split K over the idle CUs
         GemmArgs b = a;
         b.split_k = gemm_suggest_split_k(a.M, a.N, a.K);
+        // few rows (<= 128, e.g. 256x256x9): the 128x192 ring tile stages 16 KB of activations per 24 KB of weights and K-tile,
+        // the 192x128 one 24 KB (a third of them padding rows) per 16 KB
+        static const int smallm_cfg = getenv("LTX_SMALLM_CFG") ? atoi(getenv("LTX_SMALLM_CFG")) : 25;
+        const int cfg = (a.M <= 128 && b.split_k > 1) ? smallm_cfg : 21;
+        if (cfg == 25) {
+            const long tiles = (long)((a.N + 191) / 192);
+            long sk = 256 / tiles;
+            const int nk = a.K / BK;
+            if (sk > 16) sk = 16;
+            if (sk > nk / 8) sk = nk / 8;
+            b.split_k = sk < 1 ? 1 : (int)sk;
+        }
         while (b.split_k > 1 && (long)b.split_k * a.M * a.N > a.split_ws_elems) --b.split_k;
         if (b.split_k > 1 && a.N % 4 == 0 && !a.ep.d2s) {
-            launch_gemm_bf16_cfg(b, 21, stream);
+            launch_gemm_bf16_cfg(b, cfg, stream);
             return;
         }
         b.split_k = 1;

@@ -14,11 +14,11 @@ inline void gemm_linear(const bf16_t* A, long lda, const LinearW& w, int M, Gemm
     GemmArgs g;
     g.A = A;
     g.lda = lda;
-    g.B = dit_linear_weights(w, s);
     g.ldb = w.in;
     g.M = M;
     g.N = w.out;
     g.K = w.in;
+    g.B = dit_linear_weights(w, s);
     if (!ep.bias_n && !ep.bias_m) ep.bias_n = w.b;
     g.ep = ep;
     if (ws.p) {

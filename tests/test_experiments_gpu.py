@@ -107,3 +107,23 @@ def test_attention_layout_reference_kernel(gpu_ctx, monkeypatch):
     got = as_f32(o)
     for h in range(H):
         assert np.abs(got[0, :, h * 128:(h + 1) * 128] - v[0, sel[h], h * 128:(h + 1) * 128]).max() <= 1e-2
+
+
+@pytest.mark.parametrize("M,N,K,split", [(128, 64, 64, 1), (128, 4096, 4096, 1), (128, 4096, 4096, 4), (77, 200, 1024, 2), (1, 64, 256, 1),
+                                         (128, 8192, 4096, 2), (33, 1000, 16384, 8), (128, 128, 320, 1), (100, 4096, 128, 1)])
+def test_gemm_weight_streaming_kernel_integer_exact(gpu_ctx, M, N, K, split):
+    """tile_cfg 90: 128 x 64 tile, the four waves split the K-tiles and read their fragments straight from global memory in a
+    permuted k order (16 consecutive k per lane), partial tiles summed through LDS in wave order, K split over workgroups through
+    the workspace. Bit-exact on integer data for ragged M / N, 1 ... 256 K-tiles (waves with 0, 1, odd and even tile counts), with
+    bias, f32 + bf16 outputs."""
+    rng = np.random.default_rng(M + N + K + split)
+    A = rng.integers(-3, 4, (M, K)).astype(np.float32)
+    B = rng.integers(-3, 4, (N, K)).astype(np.float32)
+    bias = rng.integers(-5, 6, (N,)).astype(np.float32)
+    out = torch.empty((M, N), device="cuda")
+    outb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_gemm(dev_bf16(A), dev_bf16(B), dev_f32(bias), tile_cfg=(split * 100 if split > 1 else 0) + 90, out_f32=out, out_bf16=outb)
+    torch.cuda.synchronize()
+    ref = A @ B.T + bias
+    assert np.array_equal(as_f32(out), ref), f"{np.count_nonzero(as_f32(out) != ref)} wrong"
+    assert np.array_equal(as_f32(outb), torch.from_numpy(ref).to(torch.bfloat16).float().numpy())
