@@ -108,6 +108,72 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(const float* __restrict__
     }
 }
 
+// R rows per workgroup (RMS norm, D = NV * 1024 exactly, rows of one batch element): the modulation vectors are the same for every
+// row of a batch element, and one workgroup per row re-read their 2 x 4 D bytes from L2 for each row - twice the bytes of the row
+// itself. Here they are fetched once per R rows, all R rows are loaded before the first reduction (one memory latency per
+// workgroup, as before), and the R sums of squares share one barrier pair.
+template <int NV, int R>
+__global__ __launch_bounds__(256) void norm_mod_rows_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, long mod_bstride, int rows_per_batch,
+                                                            bf16_t* __restrict__ out, long ldo, int rows, float eps, int round_norm_bf16) {
+    __shared__ float red[4][R];
+    const int row0 = blockIdx.x * R;
+    const long b = row0 / rows_per_batch;   // the launcher guarantees that the R rows do not straddle a batch element
+    const float* sc = scale + b * mod_bstride;
+    const float* sh = shift + b * mod_bstride;
+    constexpr int D = NV * 1024;
+    f32x4 v[R][NV], s4[NV], h4[NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = (row0 + r) < rows ? (row0 + r) : rows - 1;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[r][j] = *(const f32x4*)(x + (long)row * ldx + (threadIdx.x + j * 256) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        s4[j] = *(const f32x4*)(sc + (threadIdx.x + j * 256) * 4);
+        h4[j] = *(const f32x4*)(sh + (threadIdx.x + j * 256) * 4);
+    }
+    float ss[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a += v[r][j][e] * v[r][j][e];
+        ss[r] = wave_reduce_sum(a);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) red[w][r] = ss[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (row0 + r >= rows) break;
+        // same summation order as norm_mod_kernel's block_reduce_sum: wave sums added in wave order
+        const float ms = (red[0][r] + red[1][r] + red[2][r] + red[3][r]) / (float)D;
+        const float rstd = rsqrtf(ms + eps);
+        bf16_t* orow = out + (long)(row0 + r) * ldo;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = v[r][j][e] * rstd;
+                if (round_norm_bf16) y[e] = bf16_to_f32(f32_to_bf16(y[e]));
+                y[e] = y[e] * (1.0f + s4[j][e]) + h4[j][e];
+            }
+            uint2 pk;
+            pk.x = pack_bf16x2(y[0], y[1]);
+            pk.y = pack_bf16x2(y[2], y[3]);
+            *(uint2*)(orow + (threadIdx.x + j * 256) * 4) = pk;
+        }
+    }
+}
+
 // one workgroup per row; thread handles float4 chunks of the first half `a` of a head and the matching `b` chunk.
 // blockIdx.y selects the job (q or k of the fused projection): one launch normalises and rotates both. The weight and
 // cos/sin chunks are fetched with the row, before the reduction (same reason as norm_mod_kernel).
@@ -551,6 +617,13 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
     LTX_REQUIRE((scale == nullptr) == (shift == nullptr), "norm_mod: scale/shift must both be set or both null");
     const int rpb = rows_per_batch < 1 ? 1 : rows_per_batch;
     ProfScope prof(PROF_ELEM, (double)rows * D * (4 + 2), stream);  // algorithmic bytes: f32 row in, bf16 row out
+    constexpr int R = 4;
+    if (norm_kind == LTX_NORM_RMS && scale && !row_map && D == 4096 && rows >= 512 && rpb % R == 0) {
+        hipLaunchKernelGGL((norm_mod_rows_kernel<4, R>), dim3((rows + R - 1) / R), dim3(256), 0, stream, x, ldx, scale, shift, mod_bstride, rpb, out, ldo,
+                           rows, eps, round_norm_bf16);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
 #define LTX_NORM_LAUNCH(NV)                                                                                              \
     hipLaunchKernelGGL(norm_mod_kernel<NV>, dim3(rows), dim3(256), 0, stream, x, ldx, scale, shift, mod_bstride, rpb, out, \
                        ldo, D, norm_kind, eps, round_norm_bf16, row_map)
@@ -562,6 +635,102 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
     HIP_CHECK(hipGetLastError());
 }
 
+// R rows per workgroup of qknorm_rope_kernel (D = 4096): the norm weights are fetched once per R rows instead of once per row
+// (they are as many bytes as a row), every row is loaded before the first reduction, the R sums share one barrier pair.
+template <int R>
+__global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(QkJob j0, QkJob j1, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                               int T, int rows, float eps) {
+    constexpr int NP = 2, D = 4096;
+    __shared__ float red[4][R];
+    const QkJob job = blockIdx.y ? j1 : j0;
+    const int row0 = blockIdx.x * R;
+    f32x4 va[R][NP], vb[R][NP], wa[NP], wb[NP];
+    int col[NP], fc[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int p = threadIdx.x + j * 256;
+        col[j] = (p >> 4) * 128 + (p & 15) * 4;
+        fc[j] = (p >> 4) * 64 + (p & 15) * 4;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = (row0 + r) < rows ? (row0 + r) : rows - 1;
+        const float* xr = job.x + (long)row * job.ldx;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            va[r][j] = *(const f32x4*)(xr + col[j]);
+            vb[r][j] = *(const f32x4*)(xr + col[j] + 64);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        wa[j] = *(const f32x4*)(job.w + col[j]);
+        wb[j] = *(const f32x4*)(job.w + col[j] + 64);
+    }
+    // the table rows too, before the reduction: a dependent load behind the barrier costs a second memory latency per workgroup
+    f32x4 c4[R][NP], s4[R][NP];
+    if (cosT) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = (row0 + r) < rows ? (row0 + r) : rows - 1;
+            const long tb = (long)(row % T) * (D >> 1);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                c4[r][j] = *(const f32x4*)(cosT + tb + fc[j]);
+                s4[r][j] = *(const f32x4*)(sinT + tb + fc[j]);
+            }
+        }
+    }
+    float ss[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a += va[r][j][e] * va[r][j][e] + vb[r][j][e] * vb[r][j][e];
+        ss[r] = wave_reduce_sum(a);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) red[w][r] = ss[r];
+    }
+    __syncthreads();
+    const float osc = job.out_scale;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        if (row >= rows) break;
+        const float rstd = rsqrtf((red[0][r] + red[1][r] + red[2][r] + red[3][r]) / (float)D + eps);
+        bf16_t* orow = job.out + (long)row * job.ldo;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            f32x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = va[r][j][e] * rstd * wa[j][e];
+                b[e] = vb[r][j][e] * rstd * wb[j][e];
+            }
+            if (cosT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = a[e], b0 = b[e];
+                    a[e] = a0 * c4[r][j][e] - b0 * s4[r][j][e];
+                    b[e] = b0 * c4[r][j][e] + a0 * s4[r][j][e];
+                }
+            }
+            uint2 pa, pb;
+            pa.x = pack_bf16x2(a[0] * osc, a[1] * osc);
+            pa.y = pack_bf16x2(a[2] * osc, a[3] * osc);
+            pb.x = pack_bf16x2(b[0] * osc, b[1] * osc);
+            pb.y = pack_bf16x2(b[2] * osc, b[3] * osc);
+            *(uint2*)(orow + col[j]) = pa;
+            *(uint2*)(orow + col[j] + 64) = pb;
+        }
+    }
+}
+
 void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const float* x1, const float* w1, bf16_t* out1,
                          long ldx, long ldo, const float* cosT, const float* sinT, int T, int rows, int D, float eps,
                          hipStream_t stream, float out_scale0) {
@@ -571,6 +740,12 @@ void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const f
     ProfScope prof(PROF_ELEM, (double)rows * D * (x1 ? 2 : 1) * (4 + 2 + (cosT ? 4 : 0)), stream);
     const dim3 grid(rows, x1 ? 2 : 1);
     const int t = T < 1 ? 1 : T;
+    if (D == 4096 && rows >= 512) {   // the DiT at full width: R rows per workgroup share one fetch of the norm weights
+        constexpr int R = 2;
+        hipLaunchKernelGGL(qknorm_rope_rows_kernel<R>, dim3((rows + R - 1) / R, x1 ? 2 : 1), dim3(256), 0, stream, j0, j1, cosT, sinT, t, rows, eps);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (D <= 2048) hipLaunchKernelGGL(qknorm_rope_kernel<1>, grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
     else if (D <= 4096) hipLaunchKernelGGL(qknorm_rope_kernel<2>, grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
     else hipLaunchKernelGGL(qknorm_rope_kernel<4>, grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
