@@ -500,11 +500,9 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             e2.gate_bstride = mod_bs;
             e2.rows_per_batch = T;
             e2.gate_rowmap = rmap;
-            e2.out_bf16 = xb;
-            e2.ld_bf16 = D;
+            // no bf16 mirror here: the next reader of xb is a cross-attention q projection, and by then either this block's successor has
+            // rewritten it (attention-out epilogue) or, when that block skips self-attention, the cast above has
             gemm_linear(ffh, 4 * D, blk.ff2, (int)rows, e2, st, sk);
-        } else {
-            launch_cast_f32_bf16(x, xb, rows * D, st);
         }
     }
     // 6. output head: LayerNorm (no affine) * (1+scale) + shift -> proj_out (LTXTransformer.swift:208-224)
