@@ -600,8 +600,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     const int pch = lane & 7;
     const bf16_t* a_src[A_PER_WAVE];
     const bf16_t* b_src[B_PER_WAVE];
-    RowPos a_pos[A_PER_WAVE];
     int a_lch[A_PER_WAVE];
+    // conv mode, separable tap tables: the voxel index of tap (dt, dy, dx) of a row is tf[dt] + ty[dy] + tx[dx] with the padding
+    // rule (reflect / clamp / replicate) already applied per axis, and `bad` has one bit per (axis, tap index) that falls into ZERO
+    // padding (those taps read the zero voxel behind the tensor). Built once per tile, branch-free; a tap change then costs a few
+    // selects and adds per row instead of re-deriving the neighbour from (f, y, x) (the 128-channel convs change tap every second
+    // K-tile).
+    struct TapTab {
+        int f0, f1, f2, y0, y1, y2, x0, x1, x2, bad;
+    };
+    TapTab a_tab[A_PER_WAVE];
+    const bf16_t* a_row0[A_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < A_PER_WAVE; ++i) {
         const int row = (wave + NW * i) * 8 + srow;
@@ -610,12 +619,34 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         gm = gm < g.M ? gm : g.M - 1;
         a_lch[i] = lch;
         if constexpr (CONV) {
-            const int hw = g.geom.H * g.geom.W;
-            a_pos[i].f = gm / hw;
-            const int rem = gm - a_pos[i].f * hw;
-            a_pos[i].y = rem / g.geom.W;
-            a_pos[i].x = rem - a_pos[i].y * g.geom.W;
+            const int F = g.geom.F, H = g.geom.H, W = g.geom.W, hw = H * W;
+            const int pf = gm / hw;
+            const int rem = gm - pf * hw;
+            const int py = rem / W;
+            const int px = rem - py * W;
             a_src[i] = g.A;
+            a_row0[i] = g.A + lch * 8;
+            const bool zero_t = g.geom.pad_mode == 1;
+            const bool zero_hw = g.geom.pad_mode == 1 || g.geom.pad_mode == 3;
+            const bool refl_hw = g.geom.pad_mode == 0;
+            int bad = 0;
+            auto axis_t = [&](int d) {
+                const int fi = g.geom.causal ? (pf + d - 2) : (pf + d - 1);
+                const bool out = fi < 0 || fi >= F;
+                bad |= (zero_t && out) ? (1 << d) : 0;
+                return clamp_idx(fi, F) * hw;
+            };
+            auto axis_s = [&](int p, int n, int d, int bit) {
+                const int v = p + d - 1;
+                const bool out = v < 0 || v >= n;
+                bad |= (zero_hw && out) ? (bit << d) : 0;
+                return refl_hw ? reflect_idx(v, n) : clamp_idx(v, n);
+            };
+            TapTab& t = a_tab[i];
+            t.f0 = axis_t(0); t.f1 = axis_t(1); t.f2 = axis_t(2);
+            t.y0 = axis_s(py, H, 0, 8) * W; t.y1 = axis_s(py, H, 1, 8) * W; t.y2 = axis_s(py, H, 2, 8) * W;
+            t.x0 = axis_s(px, W, 0, 64); t.x1 = axis_s(px, W, 1, 64); t.x2 = axis_s(px, W, 2, 64);
+            t.bad = bad;
         } else {
             a_src[i] = g.A + (long)gm * g.lda + lch * 8;
         }
@@ -638,31 +669,36 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
 
     // conv mode: the gathered source pointers only change when the 3x3x3 tap changes (every C/64 K-tiles); inside a
     // tap they just advance by one K-tile. K-tiles are staged in increasing order, so the pointers are loop state.
+    int a_fy[A_PER_WAVE];  // tf[dt] + ty[dy] of the current (dt, dy): changes every third tap
+    int fy_of = -1;        // tap / 3 that a_fy belongs to
     auto conv_tap_ptrs = [&](int tap) {
         const int dt = (g.geom.kt == 3) ? tap / 9 : 1;
         const int t9 = (g.geom.kt == 3) ? tap - dt * 9 : tap;
         const int dy = t9 / 3, dx = t9 - dy * 3;
+        // uniform all-ones / zero masks instead of `dt == 0 ? f0 : ...`: the compiler turns such a chain over struct fields into an
+        // indexed scratch array (a scratch load + vmcnt(0) in the middle of the ring's counted waits)
+        if (tap / 3 != fy_of) {
+            fy_of = tap / 3;
+            const int mt1 = -(dt == 1), mt2 = -(dt == 2), my1 = -(dy == 1), my2 = -(dy == 2);
+#pragma unroll
+            for (int i = 0; i < A_PER_WAVE; ++i) {
+                const TapTab& t = a_tab[i];
+                a_fy[i] = t.f0 + t.y0 + (((t.f1 - t.f0) & mt1) + ((t.f2 - t.f0) & mt2)) + (((t.y1 - t.y0) & my1) + ((t.y2 - t.y0) & my2));
+            }
+        }
+        const int mx1 = -(dx == 1), mx2 = -(dx == 2);
+        const int mask = (1 << dt) | (8 << dy) | (64 << dx);
+        const int zero_vox = g.geom.F * g.geom.H * g.geom.W;  // the zero voxel the caller keeps behind the tensor
+        const bool zero_pad = g.geom.pad_mode == 1 || g.geom.pad_mode == 3;
 #pragma unroll
         for (int i = 0; i < A_PER_WAVE; ++i) {
-            int fi = g.geom.causal ? (a_pos[i].f + dt - 2) : (a_pos[i].f + dt - 1);
-            int yi = a_pos[i].y + dy - 1, xi = a_pos[i].x + dx - 1;
-            long pos;
-            if (g.geom.pad_mode == 1 || g.geom.pad_mode == 3) {
-                if (g.geom.pad_mode == 3) fi = clamp_idx(fi, g.geom.F);  // zeros in H/W, replicated frames in T
-                const bool ok = fi >= 0 && fi < g.geom.F && yi >= 0 && yi < g.geom.H && xi >= 0 && xi < g.geom.W;
-                pos = ok ? ((long)fi * g.geom.H + yi) * g.geom.W + xi : (long)g.geom.F * g.geom.H * g.geom.W;
-            } else {
-                fi = clamp_idx(fi, g.geom.F);
-                if (g.geom.pad_mode == 0) {
-                    yi = reflect_idx(yi, g.geom.H);
-                    xi = reflect_idx(xi, g.geom.W);
-                } else {
-                    yi = clamp_idx(yi, g.geom.H);
-                    xi = clamp_idx(xi, g.geom.W);
-                }
-                pos = ((long)fi * g.geom.H + yi) * g.geom.W + xi;
+            const TapTab& t = a_tab[i];
+            int vox = a_fy[i] + t.x0 + (((t.x1 - t.x0) & mx1) + ((t.x2 - t.x0) & mx2));
+            if (zero_pad) {
+                const int hit = -(int)((t.bad & mask) != 0);
+                vox = (zero_vox & hit) | (vox & ~hit);
             }
-            a_src[i] = g.A + pos * g.geom.C + a_lch[i] * 8;
+            a_src[i] = a_row0[i] + (long)vox * g.geom.C;
         }
     };
     int conv_tap = kt0 / cpt, conv_cc = kt0 - conv_tap * cpt;  // position of the NEXT K-tile to stage
