@@ -94,7 +94,20 @@ LTX_DEVFN float gelu_tanh(float x) {
     // far inside the bf16 rounding of the stored value; exp overflow for very negative u gives x / inf = -0, the correct limit.
     return __fdividef(x, 1.0f + __expf(-2.0f * u));
 }
-LTX_DEVFN float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with one v_exp_f32 and one v_rcp_f32 (relative error ~2e-7, far inside the bf16 rounding of every stored value); the
+// IEEE division it replaces is a ten-instruction sequence that the conv epilogues run per element on the SIMDs that issue the MFMAs
+LTX_DEVFN float silu_f(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
+
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: four row rotations, no LDS crossbar
+LTX_DEVFN float row16_allsum(float v) {
+#define LTX_ROW_ROR_ADD(N) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (N), 0xf, 0xf, false))
+    LTX_ROW_ROR_ADD(8);
+    LTX_ROW_ROR_ADD(4);
+    LTX_ROW_ROR_ADD(2);
+    LTX_ROW_ROR_ADD(1);
+#undef LTX_ROW_ROR_ADD
+    return v;
+}
 
 // Bijective XCD-aware remap of a linear workgroup id (guide T1): blocks b and b+8 share an XCD under
 // round-robin dispatch, so give each XCD a contiguous chunk of the tile grid. Speed only.

@@ -42,9 +42,14 @@ struct GemmEpilogue {
     // (VideoDecoder.swift:201-251); 2: per-frame pixel shuffle (1,2,2) of the latent upscaler
     // (SpatialUpscaler.swift:116-131). Conv output channels are stored sub-position-major (permuted at load).
     int d2s = 0;
-    // cache policy of the interior-column epilogue's output stores: 0 plain (write-back: dirty lines are flushed at the kernel
-    // boundary), 16 = sc1 (write-through), 2 = nt. A/B knob (LTX_GEMM_STORE_AUX); see DESIGN.md section 4.
-    int store_aux = 0;
+    // fused PixelNorm + SiLU second output of a conv launch whose ONE column tile holds every channel (N == the tile's 128 columns):
+    // pn_out[m][n] = bf16(silu(v[m][n] / sqrt(mean_n(v[m][:]^2) + 1e-8) * pn_scale[n] + pn_shift[n])), v = the value the f32 output
+    // gets (after bias and residual). The VAE's 128-channel stage: the next conv's input without a pass over the f32 stream
+    // (vaePixelNorm + modulation + SiLU: VideoDecoder.swift:29-32,93-113). out_f32 may be null (the res-block's inner conv).
+    bf16_t* pn_out = nullptr;
+    long ld_pn = 0;
+    const float* pn_scale = nullptr;  // [N], the "1 + scale" row of the block's modulation table
+    const float* pn_shift = nullptr;  // [N]
 };
 
 // Geometry of an implicit-GEMM conv3d A operand: x is [F][H][W][C] bf16 (channels-last), 3x3x3 taps,

@@ -113,7 +113,9 @@ LTX_DEVFN void gemm_residual_prefetch(const GemmArgs& g, int m0, int n0, int wr,
     rt.valid = true;
 }
 
-template <int BM, int BN, int WGM = 2, int WGN = 2, class Get>
+// PN: the fused PixelNorm + SiLU second output (GemmEpilogue::pn_out) is compiled in (conv instantiations only: it adds a
+// workgroup barrier per 16-row slab and registers the dense kernels' epilogues do not have to spare).
+template <int BM, int BN, int WGM = 2, int WGN = 2, bool PN = false, class Get>
 LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, int wr, int wc, int lane, int wave, char* smem,
                                   const ResidualTile<BM, BN, WGM, WGN>* pre = nullptr) {
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
@@ -200,6 +202,18 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
             }
         };
         prefetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        // fused PixelNorm: the two waves of a tile row-block (wc = 0 / 1) each hold 64 of a row's 128 channels; they trade their
+        // partial sums of squares through LDS, double-buffered by slab parity so that one barrier per slab is enough
+        const bool pn = PN && ep.pn_out != nullptr;  // workgroup-uniform
+        float* pns = (float*)(smem + WGM * WGN * (16 * WN * 4));  // [2][waves][16 rows], behind the transpose scratch
+        f32x4 pn_s4 = f32x4{1.f, 1.f, 1.f, 1.f}, pn_h4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PN) {
+            static_assert(WGN == 2 && LPR == 16, "fused PixelNorm: two waves per tile row, 16 lanes per 64-column half row");
+            if (pn && ep.pn_scale) {
+                pn_s4 = *(const f32x4*)(ep.pn_scale + gn_w + (lane % LPR) * 4);
+                pn_h4 = *(const f32x4*)(ep.pn_shift + gn_w + (lane % LPR) * 4);
+            }
+        }
         static_for<0, MI>([&](auto mi_c) {
             constexpr int mi = decltype(mi_c)::value;
             constexpr int buf = mi & 1;
@@ -211,6 +225,8 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = slab[ni][r];
             });
+            f32x4 pn_v[PN ? NIT : 1];
+            float pn_s2[PN ? NIT : 1];
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int chunk = it * 64 + lane;
@@ -247,16 +263,42 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
                     uint2 pk;
                     pk.x = pack_bf16x2(v[0], v[1]);
                     pk.y = pack_bf16x2(v[2], v[3]);
-                    if (ep.store_aux == 16) {
-                        // write-through: the bytes leave L2 as they are produced instead of in one flush at the kernel boundary
-                        if (ep.out_f32) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ep.out_f32 + (long)gm * ep.ld_f32 + gn_w + c4), "v"(v) : "memory");
-                        if (ep.out_bf16) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn_w + c4), "v"(pk) : "memory");
-                    } else if (ep.store_aux == 2) {
-                        if (ep.out_f32) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ep.out_f32 + (long)gm * ep.ld_f32 + gn_w + c4), "v"(v) : "memory");
-                        if (ep.out_bf16) asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 1" ::"v"(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn_w + c4), "v"(pk) : "memory");
-                    } else {
-                        if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn_w + c4) = v;
-                        if (ep.out_bf16) *(uint2*)(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn_w + c4) = pk;
+                    if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn_w + c4) = v;
+                    if (ep.out_bf16) *(uint2*)(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn_w + c4) = pk;
+                }
+                if constexpr (PN) {
+                    if (pn) {
+                        pn_v[it] = v;
+                        pn_s2[it] = row16_allsum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);  // this wave's 64 channels of row it*4 + lane/16
+                    }
+                }
+            }
+            if constexpr (PN) {
+                if (pn) {
+                    float* mine = pns + (buf * WGM * WGN + wave) * 16;
+                    const float* other = pns + (buf * WGM * WGN + (wave ^ 1)) * 16;
+                    if ((lane & (LPR - 1)) == 0) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) mine[it * (64 / LPR) + (lane / LPR)] = pn_s2[it];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int chunk = it * 64 + lane;
+                        const int row = chunk / LPR;
+                        const int c4 = (chunk % LPR) * 4;
+                        const int gm = m0 + wr * WM + mi * 16 + row;
+                        const float tot = pn_s2[it] + other[row];
+                        const float inv = __builtin_amdgcn_rsqf(tot * (1.0f / (float)BN) + 1e-8f);
+                        f32x4 y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = silu_f(pn_v[it][e] * inv * pn_s4[e] + pn_h4[e]);
+                        if (gm < g.M) {
+                            uint2 pk;
+                            pk.x = pack_bf16x2(y[0], y[1]);
+                            pk.y = pack_bf16x2(y[2], y[3]);
+                            *(uint2*)(ep.pn_out + (long)gm * ep.ld_pn + gn_w + c4) = pk;
+                        }
                     }
                 }
             }
@@ -378,11 +420,11 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
     });
 }
 
-template <int BM, int BN, int WGM = 2, int WGN = 2>
+template <int BM, int BN, int WGM = 2, int WGN = 2, bool PN = false>
 LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const GemmArgs& g, int m0, int n0, int wr, int wc,
                              int lane, int wave, char* smem, const ResidualTile<BM, BN, WGM, WGN>* pre = nullptr) {
     constexpr int NI = BN / WGN / 16;
-    gemm_epilogue_with<BM, BN, WGM, WGN>(
+    gemm_epilogue_with<BM, BN, WGM, WGN, PN>(
         [&](auto mi_c, f32x4(&slab)[NI]) {
             constexpr int mi = decltype(mi_c)::value;
 #pragma unroll
@@ -843,9 +885,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         // MFMAs of the last PD-1 K-tiles, instead of at the top of the epilogue
         if (!g.ep.d2s && g.split_k <= 1 && n0 + BN <= g.N && kt < nk) {
             gemm_bias_prefetch<BM, BN, WGM, WGN>(g, n0, wc, lane, rt);
-            if constexpr (!CONV) {
-                if (g.ep.resid) gemm_residual_prefetch<BM, BN, WGM, WGN>(g, m0, n0, wr, wc, lane, rt);
-            }
+            if (g.ep.resid) gemm_residual_prefetch<BM, BN, WGM, WGN>(g, m0, n0, wr, wc, lane, rt);
         }
     }
     for (; kt < nk; ++kt) ktile(kt, std::false_type{});
@@ -861,7 +901,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         gemm_epilogue<BM, BN, WGM, WGN>(acc, gs, m0, n0, wr, wc, lane, wave, smem);
         return;
     }
-    gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem, &rt);
+    gemm_epilogue<BM, BN, WGM, WGN, (CONV && BN == 128 && WGN == 2)>(acc, g, m0, n0, wr, wc, lane, wave, smem, &rt);
 #ifdef GEMM_V2_STAMPS
     {
         const unsigned long long st3 = wall_clock64();
@@ -1142,7 +1182,8 @@ void validate(const GemmArgs& a) {
         LTX_REQUIRE(a.lda % 8 == 0, "gemm: lda=%ld must be a multiple of 8", a.lda);
     }
     const GemmEpilogue& e = a.ep;
-    LTX_REQUIRE(e.out_f32 || e.out_bf16 || e.out_bf16_t, "gemm: no output");
+    LTX_REQUIRE(e.out_f32 || e.out_bf16 || e.out_bf16_t || e.pn_out, "gemm: no output");
+    if (e.pn_out) LTX_REQUIRE(e.ld_pn % 4 == 0 && ((uintptr_t)e.pn_out & 7) == 0, "gemm: PixelNorm output alignment");
     if (e.out_f32) LTX_REQUIRE(e.ld_f32 % 4 == 0 && ((uintptr_t)e.out_f32 & 15) == 0, "gemm: f32 output alignment");
     if (e.out_bf16) LTX_REQUIRE(e.ld_bf16 % 4 == 0 && ((uintptr_t)e.out_bf16 & 7) == 0, "gemm: bf16 output alignment");
     if (e.resid && !e.d2s) LTX_REQUIRE(e.out_f32 || e.resid_src, "gemm: residual mode needs an f32 stream");
@@ -1294,8 +1335,6 @@ int gemm_suggest_split_k(int M, int N, int K) {
 void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     // A/B hook: LTX_GEMM_GROUP_M="N:g,..." overrides the supertile height of dense launches with that N (tile_coords)
     GemmArgs a = a_in;
-    static const int store_aux = getenv("LTX_GEMM_STORE_AUX") ? atoi(getenv("LTX_GEMM_STORE_AUX")) : 0;
-    if (!a.conv && !a.ep.store_aux) a.ep.store_aux = store_aux;
     if (const char* f = getenv("LTX_GEMM_GROUP_M")) {
         for (const char* q = f; *q;) {
             const long n = strtol(q, (char**)&q, 10);
@@ -1327,9 +1366,17 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         const char* cc = getenv("LTX_CONV_CFG");  // A/B hook for tile experiments (21 = 192x128 ring, 23 = 256x128 ring)
         // N <= 64 (the decoder's conv_out, 128 -> 48 channels): a 192x128 tile spends 62 % of its MFMAs on padding columns
         const int conv_default = (a.N <= 64 && a.split_k <= 1) ? 27 : 21;
+        if (a.ep.pn_out) {
+            // the fused PixelNorm output needs every channel of a row in ONE 128-column tile and the epilogue in the GEMM launch
+            LTX_REQUIRE(a.N == 128 && a.split_k <= 1 && !a.ep.d2s && (a.ep.pn_scale == nullptr) == (a.ep.pn_shift == nullptr),
+                        "gemm: fused PixelNorm output needs N == 128 (got %d), no split-K and no depth-to-space store", a.N);
+            launch_gemm_bf16_cfg(a, 21, stream);
+            return;
+        }
         launch_gemm_bf16_cfg(a, (cc && a.split_k <= 1) ? atoi(cc) : conv_default, stream);
         return;
     }
+    LTX_REQUIRE(!a.ep.pn_out, "gemm: the fused PixelNorm output exists for conv launches only");
     LTX_REQUIRE(!a.Bq, "gemm: quantised codes are only read by the experimental weight-streaming kernel");
     if (a.split_ws && a.split_k == 0) {
         // caller-provided workspace, split count left to the launcher: few output tiles and a long reduction (the DiT at

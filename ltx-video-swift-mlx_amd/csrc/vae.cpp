@@ -299,49 +299,84 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
     }
     float* x = xa;
     float* xo = xb;
+    // Stages whose channels fit one 128-column GEMM tile (the last, most expensive one) never run a PixelNorm pass: each conv's
+    // epilogue also emits the NEXT conv's input, PixelNorm + modulation + SiLU of the value it just produced, into the other of
+    // two bf16 buffers (the conv reads one while it writes the other). Wider stages keep the separate row pass.
+    bf16_t* hb2 = m->hb2.as<bf16_t>();
+    const int C3 = m->channels[3];
     for (int g = 0; g < 4; ++g) {
         const int C = m->groups[g].C;
+        const bool fuse = C == 128 && hb2 != nullptr;
+        bf16_t* hin = hb;   // the next conv's input
+        bf16_t* hout = hb2;
         for (int r = 0; r < 5; ++r) {
             const VaeResBlock& rb = m->groups[g].blocks[r];
             const float* md = mods + mod_ofs_group[g] + (long)r * 4 * C;
-            launch_pixelnorm_silu(x, md + 1 * C, md + 0 * C, hb, d.P(), C, st);
+            if (!fuse || r == 0) launch_pixelnorm_silu(x, md + 1 * C, md + 0 * C, hin, d.P(), C, st);
             GemmEpilogue e1;
-            e1.out_f32 = t1;
-            e1.ld_f32 = C;
-            conv3d(hb, d, rb.conv1, e1, st, skws, skn);
-            launch_pixelnorm_silu(t1, md + 3 * C, md + 2 * C, hb, d.P(), C, st);
+            if (fuse) {
+                e1.pn_out = hout;  // h = silu(pixelnorm(conv1(.)) * (1 + scale2) + shift2), the f32 value is not kept
+                e1.ld_pn = C;
+                e1.pn_scale = md + 3 * C;
+                e1.pn_shift = md + 2 * C;
+            } else {
+                e1.out_f32 = t1;
+                e1.ld_f32 = C;
+            }
+            conv3d(hin, d, rb.conv1, e1, st, skws, skn);
+            if (fuse) {
+                bf16_t* t = hin; hin = hout; hout = t;
+            } else {
+                launch_pixelnorm_silu(t1, md + 3 * C, md + 2 * C, hin, d.P(), C, st);
+            }
             GemmEpilogue e2;  // x = conv2(h) + x, in place
             e2.out_f32 = x;
             e2.ld_f32 = C;
             e2.resid = 1;
             e2.gate_scalar = 1.0f;
-            conv3d(hb, d, rb.conv2, e2, st, skws, skn);
+            if (fuse) {
+                // ... and the input of what follows: the next block's conv1, the upsampler's conv (plain bf16 cast) or conv_out
+                const float* nmd = r + 1 < 5 ? md + 4L * C : (g == 3 ? mods + last_mod : nullptr);
+                if (nmd || g == 3) {
+                    e2.pn_out = hout;
+                    e2.ld_pn = C;
+                    e2.pn_scale = g == 3 && r == 4 ? mods + last_mod + C3 : nmd + 1 * C;
+                    e2.pn_shift = g == 3 && r == 4 ? mods + last_mod : nmd + 0 * C;
+                } else {
+                    e2.out_bf16 = hout;
+                    e2.ld_bf16 = C;
+                }
+            }
+            conv3d(hin, d, rb.conv2, e2, st, skws, skn);
+            if (fuse) {
+                bf16_t* t = hin; hin = hout; hout = t;
+            }
         }
         if (g < 3) {
             // depth-to-space upsampler (VideoDecoder.swift:215-251): conv on the raw stream, D2S, drop frame 0, + D2S(x)
-            launch_cast_f32_bf16(x, hb, d.P() * C, st);
+            if (!fuse) launch_cast_f32_bf16(x, hin, d.P() * C, st);
             GemmEpilogue e;
             e.out_f32 = xo;
             e.ld_f32 = C / 2;
             e.d2s = 1;
             e.resid_src = x;
             e.ld_resid = C;
-            conv3d(hb, d, m->up[g], e, st);
+            conv3d(hin, d, m->up[g], e, st);
             d.F = 2 * d.F - 1;
             d.H *= 2;
             d.W *= 2;
             float* tmp = x;
             x = xo;
             xo = tmp;
+        } else if (!fuse) {
+            launch_pixelnorm_silu(x, mods + last_mod + C3, mods + last_mod, hin, d.P(), C3, st);
         }
-    }
-    const int C3 = m->channels[3];
-    launch_pixelnorm_silu(x, mods + last_mod + C3, mods + last_mod, hb, d.P(), C3, st);
-    {
-        GemmEpilogue e;
-        e.out_f32 = t1;
-        e.ld_f32 = 48;
-        conv3d(hb, d, m->conv_out, e, st);
+        if (g == 3) {
+            GemmEpilogue e;
+            e.out_f32 = t1;
+            e.ld_f32 = 48;
+            conv3d(hin, d, m->conv_out, e, st);
+        }
     }
     launch_vae_unpatchify_frames(t1, 48, frames, d.F, d.H, d.W, apply_clip, st);
     return d.F;
@@ -362,6 +397,7 @@ void ensure_decode_workspace(ltx_ctx* ctx, VaeModel* m, const TilePlan& plan, in
         m->xb.ensure((size_t)elems * 4);
         m->t1.ensure((size_t)elems * 4);
         m->hb.ensure((size_t)elems * 2);
+        m->hb2.ensure((size_t)elems * 2);
         m->skws.ensure((size_t)elems * 4);
         m->ws_elems = elems;
     }

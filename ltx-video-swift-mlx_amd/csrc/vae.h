@@ -61,7 +61,7 @@ struct VaeModel {
     std::map<std::string, Slot> slots;
 
     // workspace
-    DevBuf xa, xb, t1, hb, mods, tile_frames, temb, skws;
+    DevBuf xa, xb, t1, hb, hb2, mods, tile_frames, temb, skws;  // hb / hb2: the convs' bf16 inputs, ping-pong where PixelNorm is fused
     long ws_elems = 0;
 };
 
