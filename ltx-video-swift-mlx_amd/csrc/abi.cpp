@@ -697,6 +697,10 @@ int ltx_op_conv3d(ltx_ctx* ctx, const uint16_t* x, int F, int H, int W, int Cin,
         g.geom.F = F; g.geom.H = H; g.geom.W = W; g.geom.C = Cin; g.geom.causal = causal; g.geom.pad_mode = 0;
         g.ep.bias_n = bias;
         g.ep.out_f32 = out; g.ep.ld_f32 = Cout;
+        // a workspace, as the VAE graph passes one: the launcher may run a last partial round of tiles as a split-K launch
+        if (ctx->op_ws.ensure((size_t)64 << 20)) HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        g.split_ws = ctx->op_ws.as<float>();
+        g.split_ws_elems = (long)(ctx->op_ws.bytes / 4);
         launch_gemm_bf16(g, ctx->stream);
     });
 }

@@ -78,6 +78,12 @@ struct GemmArgs {
     int split_k = 1;         // 0 with a workspace: let launch_gemm_bf16 decide (dense GEMMs)
     float* split_ws = nullptr;
     long split_ws_elems = 0;  // capacity of split_ws in floats (only read when split_k == 0)
+    // Tile window (ring kernels): the launch covers the linear tiles [tile0, tile0 + tile_count) of the problem's tile order
+    // (tile_count 0 = all). With split-K, win_row0 / win_rows name the rows those tiles cover: the partial slices and the finish
+    // pass are compact over that row range. Used by the conv launcher to run the last partial round of a launch as a split-K
+    // launch over every CU instead of one K-long tile on a quarter of them.
+    int tile0 = 0, tile_count = 0;
+    int win_row0 = 0, win_rows = 0;
     int group_m = 4;  // row-tiles per supertile of the workgroup order (0 = column-major tile order); see tile_coords()
     // B as affine-quantised codes (experimental weight-streaming kernel only, M <= 128): 8-bit codes [N][K] (one per byte) and bf16 scale / bias
     // per 64-wide group along K, [N][K/64]; w' = bf16(q * scale + bias). When set, B may be null.

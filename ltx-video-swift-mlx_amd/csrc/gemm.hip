@@ -630,7 +630,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     const int wr = wave / WGN, wc = wave % WGN;
 
     const int tiles_m = (g.M + BM - 1) / BM;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x) + g.tile0;
     int tm, tn;
     tile_coords(g, bid, tiles_m, BN, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     if (g.split_k > 1) {
         GemmArgs gs = g;  // raw partial tile -> workspace slice of this split
         gs.ep = GemmEpilogue{};
-        gs.ep.out_f32 = g.split_ws + (long)blockIdx.y * g.M * g.N;
+        gs.ep.out_f32 = g.split_ws + ((long)blockIdx.y * (g.win_rows ? g.win_rows : g.M) - g.win_row0) * g.N;  // rows are absolute
         gs.ep.ld_f32 = g.N;
         gemm_epilogue<BM, BN, WGM, WGN>(acc, gs, m0, n0, wr, wc, lane, wave, smem);
         return;
@@ -1150,19 +1150,30 @@ void launch_v2(const GemmArgs& a, hipStream_t stream) {
         HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     });
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int all_tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int tiles = a.tile_count ? a.tile_count : all_tiles;
+    LTX_REQUIRE(a.tile0 >= 0 && a.tile0 + tiles <= all_tiles, "gemm: tile window [%d, %d) outside %d tiles", a.tile0, a.tile0 + tiles, all_tiles);
     if (a.split_k > 1) {
         const GemmEpilogue& e = a.ep;
         LTX_REQUIRE(a.split_ws && a.N % 4 == 0 && !e.d2s, "gemm split-K: needs a workspace, N %% 4 == 0 and no depth-to-space epilogue");
         LTX_REQUIRE(a.split_k <= a.K / BK, "gemm split-K: %d splits for %d K-tiles", a.split_k, a.K / BK);
+        LTX_REQUIRE(!a.win_rows || (!e.gate && !e.bias_m && !e.out_bf16_t && a.win_row0 + a.win_rows <= a.M),
+                    "gemm split-K: a row window takes neither per-row gates / biases nor the transposed output");
     }
     hipLaunchKernelGGL((gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN>), dim3(tiles, a.split_k > 1 ? a.split_k : 1),
                        dim3(WGM * WGN * 64), smem, stream, a);
     HIP_CHECK(hipGetLastError());
     if (a.split_k > 1) {
-        const long total = (long)a.M * (a.N / 4);
+        const int rows = a.win_rows ? a.win_rows : a.M;
+        GemmEpilogue e = a.ep;  // the finish pass indexes rows from the window's first row
+        if (a.win_rows) {
+            if (e.out_f32) e.out_f32 += (long)a.win_row0 * e.ld_f32;
+            if (e.out_bf16) e.out_bf16 += (long)a.win_row0 * e.ld_bf16;
+            if (e.resid_src) e.resid_src += (long)a.win_row0 * e.ld_resid;
+        }
+        const long total = (long)rows * (a.N / 4);
         const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, rows, a.N, e);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -1372,6 +1383,35 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
                         "gemm: fused PixelNorm output needs N == 128 (got %d), no split-K and no depth-to-space store", a.N);
             launch_gemm_bf16_cfg(a, 21, stream);
             return;
+        }
+        // Last partial round: T tiles = q full rounds of 256 + r. With r <= 128 the r tiles of the last round would run K-long on
+        // r CUs while the others idle (the VAE's 256-channel stage: 832 tiles = 3.25 rounds, 19 % of every conv). Run the full
+        // rounds as one launch and the remainder as a split-K launch over all CUs (window fields of GemmArgs).
+        static const bool no_tail = getenv("LTX_CONV_NO_TAIL") != nullptr;  // A/B hook
+        if (!no_tail && !cc && conv_default == 21 && a.split_k <= 1 && a.split_ws && !a.ep.d2s && a.N % 4 == 0 && !a.ep.gate && !a.ep.bias_m &&
+            !a.ep.out_bf16_t && a.group_m > 0) {
+            const int tiles_m = (a.M + 191) / 192, tiles_n = (a.N + 127) / 128, tiles = tiles_m * tiles_n;
+            const int full = tiles / 256 * 256, tail = tiles - full, per = a.group_m * tiles_n, nk = a.K / BK;
+            if (full >= 512 && tail > 0 && tail <= 128 && full % per == 0) {
+                const int row0 = full / per * a.group_m * 192;  // whole supertiles before the window: it covers complete rows
+                int sk = 256 / tail;
+                if (sk > 8) sk = 8;
+                if (sk > nk / 8) sk = nk / 8;
+                while (sk > 1 && (long)sk * (a.M - row0) * a.N > a.split_ws_elems) --sk;
+                if (sk > 1) {
+                    GemmArgs head = a, rest = a;
+                    head.tile_count = full;
+                    head.split_ws = nullptr;
+                    rest.tile0 = full;
+                    rest.tile_count = tail;
+                    rest.split_k = sk;
+                    rest.win_row0 = row0;
+                    rest.win_rows = a.M - row0;
+                    launch_gemm_bf16_cfg(head, 21, stream);
+                    launch_gemm_bf16_cfg(rest, 21, stream);
+                    return;
+                }
+            }
         }
         launch_gemm_bf16_cfg(a, (cc && a.split_k <= 1) ? atoi(cc) : conv_default, stream);
         return;

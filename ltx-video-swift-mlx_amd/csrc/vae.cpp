@@ -228,10 +228,9 @@ void conv3d(const bf16_t* x, const Dims& d, const ConvW& cw, GemmEpilogue ep, hi
     if (skws && !ep.d2s && cw.cout % 4 == 0) {
         int sk = gemm_suggest_split_k(g.M, g.N, g.K);
         while (sk > 1 && (long)sk * g.M * g.N > skws_elems) --sk;
-        if (sk > 1) {
-            g.split_k = sk;
-            g.split_ws = skws;
-        }
+        if (sk > 1) g.split_k = sk;
+        g.split_ws = skws;  // also lets the launcher run a last partial round of tiles as a split-K launch
+        g.split_ws_elems = skws_elems;
     }
     launch_gemm_bf16(g, st);
 }

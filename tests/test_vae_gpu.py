@@ -36,6 +36,23 @@ def test_conv3d_integer_exact(gpu_ctx, oracle, F, H, W, Cin, Cout, causal):
     assert np.array_equal(out.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("F,H,W,Cin,Cout", [(6, 96, 192, 64, 128), (6, 96, 96, 64, 256)])
+def test_conv3d_split_tail_integer_exact(gpu_ctx, oracle, F, H, W, Cin, Cout):
+    """576 output tiles = two full rounds of 256 + 64: the launcher runs the 64 as a split-K launch over a tile window
+    (csrc/gemm.hip, conv branch of launch_gemm_bf16). Small integers: every summation order gives the same f32."""
+    rng = np.random.default_rng(F + H + W + Cout)
+    x = rng.integers(-2, 3, (1, Cin, F, H, W)).astype(np.float32)
+    w = rng.integers(-2, 3, (Cout, Cin, 3, 3, 3)).astype(np.float32)
+    b = rng.integers(-4, 5, (Cout,)).astype(np.float32)
+    ref = oracle.conv3d_full(x, w, b, causal=False)[0].transpose(1, 2, 3, 0)
+    xd = torch.from_numpy(np.ascontiguousarray(x[0].transpose(1, 2, 3, 0))).to(torch.bfloat16).cuda()
+    wd = torch.from_numpy(relayout(w)).to(torch.bfloat16).cuda()
+    out = torch.full((F, H, W, Cout), float("nan"), device="cuda")
+    gpu_ctx.op_conv3d(xd, wd, torch.from_numpy(b).cuda(), out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
 @pytest.fixture(scope="module")
 def vae_model(ltx, oracle, gpu_ctx, tmp_path_factory):
     from safetensors.torch import save_file
