@@ -79,9 +79,20 @@ void launch_lincomb(const float* a, const float* b, float ca, float cb, float* o
 // latent/noise element (c,p) lives at [c*chan_stride + p] (lets a temporal tile be a strided view of the full latent)
 void launch_vae_prepare(const float* latent, long chan_stride, const float* noise, float noise_scale, const float* mean,
                         const float* std_, bf16_t* out, int C, long P, hipStream_t stream);
-// out[r][c] = table[r][c] + (te ? te[r][c] : 0) + (r odd ? 1 : 0): rows shift,scale+1[,shift2,scale2+1]
-// (VAEResBlock3d modulation, VideoDecoder.swift:93-113; final norm :421-434)
-void launch_vae_make_mods(const float* table, const float* te, float* out, int rows, int C, hipStream_t stream);
+// VAE modulation tables, up to 24 in one launch: out[r][c] = table[r][c] + (te ? te[r][c] : 0) + (r odd ? 1 : 0), rows
+// shift, scale+1[, shift2, scale2+1] (VAEResBlock3d modulation, VideoDecoder.swift:93-113; final norm :421-434)
+struct VaeModsJob {
+    const float* table;
+    const float* te;
+    float* out;
+    int rows, C;
+};
+struct VaeModsBatch {
+    static constexpr int MAX_JOBS = 24;
+    VaeModsJob job[MAX_JOBS];
+    int n = 0;
+};
+void launch_vae_make_mods_batch(const VaeModsBatch& b, hipStream_t stream);
 // temporal-tile blend (VideoDecoder.swift:561-592): r[i] = r[i]*(1-i/n) + nx[i]*(i/n) for frame i < n
 void launch_blend_frames(float* r, const float* nx, int n_frames, long frame_elems, hipStream_t stream);
 void launch_clip01(float* x, long n, hipStream_t stream);
@@ -92,8 +103,6 @@ void launch_pixelnorm_silu(const float* x, const float* scale, const float* shif
 // conv_out [F*H*W][ldx] f32 (48 valid channels) -> frames (F, 4H, 4W, 3) f32 = clip((x+1)/2, 0, 1)
 // (unpatchify VideoDecoder.swift:257-275 + decodeVideo :501-505). When blend_w >= 0 nothing is blended here;
 // temporal-tile blending is done by launch_blend_frames on the (F,H,W,3) tensors.
-void launch_vae_unpatchify_frames(const float* x, long ldx, float* frames, int F, int H, int W, int apply_clip,
-                                  hipStream_t stream);
 
 // ---- latent upscaler helpers (SpatialUpscaler.swift) ----
 // GroupNorm statistics over (all positions, C/G channels) per group, population variance: stats[g] = {mean, rstd}

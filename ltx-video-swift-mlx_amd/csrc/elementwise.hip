@@ -506,32 +506,14 @@ __global__ __launch_bounds__(256) void pixelnorm_silu_kernel(const float* __rest
     }
 }
 
-// x: [F*H*W][ldx] f32 with channel = (c*4 + a)*4 + b ; frames (F, 4H, 4W, 3): a -> W offset, b -> H offset
-__global__ void vae_unpatchify_frames_kernel(const float* __restrict__ x, long ldx, float* __restrict__ frames, int F,
-                                             int H, int W, int apply_clip) {
-    const long n = (long)F * H * W * 48;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // enumerate outputs so that consecutive threads write consecutive floats of the (F,4H,4W,3) tensor:
-    // i = (((f*4H + Y)*4W + X)*3 + c)
-    const int c = i % 3;
-    long r = i / 3;
-    const int X = r % (4 * W);
-    r /= (4 * W);
-    const int Y = r % (4 * H);
-    const int f = r / (4 * H);
-    const int w = X >> 2, a = X & 3, h = Y >> 2, b = Y & 3;
-    float v = x[(((long)f * H + h) * W + w) * ldx + (c * 4 + a) * 4 + b];
-    if (apply_clip) v = fminf(fmaxf((v + 1.0f) * 0.5f, 0.f), 1.f);
-    frames[i] = v;
-}
-
-__global__ void vae_make_mods_kernel(const float* __restrict__ table, const float* __restrict__ te, float* __restrict__ out,
-                                     int rows, int C) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)rows * C) return;
-    const int r = i / C;
-    out[i] = table[i] + (te ? te[i] : 0.f) + ((r & 1) ? 1.0f : 0.f);
+// every modulation table of a decode in one launch (21 of them at a few KB each were 21 launches of ~5 us)
+__global__ void vae_make_mods_batch_kernel(const VaeModsBatch b) {
+    const VaeModsJob& j = b.job[blockIdx.y];
+    const long n = (long)j.rows * j.C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = i / j.C;
+        j.out[i] = j.table[i] + (j.te ? j.te[i] : 0.f) + ((r & 1) ? 1.0f : 0.f);
+    }
 }
 __global__ void blend_frames_kernel(float* __restrict__ r, const float* __restrict__ nx, int n_frames, long frame_elems) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -891,8 +873,9 @@ void launch_vae_prepare(const float* latent, long chan_stride, const float* nois
     hipLaunchKernelGGL(vae_prepare_kernel, dim3(cdiv(P, 32), cdiv(C, 32)), dim3(256), 0, stream, latent, chan_stride, noise, noise_scale, mean, std_, out, C, P);
     HIP_CHECK(hipGetLastError());
 }
-void launch_vae_make_mods(const float* table, const float* te, float* out, int rows, int C, hipStream_t stream) {
-    hipLaunchKernelGGL(vae_make_mods_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, stream, table, te, out, rows, C);
+void launch_vae_make_mods_batch(const VaeModsBatch& b, hipStream_t stream) {
+    LTX_REQUIRE(b.n >= 1 && b.n <= VaeModsBatch::MAX_JOBS, "vae_make_mods_batch: %d jobs", b.n);
+    hipLaunchKernelGGL(vae_make_mods_batch_kernel, dim3(4, b.n), dim3(256), 0, stream, b);
     HIP_CHECK(hipGetLastError());
 }
 void launch_blend_frames(float* r, const float* nx, int n_frames, long frame_elems, hipStream_t stream) {
@@ -926,12 +909,6 @@ void launch_pixelnorm_silu(const float* x, const float* scale, const float* shif
     else if (lpp == 32) PN_LAUNCH(32);
     else PN_LAUNCH(64);
 #undef PN_LAUNCH
-    HIP_CHECK(hipGetLastError());
-}
-void launch_vae_unpatchify_frames(const float* x, long ldx, float* frames, int F, int H, int W, int apply_clip,
-                                  hipStream_t stream) {
-    const long n = (long)F * H * W * 48;
-    hipLaunchKernelGGL(vae_unpatchify_frames_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, ldx, frames, F, H, W, apply_clip);
     HIP_CHECK(hipGetLastError());
 }
 

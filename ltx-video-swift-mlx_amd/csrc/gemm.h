@@ -41,7 +41,11 @@ struct GemmEpilogue {
     // depth-to-space store. 1: VAE upsampler (2,2,2) with first-frame drop and tiled D2S residual
     // (VideoDecoder.swift:201-251); 2: per-frame pixel shuffle (1,2,2) of the latent upscaler
     // (SpatialUpscaler.swift:116-131). Conv output channels are stored sub-position-major (permuted at load).
+    // 3: the VAE decoder's final un-patchify (VideoDecoder.swift:257-275) as the store: 48 output channels, permuted at load to
+    // n' = b*12 + a*3 + c (original (c*4 + a)*4 + b), go to frames (F, 4H, 4W, 3) at pixel (4y + b, 4x + a), colour c: 16-byte
+    // chunks of one pixel row. With clip01 the stored value is clamp((v + 1) / 2, 0, 1) (VideoDecoder.swift:501-507).
     int d2s = 0;
+    int clip01 = 0;
     // fused PixelNorm + SiLU second output of a conv launch whose ONE column tile holds every channel (N == the tile's 128 columns):
     // pn_out[m][n] = bf16(silu(v[m][n] / sqrt(mean_n(v[m][:]^2) + 1e-8) * pn_scale[n] + pn_shift[n])), v = the value the f32 output
     // gets (after bias and residual). The VAE's 128-channel stage: the next conv's input without a pass over the f32 stream

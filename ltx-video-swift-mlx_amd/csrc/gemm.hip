@@ -359,6 +359,20 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
                 const int x = rem - y * g.geom.W;
                 orow = ((long)f * (2 * g.geom.H) + (2 * y + (sub >> 1))) * (2 * g.geom.W) + (2 * x + (sub & 1));
                 ocol = c;
+            } else if (ep.d2s == 3) {
+                // un-patchify store: this 4-wide chunk is one pixel row b, floats a*3 + c of its 12
+                const int hw = g.geom.H * g.geom.W;
+                const int f = gm / hw;
+                const int rem = gm - f * hw;
+                const int y = rem / g.geom.W;
+                const int x = rem - y * g.geom.W;
+                const int b = gn / 12;
+                orow = (((long)f * (4 * g.geom.H) + (4 * y + b)) * (4 * g.geom.W) + 4 * x) * 3;  // ld_f32 is 1
+                ocol = gn - b * 12;
+                if (ep.clip01) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf((v[e] + 1.0f) * 0.5f, 0.f), 1.f);
+                }
             } else if (ep.d2s) {
                 // VAE upsampler (VideoDecoder.swift:201-251). Conv output channels were permuted at load time to
                 // n' = sub*Cout + c (sub = dt*4+dh*2+dw), so this 4-wide chunk has one `sub` and consecutive c.
@@ -1195,15 +1209,16 @@ void validate(const GemmArgs& a) {
     const GemmEpilogue& e = a.ep;
     LTX_REQUIRE(e.out_f32 || e.out_bf16 || e.out_bf16_t || e.pn_out, "gemm: no output");
     if (e.pn_out) LTX_REQUIRE(e.ld_pn % 4 == 0 && ((uintptr_t)e.pn_out & 7) == 0, "gemm: PixelNorm output alignment");
-    if (e.out_f32) LTX_REQUIRE(e.ld_f32 % 4 == 0 && ((uintptr_t)e.out_f32 & 15) == 0, "gemm: f32 output alignment");
+    if (e.out_f32) LTX_REQUIRE((e.ld_f32 % 4 == 0 || e.d2s == 3) && ((uintptr_t)e.out_f32 & 15) == 0, "gemm: f32 output alignment");
     if (e.out_bf16) LTX_REQUIRE(e.ld_bf16 % 4 == 0 && ((uintptr_t)e.out_bf16 & 7) == 0, "gemm: bf16 output alignment");
+    if (e.d2s == 3) LTX_REQUIRE(a.conv && a.N == 48 && e.out_f32 && e.ld_f32 == 1 && !e.out_bf16 && !e.resid && a.split_k <= 1, "gemm: the un-patchify store is for the 48-channel conv_out with one f32 output");
     if (e.resid && !e.d2s) LTX_REQUIRE(e.out_f32 || e.resid_src, "gemm: residual mode needs an f32 stream");
     if (!e.d2s) {  // the interior-column epilogue reads these with 16-B accesses
         LTX_REQUIRE(((uintptr_t)e.bias_n & 15) == 0, "gemm: bias must be 16-B aligned");
         LTX_REQUIRE(((uintptr_t)e.gate & 15) == 0 && e.gate_bstride % 4 == 0, "gemm: gate must be 16-B aligned (stride %ld)", (long)e.gate_bstride);
         LTX_REQUIRE(((uintptr_t)e.resid_src & 15) == 0 && (!e.resid_src || e.ld_resid % 4 == 0), "gemm: residual source alignment");
     }
-    if (e.d2s) LTX_REQUIRE(a.conv && a.N % 32 == 0, "gemm: d2s epilogue needs conv mode and N%%32==0");
+    if (e.d2s && e.d2s != 3) LTX_REQUIRE(a.conv && a.N % 32 == 0, "gemm: d2s epilogue needs conv mode and N%%32==0");
 }
 
 }  // namespace
@@ -1303,8 +1318,10 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 3: launch_one<96, 128, true>(a, stream); break;
             case 4: launch_one<128, 96, true>(a, stream); break;
             case 21: launch_v2<192, 128, 4, true, 4, 2>(a, stream); break;   // 8 waves (4x2), per-wave 48x64, 4-slot ring
+#ifdef LTX_EXPERIMENTS  // measured, not selected for convs (VAE decode 19.4 ms with the 256x128 ring against 17.0)
             case 23: launch_v2<256, 128, 3, true, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, true, 2, 4>(a, stream); break;
+#endif
             case 27: launch_v2<256, 64, 4, true, 4, 2>(a, stream); break;   // narrow outputs (the VAE's 128 -> 48 conv_out): per-wave 64x32
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
         }
@@ -1374,7 +1391,7 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         // implicit-GEMM convs: the per-tap gather arithmetic must hide under MFMAs (8-wave ring kernels interleave it;
         // the two-stage 4-wave kernel serialises it and ran the 256-channel VAE stage at 150 TFLOP/s). M is huge, so
         // tile-count quantisation does not matter; N <= 128 wants the 192x128 tile, wide N the same (B re-use).
-        const char* cc = getenv("LTX_CONV_CFG");  // A/B hook for tile experiments (21 = 192x128 ring, 23 = 256x128 ring)
+        const char* cc = getenv("LTX_CONV_CFG");  // A/B hook for tile experiments (21 = 192x128 ring; 23 = 256x128 ring in the experiments build)
         // N <= 64 (the decoder's conv_out, 128 -> 48 channels): a 192x128 tile spends 62 % of its MFMAs on padding columns
         const int conv_default = (a.N <= 64 && a.split_k <= 1) ? 27 : 21;
         if (a.ep.pn_out) {

@@ -20,50 +20,64 @@ struct Pending {
     int kind;
     long numel;
     int cout, cin;
-    bool perm;
+    int perm;
     int init;
 };
 
 }  // namespace
 
+// stored output channel `op` of a conv <- channel of the file. perm 1: depth-to-space sub-major (op = sub*Cout/8 + c <- c*8 + sub);
+// perm 2: conv_out in un-patchify order (op = b*12 + a*3 + c <- (c*4 + a)*4 + b, VideoDecoder.swift:257-275)
+static int vae_file_channel(int perm, int op, int O) {
+    if (perm == 1) {
+        const int co = O / 8;
+        return (op % co) * 8 + op / co;
+    }
+    if (perm == 2) {
+        const int b = op / 12, a = (op % 12) / 3, c = op % 3;
+        return (c * 4 + a) * 4 + b;
+    }
+    return op;
+}
+
 VaeModel* vae_create() {
     VaeModel* m = new VaeModel();
     std::vector<Pending> pend;
-    auto conv = [&](const std::string& name, ConvW& c, int cin, int cout, bool perm) {
+    auto conv = [&](const std::string& name, ConvW& c, int cin, int cout, int perm) {
         c.cin = cin;
         c.cout = cout;
-        c.d2s_perm = perm;
+        c.d2s_perm = perm == 1;
         pend.push_back({name + ".conv.weight", (void**)&c.w, 0, (long)cout * cin * 27, cout, cin, perm, 0});
         pend.push_back({name + ".conv.bias", (void**)&c.b, 1, cout, cout, 0, perm, 0});
     };
     auto te = [&](const std::string& name, VaeTimeEmbedder& t, int out) {
         t.hidden = 256;
         t.out = out;
-        pend.push_back({name + ".timestep_embedder.linear_1.weight", (void**)&t.w1, 2, 256L * 256, 256, 256, false, 0});
-        pend.push_back({name + ".timestep_embedder.linear_1.bias", (void**)&t.b1, 1, 256, 256, 0, false, 0});
-        pend.push_back({name + ".timestep_embedder.linear_2.weight", (void**)&t.w2, 2, (long)out * 256, out, 256, false, 0});
-        pend.push_back({name + ".timestep_embedder.linear_2.bias", (void**)&t.b2, 1, out, out, 0, false, 0});
+        pend.push_back({name + ".timestep_embedder.linear_1.weight", (void**)&t.w1, 2, 256L * 256, 256, 256, 0, 0});
+        pend.push_back({name + ".timestep_embedder.linear_1.bias", (void**)&t.b1, 1, 256, 256, 0, 0, 0});
+        pend.push_back({name + ".timestep_embedder.linear_2.weight", (void**)&t.w2, 2, (long)out * 256, out, 256, 0, 0});
+        pend.push_back({name + ".timestep_embedder.linear_2.bias", (void**)&t.b2, 1, out, out, 0, 0, 0});
     };
-    conv("conv_in", m->conv_in, m->latent_channels, m->channels[0], false);
-    conv("conv_out", m->conv_out, m->channels[3], 48, false);
+    conv("conv_in", m->conv_in, m->latent_channels, m->channels[0], 0);
+    conv("conv_out", m->conv_out, m->channels[3], 48, 2);  // stored in the un-patchify order: its epilogue writes the frames
     for (int g = 0; g < 4; ++g) {
         const int C = m->channels[g];
         m->groups[g].C = C;
         const std::string gp = "up_blocks_" + std::to_string(2 * g) + ".";
         for (int r = 0; r < 5; ++r) {
             const std::string rp = gp + "res_blocks." + std::to_string(r) + ".";
-            conv(rp + "conv1", m->groups[g].blocks[r].conv1, C, C, false);
-            conv(rp + "conv2", m->groups[g].blocks[r].conv2, C, C, false);
-            pend.push_back({rp + "scale_shift_table", (void**)&m->groups[g].blocks[r].sst, 1, 4L * C, 4 * C, 0, false, 0});
+            conv(rp + "conv1", m->groups[g].blocks[r].conv1, C, C, 0);
+            conv(rp + "conv2", m->groups[g].blocks[r].conv2, C, C, 0);
+            pend.push_back({rp + "scale_shift_table", (void**)&m->groups[g].blocks[r].sst, 1, 4L * C, 4 * C, 0, 0, 0});
         }
         te(gp + "time_embedder", m->groups[g].te, 4 * C);
-        if (g < 3) conv("up_blocks_" + std::to_string(2 * g + 1) + ".conv", m->up[g], C, 4 * C, true);
+        if (g < 3) conv("up_blocks_" + std::to_string(2 * g + 1) + ".conv", m->up[g], C, 4 * C, 1);
     }
     te("last_time_embedder", m->last_te, 2 * m->channels[3]);
-    pend.push_back({"last_scale_shift_table", (void**)&m->last_sst, 1, 2L * m->channels[3], 0, 0, false, 0});
-    pend.push_back({"mean_of_means", (void**)&m->mean, 1, m->latent_channels, 0, 0, false, 0});
-    pend.push_back({"std_of_means", (void**)&m->std_, 1, m->latent_channels, 0, 0, false, 1});
-    pend.push_back({"timestep_scale_multiplier", (void**)&m->ts_mult, 3, 1, 0, 0, false, 0});
+    pend.push_back({"last_scale_shift_table", (void**)&m->last_sst, 1, 2L * m->channels[3], 0, 0, 0, 0});
+    pend.push_back({"mean_of_means", (void**)&m->mean, 1, m->latent_channels, 0, 0, 0, 0});
+    pend.push_back({"std_of_means", (void**)&m->std_, 1, m->latent_channels, 0, 0, 0, 1});
+    pend.push_back({"timestep_scale_multiplier", (void**)&m->ts_mult, 3, 1, 0, 0, 0, 0});
 
     size_t total = 0;
     for (auto& p : pend) total += DeviceArena::padded((size_t)p.numel * ((p.kind == 0 || p.kind == 2) ? 2 : 4));
@@ -142,7 +156,7 @@ void vae_load_safetensors(ltx_ctx* ctx, VaeModel* m, const std::string& path, co
             const int O = s.cout, I = s.cin;
             const int co = O / 8;
             for (int op = 0; op < O; ++op) {
-                const int o = s.perm ? ((op % co) * 8 + op / co) : op;
+                const int o = vae_file_channel(s.perm, op, O);
                 for (int tap = 0; tap < 27; ++tap)
                     for (int i = 0; i < I; ++i) dst[((size_t)op * 27 + tap) * I + i] = src[((size_t)o * I + i) * 27 + tap];
             }
@@ -155,8 +169,8 @@ void vae_load_safetensors(ltx_ctx* ctx, VaeModel* m, const std::string& path, co
             st_to_f32(st, t, f);
             if (s.perm) {
                 std::vector<float> q(f, f + s.numel);
-                const int O = (int)s.numel, co = O / 8;
-                for (int op = 0; op < O; ++op) f[op] = q[(op % co) * 8 + op / co];
+                const int O = (int)s.numel;
+                for (int op = 0; op < O; ++op) f[op] = q[vae_file_channel(s.perm, op, O)];
             }
             if (s.kind == 3) m->ts_mult_host = f[0];
         }
@@ -250,42 +264,35 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
     // per-block modulation vectors: rows shift1, scale1+1, shift2, scale2+1 (VideoDecoder.swift:93-113)
     float* emb = m->temb.as<float>();        // [256] sinusoid, [256] hidden, then per-group outputs
     if (has_ts) {
-        float* tsd = emb + 8192;
+        float* tsd = emb + 16384;
         launch_fill_const_f32(tsd, 1, timestep, st);
         launch_timestep_embedding(tsd, m->ts_mult_host, emb, 1, 256, st);
     }
     long mod_off = 0;
     long mod_ofs_group[4];
+    VaeModsBatch mb;  // every table of the decode in one launch; the time embeddings of the groups sit side by side in `emb`
+    float* te_next = emb + 512;
+    auto time_embed = [&](const VaeTimeEmbedder& t) -> const float* {
+        if (!has_ts) return nullptr;
+        float* hid = emb + 256;
+        float* out = te_next;
+        te_next += t.out;
+        launch_gemv_f32(emb, 256, t.w1, 256, t.b1, hid, 256, 1, 256, 256, LTX_ACT_NONE, st);
+        launch_gemv_f32(hid, 256, t.w2, 256, t.b2, out, t.out, 1, t.out, 256, LTX_ACT_SILU, st);
+        return out;
+    };
     for (int g = 0; g < 4; ++g) {
         const int C = m->groups[g].C;
-        const float* te = nullptr;
-        if (has_ts) {
-            float* hid = emb + 256;
-            float* out = emb + 512;
-            const VaeTimeEmbedder& t = m->groups[g].te;
-            launch_gemv_f32(emb, 256, t.w1, 256, t.b1, hid, 256, 1, 256, 256, LTX_ACT_NONE, st);
-            launch_gemv_f32(hid, 256, t.w2, 256, t.b2, out, t.out, 1, t.out, 256, LTX_ACT_SILU, st);
-            te = out;
-        }
+        const float* te = time_embed(m->groups[g].te);
         mod_ofs_group[g] = mod_off;
         for (int r = 0; r < 5; ++r) {
-            launch_vae_make_mods(m->groups[g].blocks[r].sst, te, mods + mod_off, 4, C, st);
+            mb.job[mb.n++] = VaeModsJob{m->groups[g].blocks[r].sst, te, mods + mod_off, 4, C};
             mod_off += 4L * C;
         }
     }
     const long last_mod = mod_off;
-    {
-        const float* te = nullptr;
-        if (has_ts) {
-            float* hid = emb + 256;
-            float* out = emb + 512;
-            const VaeTimeEmbedder& t = m->last_te;
-            launch_gemv_f32(emb, 256, t.w1, 256, t.b1, hid, 256, 1, 256, 256, LTX_ACT_NONE, st);
-            launch_gemv_f32(hid, 256, t.w2, 256, t.b2, out, t.out, 1, t.out, 256, LTX_ACT_SILU, st);
-            te = out;
-        }
-        launch_vae_make_mods(m->last_sst, te, mods + last_mod, 2, m->channels[3], st);
-    }
+    mb.job[mb.n++] = VaeModsJob{m->last_sst, time_embed(m->last_te), mods + last_mod, 2, m->channels[3]};
+    launch_vae_make_mods_batch(mb, st);
 
     // noise blend + denormalise -> channels-last bf16 (VideoDecoder.swift:366-381)
     Dims d = d0;
@@ -371,13 +378,14 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
             launch_pixelnorm_silu(x, mods + last_mod + C3, mods + last_mod, hin, d.P(), C3, st);
         }
         if (g == 3) {
-            GemmEpilogue e;
-            e.out_f32 = t1;
-            e.ld_f32 = 48;
+            GemmEpilogue e;  // conv_out's channels are stored in un-patchify order: the epilogue writes (F, 4H, 4W, 3) itself
+            e.out_f32 = frames;
+            e.ld_f32 = 1;
+            e.d2s = 3;
+            e.clip01 = apply_clip;
             conv3d(hin, d, m->conv_out, e, st);
         }
     }
-    launch_vae_unpatchify_frames(t1, 48, frames, d.F, d.H, d.W, apply_clip, st);
     return d.F;
 }
 
@@ -401,7 +409,7 @@ void ensure_decode_workspace(ltx_ctx* ctx, VaeModel* m, const TilePlan& plan, in
         m->ws_elems = elems;
     }
     m->mods.ensure((size_t)(20 * 4 * 1024 + 256) * 4);
-    m->temb.ensure((size_t)(8192 + 64) * 4);
+    m->temb.ensure((size_t)(16384 + 64) * 4);  // sinusoid [256], hidden [256], the groups' time embeddings (4C each), the timestep at 16384
 }
 
 TilePlan checked_plan(const VaeDecodeArgs& a) {

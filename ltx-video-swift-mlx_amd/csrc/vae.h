@@ -54,7 +54,7 @@ struct VaeModel {
         int kind = 0;  // 0 conv weight (relayout), 1 f32 vector (optionally d2s-permuted), 2 bf16 matrix [out][in], 3 scalar
         long numel = 0;
         int cout = 0, cin = 0;
-        bool perm = false;
+        int perm = 0;  // output-channel order: 0 as in the file, 1 depth-to-space sub-major (upsampler convs), 2 un-patchify row-major (conv_out)
         int init = 0;
         bool loaded = false;
     };
