@@ -312,7 +312,7 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
     const int C3 = m->channels[3];
     for (int g = 0; g < 4; ++g) {
         const int C = m->groups[g].C;
-        const bool fuse = C == 128 && hb2 != nullptr;
+        const bool fuse = C == 128;
         bf16_t* hin = hb;   // the next conv's input
         bf16_t* hout = hb2;
         for (int r = 0; r < 5; ++r) {
@@ -340,6 +340,12 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
             e2.ld_f32 = C;
             e2.resid = 1;
             e2.gate_scalar = 1.0f;
+            if (!fuse && r == 4 && g < 3) {
+                // the group's last conv also emits the bf16 copy of the stream that the upsampler's conv reads (into the other
+                // buffer: neighbouring tiles are still reading this conv's input)
+                e2.out_bf16 = hout;
+                e2.ld_bf16 = C;
+            }
             if (fuse) {
                 // ... and the input of what follows: the next block's conv1, the upsampler's conv (plain bf16 cast) or conv_out
                 const float* nmd = r + 1 < 5 ? md + 4L * C : (g == 3 ? mods + last_mod : nullptr);
@@ -360,7 +366,9 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
         }
         if (g < 3) {
             // depth-to-space upsampler (VideoDecoder.swift:215-251): conv on the raw stream, D2S, drop frame 0, + D2S(x)
-            if (!fuse) launch_cast_f32_bf16(x, hin, d.P() * C, st);
+            if (!fuse) {
+                bf16_t* t = hin; hin = hout; hout = t;  // written by the last conv2 above
+            }
             GemmEpilogue e;
             e.out_f32 = xo;
             e.ld_f32 = C / 2;
