@@ -1309,7 +1309,7 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     validate(a);
     LTX_REQUIRE(a.split_k <= 1 || (cfg >= 20 && cfg < 30) || cfg == 90, "gemm: split-K needs a ring kernel or the weight-streaming kernel (tile cfg %d)", cfg);
     LTX_REQUIRE(!a.Bq || cfg == 90, "gemm: quantised codes are read by the weight-streaming kernel only (tile cfg %d)", cfg);
-    ProfScope prof(a.conv ? PROF_CONV : PROF_GEMM, 2.0 * a.M * a.N * a.K, stream);
+    ProfScope prof(a.conv ? PROF_CONV : PROF_GEMM, 2.0 * (a.win_rows ? a.win_rows : a.M) * a.N * a.K, stream);  // a tile window's rows
     // cfg 0..2: v1 (2-stage, one barrier + full drain per K-tile); cfg 10..: v2 (ring + counted vmcnt)
     if (a.conv) {
         switch (cfg) {
@@ -1418,6 +1418,7 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
                 if (sk > 1) {
                     GemmArgs head = a, rest = a;
                     head.tile_count = full;
+                    head.win_rows = row0;  // rows [0, row0): only the work accounting reads it on a launch without split-K
                     head.split_ws = nullptr;
                     rest.tile0 = full;
                     rest.tile_count = tail;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Post-process a rocprofv3 --kernel-trace CSV of `tools/bench_vae.py`: the launch timeline of the LAST VAE decode in the trace
-(from its first kernel after the previous decode's final clip / unpatchify to the end) with grid, duration and gap.
+(from the first kernel after the previous decode's conv_out to its own conv_out) with grid, duration and gap.
 Usage: python tools/trace_vae.py <kernel_trace.csv>"""
 import csv
 import re
@@ -20,7 +20,8 @@ def main():
     ev = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
            int(r.get("Grid_Size_X", 0) or 0) * max(int(r.get("Grid_Size_Y", 1) or 1), 1), int(r.get("Workgroup_Size_X", 1) or 1),
            int(r.get("Grid_Size_Y", 1) or 1)) for r in rows]
-    ends = [i for i, e in enumerate(ev) if e[0].startswith("vae_unpatchify")]
+    # conv_out (the 256x64 tile instantiation; its epilogue writes the frames) is the last launch of a decode
+    ends = [i for i, e in enumerate(ev) if e[0].startswith("gemm_bf16_kernel_v2<256, 64")]
     if len(ends) < 2:
         print("need two decodes in the trace")
         return
