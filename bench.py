@@ -53,14 +53,15 @@ PEAK_BF16_TFLOPS = 2500.0
 # Reported beside `frac` for context only; `frac` stays priced against the 2.5 PFLOP/s headline.
 SUSTAINED_BF16_TFLOPS = 2000.0
 HBM_PEAK_GBPS = 8000.0
-TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRAFFIC_FILES = ("r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+VAE_TRAFFIC_FILES = ("r02_pmc_traffic_vae.json",)
 
 
-def pmc_traffic():
+def pmc_traffic(files=None):
     """HBM-side bytes per GEMM launch (mean over all GEMM launches of this workload) and the file they come from. PMC counters
     cannot be read from inside the process: they come from two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE) of this
     same command, corrected as MI355X_MICROARCH.md prescribes (KiB units, FETCH_SIZE x2 on gfx950) by tools/pmc_traffic.py."""
-    for name in TRAFFIC_FILES:
+    for name in (files or TRAFFIC_FILES):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return round(json.load(f)["gemm_all"]["hbm_bytes_per_launch"]), "profiles/" + name
@@ -591,10 +592,11 @@ def bench_vae(ctx, ltx, torch, dev, F, H, W, iters=3):
            "tflops": round(12.96 / (ms * 1e-3), 1)}
     if c["ms"] > 0:
         ach = c["work"] / (c["ms"] * 1e-3) / 1e12
+        vtraffic, vsrc = pmc_traffic(VAE_TRAFFIC_FILES)  # fabric-side bytes per conv launch, two --pmc passes of tools/bench_vae.py
         res["conv_kernel_tflops"] = round(ach, 1)
         res["conv_ms"] = round(c["ms"] / iters, 3)
         res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel_v2<conv>", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": vtraffic, "traffic_source": vsrc,
                            "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / max(1, c["launches"]), 2),
                            "whole_decode_frac": round(12.96 / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4),
                            "hbm_frac_at_algorithmic_bytes": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
