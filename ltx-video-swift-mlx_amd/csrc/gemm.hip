@@ -666,6 +666,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         int f0, f1, f2, y0, y1, y2, x0, x1, x2, bad;
     };
     TapTab a_tab[A_PER_WAVE];
+    struct TapStep {
+        int x01, x12, y01, y12, t01, t12;
+    };
+    TapStep a_step[CONV ? A_PER_WAVE : 1];
+    const bool conv_steps = CONV && !(g.geom.pad_mode == 1 || g.geom.pad_mode == 3);  // no zero padding: taps are positions
     const bf16_t* a_row0[A_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < A_PER_WAVE; ++i) {
@@ -703,6 +708,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
             t.y0 = axis_s(py, H, 0, 8) * W; t.y1 = axis_s(py, H, 1, 8) * W; t.y2 = axis_s(py, H, 2, 8) * W;
             t.x0 = axis_s(px, W, 0, 64); t.x1 = axis_s(px, W, 1, 64); t.x2 = axis_s(px, W, 2, 64);
             t.bad = bad;
+            // without zero padding a tap is a position, and the next tap in (dt, dy, dx) order is that position plus one of six
+            // per-row steps (elements): a tap change is then a 64-bit add per row
+            TapStep& st = a_step[i];
+            const int C = g.geom.C;
+            st.x01 = (t.x1 - t.x0) * C;
+            st.x12 = (t.x2 - t.x1) * C;
+            st.y01 = (t.x0 - t.x2 + t.y1 - t.y0) * C;
+            st.y12 = (t.x0 - t.x2 + t.y2 - t.y1) * C;
+            st.t01 = (t.x0 - t.x2 + t.y0 - t.y2 + t.f1 - t.f0) * C;
+            st.t12 = (t.x0 - t.x2 + t.y0 - t.y2 + t.f2 - t.f1) * C;
         } else {
             a_src[i] = g.A + (long)gm * g.lda + lch * 8;
         }
@@ -757,20 +772,36 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
             a_src[i] = a_row0[i] + (long)vox * g.geom.C;
         }
     };
+    // tap `from` -> from + 1 where taps are positions: one uniform branch picks the step, each arm is a 64-bit add per row
+    auto conv_tap_step = [&](int from) {
+        const int t9 = (g.geom.kt == 3) ? from % 9 : from;
+        const int dt = (g.geom.kt == 3) ? from / 9 : 1;
+        const int dy = t9 / 3, dx = t9 - dy * 3;
+#define LTX_TAP_STEP(FIELD)                                                   \
+    _Pragma("unroll") for (int i = 0; i < A_PER_WAVE; ++i) a_src[i] += (long)a_step[i].FIELD
+        if (dx == 0) { LTX_TAP_STEP(x01); }
+        else if (dx == 1) { LTX_TAP_STEP(x12); }
+        else if (dy == 0) { LTX_TAP_STEP(y01); }
+        else if (dy == 1) { LTX_TAP_STEP(y12); }
+        else if (dt == 0) { LTX_TAP_STEP(t01); }
+        else { LTX_TAP_STEP(t12); }
+#undef LTX_TAP_STEP
+    };
     int conv_tap = kt0 / cpt, conv_cc = kt0 - conv_tap * cpt;  // position of the NEXT K-tile to stage
     auto stage = [&](int slot, int kt) {
         char* base = smem + slot * STAGE;
         if constexpr (CONV) {
-            if (conv_cc == 0) conv_tap_ptrs(conv_tap);
 #pragma unroll
             for (int i = 0; i < A_PER_WAVE; ++i) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + conv_cc * BK),
                                                  (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024),
                                                  16, 0, 0);
             }
-            if (++conv_cc == cpt) {
+            if (++conv_cc == cpt) {  // the pointers of the next tap, behind the loads of this one
                 conv_cc = 0;
-                ++conv_tap;
+                if (++conv_tap < 9 * g.geom.kt) {
+                    if (conv_steps) conv_tap_step(conv_tap - 1); else conv_tap_ptrs(conv_tap);
+                }
             }
         } else {
 #pragma unroll
@@ -827,7 +858,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
 
     // prologue: fill PD ring slots, wait for tile 0, fetch its first fragments
     if constexpr (CONV) {
-        if (conv_cc != 0) conv_tap_ptrs(conv_tap);  // a K split may begin in the middle of a tap
+        conv_tap_ptrs(conv_tap);  // absolute pointers of the first tap (a K split may begin at any tap, in the middle of one)
     }
 #pragma unroll
     for (int s = 0; s < PD; ++s)
