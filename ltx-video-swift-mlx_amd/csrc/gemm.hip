@@ -391,11 +391,13 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
                 ocol = c;
                 if (ep.resid_src) {
                     // residual = D2S(x)[c mod C/8], tiled along channels (VideoDecoder.swift:219-234)
+                    // c is a multiple of 4 and so is C/8: the chunk's four channels wrap together - one modulo, not four
                     const int cd2s = g.geom.C >> 3;
-                    const float* rs = ep.resid_src + (long)gm * ep.ld_resid;
+                    const int cm = (cd2s & (cd2s - 1)) == 0 ? (c & (cd2s - 1)) : (c % cd2s);
+                    const float* rs = ep.resid_src + (long)gm * ep.ld_resid + cm * 8 + sub;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (e < nv) v[e] += rs[((c + e) % cd2s) * 8 + sub];
+                        if (e < nv) v[e] += rs[e * 8];
                 }
             } else if (ep.resid) {
                 const float* rs = (ep.resid_src ? ep.resid_src + (long)gm * ep.ld_resid : ep.out_f32 + (long)gm * ep.ld_f32) + gn;
@@ -1250,6 +1252,7 @@ void validate(const GemmArgs& a) {
         LTX_REQUIRE(((uintptr_t)e.resid_src & 15) == 0 && (!e.resid_src || e.ld_resid % 4 == 0), "gemm: residual source alignment");
     }
     if (e.d2s && e.d2s != 3) LTX_REQUIRE(a.conv && a.N % 32 == 0, "gemm: d2s epilogue needs conv mode and N%%32==0");
+    if (e.d2s == 1 && e.resid_src) LTX_REQUIRE(a.geom.C % 32 == 0, "gemm: the depth-to-space residual needs C %% 32 == 0 (C=%d)", a.geom.C);
 }
 
 }  // namespace
