@@ -1347,12 +1347,12 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     // cfg 0..2: v1 (2-stage, one barrier + full drain per K-tile); cfg 10..: v2 (ring + counted vmcnt)
     if (a.conv) {
         switch (cfg) {
+            case 21: launch_v2<192, 128, 4, true, 4, 2>(a, stream); break;   // 8 waves (4x2), per-wave 48x64, 4-slot ring
+#ifdef LTX_EXPERIMENTS  // measured, not selected for convs (VAE decode 19.4 ms with the 256x128 ring, 22.8 with the two-stage kernel, against 17.0)
             case 0: launch_one<128, 128, true>(a, stream); break;
             case 1: launch_one<192, 128, true>(a, stream); break;
             case 3: launch_one<96, 128, true>(a, stream); break;
             case 4: launch_one<128, 96, true>(a, stream); break;
-            case 21: launch_v2<192, 128, 4, true, 4, 2>(a, stream); break;   // 8 waves (4x2), per-wave 48x64, 4-slot ring
-#ifdef LTX_EXPERIMENTS  // measured, not selected for convs (VAE decode 19.4 ms with the 256x128 ring against 17.0)
             case 23: launch_v2<256, 128, 3, true, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, true, 2, 4>(a, stream); break;
 #endif

@@ -32,4 +32,4 @@ def test_production_gemm_kernels_have_no_scratch(tmp_path):
             continue
         seen += 1
         assert int(scratch) == 0 and int(spills) == 0, f"{name}: private segment {scratch} bytes, {spills} spilled VGPRs"
-    assert seen >= 10, f"only {seen} GEMM kernels found in the metadata"
+    assert seen >= 8, f"only {seen} GEMM kernels found in the metadata"  # 4 two-stage + 3 ring (dense) + 192x256 + 2 conv ring
