@@ -1369,6 +1369,7 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 22: { GemmArgs b = a; b.group_m = 0; launch_v2<192, 128, 4, false, 4, 2>(b, stream); break; }  // A/B: column-major order
             case 23: launch_v2<256, 128, 3, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
+            case 29: launch_v2<128, 64, 4, false, 2, 2>(a, stream); break;  // few rows: narrow column tiles, 4 waves, one workgroup per CU
             case 75: launch_dtl(a, stream); break;  // 192x256, one wave per SIMD, fragments of a whole K-tile in registers, 2 + 3 LDS slots
 #ifdef LTX_EXPERIMENTS  // measured, not selected (gemm_experiments.inc)
             case 90: launch_stream(a, stream); break;  // weight-streaming kernel for M <= 128 (bf16 weights or 8-bit codes): 1.4x slower than the ring split-K path
@@ -1475,10 +1476,19 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         // small token counts, e.g. 256x256x9 -> 128 tokens: 32 tiles of weights to stream with 256 CUs) -> split K over the idle CUs
         GemmArgs b = a;
         b.split_k = gemm_suggest_split_k(a.M, a.N, a.K);
-        // few rows (<= 128, e.g. 256x256x9): the 128x192 ring tile stages 16 KB of activations per 24 KB of weights and K-tile,
-        // the 192x128 one 24 KB (a third of them padding rows) per 16 KB
-        static const int smallm_cfg = getenv("LTX_SMALLM_CFG") ? atoi(getenv("LTX_SMALLM_CFG")) : 25;
+        // few rows (<= 128, e.g. 256x256x9): narrow 128x64 ring tiles - 64 column tiles at N = 4096, so 4 splits fill the chip and
+        // the partial slices are a quarter of the weights (128x192 tiles needed 16 splits: as many partial bytes as weight bytes),
+        // and the FFN's first GEMM (256 column tiles) needs no split at all. Config 1: 12.04 ms per forward against 12.25 (cfg 25).
+        static const int smallm_cfg = getenv("LTX_SMALLM_CFG") ? atoi(getenv("LTX_SMALLM_CFG")) : 29;
         const int cfg = (a.M <= 128 && b.split_k > 1) ? smallm_cfg : 21;
+        if (cfg == 29) {
+            const long tiles = (long)((a.N + 63) / 64);
+            long sk = 256 / tiles;
+            const int nk = a.K / BK;
+            if (sk > 16) sk = 16;
+            if (sk > nk / 8) sk = nk / 8;
+            b.split_k = sk < 1 ? 1 : (int)sk;
+        }
         if (cfg == 25) {
             const long tiles = (long)((a.N + 191) / 192);
             long sk = 256 / tiles;
@@ -1488,7 +1498,11 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
             b.split_k = sk < 1 ? 1 : (int)sk;
         }
         while (b.split_k > 1 && (long)b.split_k * a.M * a.N > a.split_ws_elems) --b.split_k;
-        if (b.split_k > 1 && a.N % 4 == 0 && !a.ep.d2s) {
+        if ((b.split_k > 1 || cfg == 29) && a.N % 4 == 0 && !a.ep.d2s) {
+            if (b.split_k <= 1) {
+                b.split_k = 1;  // enough column tiles to fill the chip without a split (the FFN's first GEMM)
+                b.split_ws = nullptr;
+            }
             launch_gemm_bf16_cfg(b, cfg, stream);
             return;
         }
