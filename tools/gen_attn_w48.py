@@ -319,8 +319,51 @@ class Gen:
             self.e(valu[vi])
             vi += 1
 
+    @staticmethod
+    def issue_cost(group):
+        """Vector-issue cycles of a filler group beside MFMAs (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost')."""
+        c = 0
+        for ins in group:
+            if ins.startswith(("v_exp_f32", "v_rcp_f32", "v_log_f32")):
+                c += 8
+            elif ins.startswith("buffer_load"):
+                c += 24
+            elif ins.startswith(("s_nop", "s_add", "s_cmp", "s_sub")):
+                c += 1
+            else:
+                c += 4
+        return c
+
+    def spread_gaps(self, stream, groups, over):
+        """Cost-aware placement: an MFMA holds the vector issue port for 8 of its 16 cycles, so a gap BETWEEN TWO MFMAs hides 8 cycles
+        of fillers; a gap that already carries a fragment read / wait hides none. Fillers go, in order, into the pure gaps of the first
+        `over` MFMAs in proportion to their issue cost; busy gaps only take what the pure ones cannot."""
+        items = [(k, t) for k, t in stream if not ("nords" in ABL and k in ("ds", "wait"))]
+        mf = [i for i, (k, _) in enumerate(items) if k == "mfma"]
+        pure = [i for n, i in enumerate(mf[:over]) if i + 1 < len(items) and items[i + 1][0] == "mfma"]
+        demand = sum(self.issue_cost(g) for g in groups)
+        cap = 8.0 * max(1, len(pure))
+        f = max(1.0, demand / cap)
+        gi, cum, allowed = 0, 0.0, 0.0
+        pure_set = set(pure)
+        for i, (kind, text) in enumerate(items):
+            self.e(text)
+            if i in pure_set:
+                allowed += 8.0 * f
+                while gi < len(groups) and cum + self.issue_cost(groups[gi]) <= allowed + 0.5:
+                    for ins in groups[gi]:
+                        self.e(ins)
+                    cum += self.issue_cost(groups[gi])
+                    gi += 1
+        while gi < len(groups):
+            for ins in groups[gi]:
+                self.e(ins)
+            gi += 1
+
     def spread(self, stream, groups, over):
         """Emit an MFMA stream with the instruction groups spread evenly behind its first `over` MFMAs (leftovers at the end)."""
+        if os.environ.get("W48_SPREAD") != "even":  # "even": the round-1 placement (one filler behind every MFMA), kept for A/B stamps
+            return self.spread_gaps(stream, groups, over)
         gi, nm = 0, 0
         for kind, text in stream:
             if "nords" in ABL and kind in ("ds", "wait"):
