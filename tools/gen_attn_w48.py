@@ -327,7 +327,7 @@ class Gen:
             if ins.startswith(("v_exp_f32", "v_rcp_f32", "v_log_f32")):
                 c += 8
             elif ins.startswith("buffer_load"):
-                c += 24
+                c += int(os.environ.get("W48_DMA_COST", "24"))
             elif ins.startswith(("s_nop", "s_add", "s_cmp", "s_sub")):
                 c += 1
             else:
@@ -341,16 +341,20 @@ class Gen:
         items = [(k, t) for k, t in stream if not ("nords" in ABL and k in ("ds", "wait"))]
         mf = [i for i, (k, _) in enumerate(items) if k == "mfma"]
         pure = [i for n, i in enumerate(mf[:over]) if i + 1 < len(items) and items[i + 1][0] == "mfma"]
+        busy = [i for n, i in enumerate(mf[:over]) if not (i + 1 < len(items) and items[i + 1][0] == "mfma")]
+        bcap = float(os.environ.get("W48_BUSY_CAP", "0"))   # cycles a gap that carries a fragment read / wait may still take
         demand = sum(self.issue_cost(g) for g in groups)
-        cap = 8.0 * max(1, len(pure))
-        f = max(1.0, demand / cap)
+        cap = 8.0 * len(pure) + bcap * len(busy)
+        f = max(1.0, demand / max(cap, 1.0))
         gi, cum, allowed = 0, 0.0, 0.0
-        pure_set = set(pure)
+        pure_set, busy_set = set(pure), set(busy)
         for i, (kind, text) in enumerate(items):
             self.e(text)
-            if i in pure_set:
-                allowed += 8.0 * f
+            if i in pure_set or (bcap > 0 and i in busy_set):
+                allowed += (8.0 if i in pure_set else bcap) * f
                 while gi < len(groups) and cum + self.issue_cost(groups[gi]) <= allowed + 0.5:
+                    if i in busy_set and self.issue_cost(groups[gi]) > 4:
+                        break  # no 8-cycle instruction beside a fragment read
                     for ins in groups[gi]:
                         self.e(ins)
                     cum += self.issue_cost(groups[gi])
