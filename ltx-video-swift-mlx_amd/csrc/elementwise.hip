@@ -713,6 +713,99 @@ __global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(QkJob j0, QkJob j
     }
 }
 
+// The self-attention pair (q and k of the same tokens) in one workgroup: R rows of BOTH jobs share one fetch of the rotary tables
+// (a table row is as many bytes as the f32 row it rotates; with one workgroup per job the second fetch came from L2 / Infinity Cache,
+// 768 workgroups later) and one barrier pair.
+template <int R>
+__global__ __launch_bounds__(256) void qknorm_rope_pair_kernel(QkJob j0, QkJob j1, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                               int T, int rows, float eps) {
+    constexpr int NP = 2, D = 4096, NJ = 2;
+    __shared__ float red[4][NJ * R];
+    const int row0 = blockIdx.x * R;
+    f32x4 va[NJ][R][NP], vb[NJ][R][NP], c4[R][NP], s4[R][NP];
+    int col[NP], fc[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int p = threadIdx.x + j * 256;
+        col[j] = (p >> 4) * 128 + (p & 15) * 4;
+        fc[j] = (p >> 4) * 64 + (p & 15) * 4;
+    }
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+        const QkJob& job = q ? j1 : j0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = (row0 + r) < rows ? (row0 + r) : rows - 1;
+            const float* xr = job.x + (long)row * job.ldx;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                va[q][r][j] = *(const f32x4*)(xr + col[j]);
+                vb[q][r][j] = *(const f32x4*)(xr + col[j] + 64);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = (row0 + r) < rows ? (row0 + r) : rows - 1;
+        const long tb = (long)(row % T) * (D >> 1);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            c4[r][j] = *(const f32x4*)(cosT + tb + fc[j]);
+            s4[r][j] = *(const f32x4*)(sinT + tb + fc[j]);
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NJ; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a += va[q][r][j][e] * va[q][r][j][e] + vb[q][r][j][e] * vb[q][r][j][e];
+            a = wave_reduce_sum(a);
+            if (lane == 0) red[w][q * R + r] = a;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+        const QkJob& job = q ? j1 : j0;
+        const float osc = job.out_scale;
+        f32x4 wa[NP], wb[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            wa[j] = *(const f32x4*)(job.w + col[j]);
+            wb[j] = *(const f32x4*)(job.w + col[j] + 64);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            if (row >= rows) break;
+            const int k = q * R + r;
+            const float rstd = rsqrtf((red[0][k] + red[1][k] + red[2][k] + red[3][k]) / (float)D + eps);
+            bf16_t* orow = job.out + (long)row * job.ldo;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                f32x4 a, b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = va[q][r][j][e] * rstd * wa[j][e], b0 = vb[q][r][j][e] * rstd * wb[j][e];
+                    a[e] = a0 * c4[r][j][e] - b0 * s4[r][j][e];
+                    b[e] = b0 * c4[r][j][e] + a0 * s4[r][j][e];
+                }
+                uint2 pa, pb;
+                pa.x = pack_bf16x2(a[0] * osc, a[1] * osc);
+                pa.y = pack_bf16x2(a[2] * osc, a[3] * osc);
+                pb.x = pack_bf16x2(b[0] * osc, b[1] * osc);
+                pb.y = pack_bf16x2(b[2] * osc, b[3] * osc);
+                *(uint2*)(orow + col[j]) = pa;
+                *(uint2*)(orow + col[j] + 64) = pb;
+            }
+        }
+    }
+}
+
 void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const float* x1, const float* w1, bf16_t* out1,
                          long ldx, long ldo, const float* cosT, const float* sinT, int T, int rows, int D, float eps,
                          hipStream_t stream, float out_scale0) {
@@ -722,6 +815,13 @@ void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const f
     ProfScope prof(PROF_ELEM, (double)rows * D * (x1 ? 2 : 1) * (4 + 2 + (cosT ? 4 : 0)), stream);
     const dim3 grid(rows, x1 ? 2 : 1);
     const int t = T < 1 ? 1 : T;
+    static const bool no_pair = getenv("LTX_QKNORM_NO_PAIR") != nullptr;  // A/B hook
+    if (D == 4096 && rows >= 512 && x1 && cosT && !no_pair) {  // q and k of the same tokens: one fetch of the tables (2.64 -> 2.54 ms of row passes per step)
+        constexpr int R = 2;
+        hipLaunchKernelGGL(qknorm_rope_pair_kernel<R>, dim3((rows + R - 1) / R), dim3(256), 0, stream, j0, j1, cosT, sinT, t, rows, eps);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (D == 4096 && rows >= 512) {   // the DiT at full width: R rows per workgroup share one fetch of the norm weights
         constexpr int R = 2;
         hipLaunchKernelGGL(qknorm_rope_rows_kernel<R>, dim3((rows + R - 1) / R, x1 ? 2 : 1), dim3(256), 0, stream, j0, j1, cosT, sinT, t, rows, eps);
