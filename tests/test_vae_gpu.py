@@ -53,6 +53,33 @@ def test_conv3d_split_tail_integer_exact(gpu_ctx, oracle, F, H, W, Cin, Cout):
     assert np.array_equal(out.cpu().numpy(), ref)
 
 
+def test_conv3d_random_shapes_integer_exact(gpu_ctx):
+    """Seeded random geometries through the conv launcher's three routes (one launch; whole rounds + split-K tail window; narrow
+    outputs) against torch's conv3d on the same integer data - exact in f32 whatever the summation order. Ragged tile counts,
+    image rows that straddle tiles, single-frame inputs."""
+    import torch.nn.functional as F_
+
+    rng = np.random.default_rng(20260)
+    cases = [(1, 2, 2), (1, 31, 45), (3, 17, 23), (2, 64, 96), (5, 95, 101), (7, 97, 193), (4, 128, 192), (9, 64, 191)]
+    for F, H, W in cases:
+        Cin = int(rng.choice([64, 128]))
+        Cout = int(rng.choice([48, 128, 256]))
+        if F * H * W * Cin * Cout * 27 > 3.5e12:  # keep the torch reference to a few seconds
+            Cin, Cout = 64, 128
+        x = torch.from_numpy(rng.integers(-2, 3, (1, Cin, F, H, W)).astype(np.float32)).cuda()
+        w = torch.from_numpy(rng.integers(-2, 3, (Cout, Cin, 3, 3, 3)).astype(np.float32)).cuda()
+        b = torch.from_numpy(rng.integers(-4, 5, (Cout,)).astype(np.float32)).cuda()
+        xp = F_.pad(x, (1, 1, 1, 1, 0, 0), mode="reflect")
+        xp = torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], 2)  # replicate in T
+        ref = F_.conv3d(xp.double(), w.double(), b.double())[0].permute(1, 2, 3, 0).float()
+        xd = x[0].permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)
+        wd = torch.from_numpy(relayout(w.cpu().numpy())).to(torch.bfloat16).cuda()
+        out = torch.full((F, H, W, Cout), float("nan"), device="cuda")
+        gpu_ctx.op_conv3d(xd, wd, b, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), (F, H, W, Cin, Cout, float((out - ref).abs().max()))
+
+
 @pytest.fixture(scope="module")
 def vae_model(ltx, oracle, gpu_ctx, tmp_path_factory):
     from safetensors.torch import save_file
