@@ -115,13 +115,16 @@ LTX_DEVFN void gemm_residual_prefetch(const GemmArgs& g, int m0, int n0, int wr,
 
 // PN: the fused PixelNorm + SiLU second output (GemmEpilogue::pn_out) is compiled in (conv instantiations only: it adds a
 // workgroup barrier per 16-row slab and registers the dense kernels' epilogues do not have to spare).
-template <int BM, int BN, int WGM = 2, int WGN = 2, bool PN = false, class Get>
+// SCR: `get(mi_c, scr)` writes the 16 x WN slab row-major into this wave's LDS scratch itself (accumulators that are not in the
+// 16x16 MFMA layout: the 32x32x16 kernel); the transposed store, which works from the 16x16 register layout, is then not available.
+template <int BM, int BN, int WGM = 2, int WGN = 2, bool PN = false, bool SCR = false, class Get>
 LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, int wr, int wc, int lane, int wave, char* smem,
                                   const ResidualTile<BM, BN, WGM, WGN>* pre = nullptr) {
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
     float* scr = (float*)(smem + wave * (16 * WN * 4));
     constexpr int LPR = WN / 4;    // lanes per output row
     const GemmEpilogue& ep = g.ep;
+    if constexpr (!SCR)
     if (ep.out_bf16_t) {
         // transposed bf16 store from the accumulator layout: acc[mi][ni][r] = C[16 mi + 4 (lane >> 4) + r][16 ni + (lane & 15)]
         static_for<0, MI>([&](auto mi_c) {
@@ -218,13 +221,17 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
             constexpr int mi = decltype(mi_c)::value;
             constexpr int buf = mi & 1;
             if constexpr (mi + 1 < MI) prefetch(std::integral_constant<int, mi + 1>{}, std::integral_constant<int, (mi + 1) & 1>{});
-            f32x4 slab[NI];
-            get(mi_c, slab);
-            static_for<0, NI>([&](auto ni_c) {
-                constexpr int ni = decltype(ni_c)::value;
+            if constexpr (SCR) {
+                get(mi_c, scr);
+            } else {
+                f32x4 slab[NI];
+                get(mi_c, slab);
+                static_for<0, NI>([&](auto ni_c) {
+                    constexpr int ni = decltype(ni_c)::value;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = slab[ni][r];
-            });
+                    for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = slab[ni][r];
+                });
+            }
             f32x4 pn_v[PN ? NIT : 1];
             float pn_s2[PN ? NIT : 1];
 #pragma unroll
@@ -307,13 +314,17 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
     }
     static_for<0, MI>([&](auto mi_c) {
         constexpr int mi = decltype(mi_c)::value;
-        f32x4 slab[NI];
-        get(mi_c, slab);
-        static_for<0, NI>([&](auto ni_c) {
-            constexpr int ni = decltype(ni_c)::value;
+        if constexpr (SCR) {
+            get(mi_c, scr);
+        } else {
+            f32x4 slab[NI];
+            get(mi_c, slab);
+            static_for<0, NI>([&](auto ni_c) {
+                constexpr int ni = decltype(ni_c)::value;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = slab[ni][r];
-        });
+                for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = slab[ni][r];
+            });
+        }
 #pragma unroll
         for (int it = 0; it < (16 * LPR) / 64; ++it) {
             const int chunk = it * 64 + lane;  // 16 rows x LPR float4 chunks, row-major
@@ -965,6 +976,207 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
 }
 
 
+#ifdef LTX_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------------------------
+// The ring kernel on v_mfma_f32_32x32x16_bf16 (dense launches). Same LDS ring, counted waits and skewed fragment pipeline as _v2;
+// what changes is the issue budget: an MFMA holds the SIMD's vector issue port for 8 cycles whether it computes for 16 or for 32
+// (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'), so the 12 MFMAs of a K-tile leave 24 free cycles per gap where the 24 of
+// the 16x16x32 form leave 8 - and the LDS-DMA pieces and fragment reads that the 16x16x32 loop cannot hide fit. Waves 2 x 4, per
+// wave 96 x 32 = 3 x 1 blocks of 32 x 32 (48 accumulator registers, as before).
+// MEASURED, NOT SELECTED (tile_cfg 31, experiments build): bit-identical to the 16x16x32 ring kernel on integer data, and slower -
+// 1536x4096x4096 951 against 1021 TFLOP/s, K = 16384 1083 against 1178 (HBM-cold weights, same process): a 96 x 32 wave tile reads
+// 16 KB of fragments per K-tile where 48 x 64 reads 14, and the compiler bunches the LDS-DMA pieces in one gap.
+//   operands: lane l holds row (l & 31), k = 8 (l >> 5) .. +7 of the 16-deep k-step  -> one ds_read_b128 per block and k-step
+//   result:   lane l holds column (l & 31), rows 8 (v / 4) + 4 (l >> 5) + (v % 4), v = 0..15
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int NSTAGE>
+__global__ __launch_bounds__(512) void gemm_bf16_kernel_m32(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WGM = 2, WGN = 4, NW = 8;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "32x32 blocks");
+    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_PER_WAVE = BM / 8 / NW, B_PER_WAVE = BN / 8 / NW;
+    static_assert(A_PER_WAVE * 8 * NW == BM && B_PER_WAVE * 8 * NW == BN, "tile rows must split evenly over the waves");
+    constexpr int LPT = A_PER_WAVE + B_PER_WAVE;
+    constexpr int PD = NSTAGE - 1;
+    constexpr int NF = 2 * (MI + NI);  // fragment reads per half K-tile (two 16-deep k-steps)
+    constexpr int NM = 2 * MI * NI;    // MFMAs per half K-tile
+    static_assert(NSTAGE >= 3, "ring needs >= 3 slots");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x) + g.tile0;
+    int tm, tn;
+    tile_coords(g, bid, tiles_m, BN, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int srow = lane >> 3, pch = lane & 7;
+    const bf16_t* a_src[A_PER_WAVE];
+    const bf16_t* b_src[B_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int row = (wave + NW * i) * 8 + srow;
+        int gm = m0 + row;
+        gm = gm < g.M ? gm : g.M - 1;
+        a_src[i] = g.A + (long)gm * g.lda + (pch ^ ((row >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i) {
+        const int row = (wave + NW * i) * 8 + srow;
+        int gn = n0 + row;
+        gn = gn < g.N ? gn : g.N - 1;
+        b_src[i] = g.B + (long)gn * g.ldb + (pch ^ ((row >> 1) & 7)) * 8;
+    }
+    int nk = g.K / BK, kt0 = 0;
+    if (g.split_k > 1) {
+        const int z = blockIdx.y;
+        kt0 = (int)((long)nk * z / g.split_k);
+        nk = (int)((long)nk * (z + 1) / g.split_k) - kt0;
+    }
+    auto stage = [&](int slot, int kt) {
+        char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (long)kt * BK),
+                                             (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PER_WAVE; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (long)kt * BK),
+                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
+    };
+
+    // fragment read offsets: row (lane & 31) of a 32-row block, 16-byte chunk (lane >> 5) + 2 ks of the row, XOR-swizzled by the row
+    const int frow = lane & 31;
+    const int fsw = (lane >> 1) & 7;  // ((row >> 1) & 7) for row = 32 k + (lane & 31)
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * ROW_BYTES + ((((lane >> 5) + 2 * ks) ^ fsw) << 4);
+    const int a_wave_off = (wr * WM) * ROW_BYTES;
+    const int b_wave_off = A_BYTES + (wc * WN) * ROW_BYTES;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    // two fragment sets (a half K-tile each = two k-steps): [k-step within the half][block]
+    s16x8 fa0[2][MI], fb0[2][NI], fa1[2][MI], fb1[2][NI];
+    auto load_frags = [&](int slot, int half, s16x8(&fa)[2][MI], s16x8(&fb)[2][NI]) {
+        const char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[k][i] = *(const s16x8*)(base + a_wave_off + i * 32 * ROW_BYTES + foff[2 * half + k]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[k][j] = *(const s16x8*)(base + b_wave_off + j * 32 * ROW_BYTES + foff[2 * half + k]);
+        }
+    };
+    auto mfma_one = [&](const s16x8(&fa)[2][MI], const s16x8(&fb)[2][NI], int k, int i, int j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[k][i]), __builtin_bit_cast(bf16x8_t, fb[k][j]),
+                                                            acc[i][j], 0, 0, 0);
+    };
+    auto mfma_first = [&](const s16x8(&fa)[2][MI], const s16x8(&fb)[2][NI]) { mfma_one(fa, fb, 0, 0, 0); };
+    auto mfma_rest = [&](const s16x8(&fa)[2][MI], const s16x8(&fb)[2][NI]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    if (k + i + j > 0) mfma_one(fa, fb, k, i, j);
+    };
+
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+        if (s < nk) stage(s, kt0 + s);
+    if (nk >= PD) wait_vmcnt_barrier<(PD - 1) * LPT>(); else wait_vmcnt_barrier<0>();
+    load_frags(0, 0, fa0, fb0);
+
+    int slot = 0;
+    bool drained = false;
+    auto ktile = [&](int kt, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        int nslot = slot + 1;
+        nslot = nslot == NSTAGE ? 0 : nslot;
+        int pslot = slot - 1;
+        pslot = pslot < 0 ? NSTAGE - 1 : pslot;
+        // ---- first half: MFMAs of k-steps 0, 1; the fragment reads of k-steps 2, 3 go two per MFMA gap
+        mfma_first(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(slot, 1, fa1, fb1);
+        mfma_rest(fa0, fb0);
+#pragma unroll
+        for (int q = 0; q < (NF + 1) / 2; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // two ds_reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1 - (NF + 1) / 2, 0);
+        if constexpr (STEADY) wait_vmcnt_barrier<(PD - 2) * LPT>(); else if (!drained) wait_vmcnt_barrier<0>();
+        // ---- second half
+        mfma_first(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STEADY) {
+            stage(pslot, kt0 + kt + PD);
+            load_frags(nslot, 0, fa0, fb0);
+            mfma_rest(fa1, fb1);
+            // five MFMAs to go: each gap takes one LDS-DMA piece and two of the next tile's fragment reads
+#pragma unroll
+            for (int q = 0; q < NM - 1; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x020, (LPT + NM - 2) / (NM - 1), 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, (NF + NM - 2) / (NM - 1), 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            }
+        } else {
+            if (kt + 1 < nk) load_frags(nslot, 0, fa0, fb0);
+            mfma_rest(fa1, fb1);
+        }
+        slot = nslot;
+    };
+    int kt = 0;
+    for (; kt < nk - PD; ++kt) ktile(kt, std::true_type{});
+    ResidualTile<BM, BN, WGM, WGN> rt;
+    if (kt < nk) {
+        ktile(kt, std::false_type{});
+        ++kt;
+        drained = true;
+        if (!g.ep.d2s && g.split_k <= 1 && n0 + BN <= g.N && kt < nk) {
+            gemm_bias_prefetch<BM, BN, WGM, WGN>(g, n0, wc, lane, rt);
+            if (g.ep.resid) gemm_residual_prefetch<BM, BN, WGM, WGN>(g, m0, n0, wr, wc, lane, rt);
+        }
+    }
+    for (; kt < nk; ++kt) ktile(kt, std::false_type{});
+    __syncthreads();
+    // the 16-row slab s of this wave's tile = half (s & 1) of block s / 2: values v = 8 (s & 1) + t, t = 0..7, at row
+    // 8 (t / 4) + 4 (lane >> 5) + (t % 4) of the slab, column 32 j + (lane & 31)
+    auto put = [&](auto s_c, float* scr) {
+        constexpr int sidx = decltype(s_c)::value;
+        constexpr int blk = sidx / 2, h = sidx % 2;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                scr[(8 * (t / 4) + 4 * (lane >> 5) + (t % 4)) * WN + 32 * j + (lane & 31)] = acc[blk][j][8 * h + t];
+    };
+    if (g.split_k > 1) {
+        GemmArgs gs = g;
+        gs.ep = GemmEpilogue{};
+        gs.ep.out_f32 = g.split_ws + ((long)blockIdx.y * (g.win_rows ? g.win_rows : g.M) - g.win_row0) * g.N;
+        gs.ep.ld_f32 = g.N;
+        gemm_epilogue_with<BM, BN, WGM, WGN, false, true>(put, gs, m0, n0, wr, wc, lane, wave, smem);
+        return;
+    }
+    gemm_epilogue_with<BM, BN, WGM, WGN, false, true>(put, g, m0, n0, wr, wc, lane, wave, smem, &rt);
+}
+
+#endif  // LTX_EXPERIMENTS
+
 // ---------------------------------------------------------------------------------------------------------------
 // small-M path: one wave per output column, f32 activations x bf16 weights
 // ---------------------------------------------------------------------------------------------------------------
@@ -1189,6 +1401,30 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_dtl(const GemmArgs g)
     });
 }
 
+#ifdef LTX_EXPERIMENTS
+template <int BM, int BN, int NSTAGE>
+void launch_m32(const GemmArgs& a, hipStream_t stream) {
+    constexpr int smem = NSTAGE * (BM + BN) * ROW_BYTES;
+    static PerDeviceOnce attr_set;
+    attr_set.run([&] {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_m32<BM, BN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    });
+    LTX_REQUIRE(!a.conv && !a.ep.out_bf16_t && !a.ep.pn_out && !a.tile_count, "gemm: the 32x32x16 ring kernel takes dense launches without a transposed output");
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    if (a.split_k > 1) {
+        LTX_REQUIRE(a.split_ws && a.N % 4 == 0 && !a.ep.d2s && a.split_k <= a.K / BK, "gemm split-K: workspace, N %% 4 == 0, no depth-to-space");
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel_m32<BM, BN, NSTAGE>), dim3(tiles, a.split_k > 1 ? a.split_k : 1), dim3(512), smem, stream, a);
+    HIP_CHECK(hipGetLastError());
+    if (a.split_k > 1) {
+        const long total = (long)a.M * (a.N / 4);
+        const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+        HIP_CHECK(hipGetLastError());
+    }
+}
+#endif
+
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2>
 void launch_v2(const GemmArgs& a, hipStream_t stream) {
     constexpr int smem = NSTAGE * (BM + BN) * ROW_BYTES;
@@ -1341,7 +1577,7 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
                     "gemm: the transposed bf16 output takes bias_n only, no split-K, ld %% 4 == 0 (ld=%ld M=%d cfg=%d)", e.ld_bf16_t, a.M, cfg);
     }
     validate(a);
-    LTX_REQUIRE(a.split_k <= 1 || (cfg >= 20 && cfg < 30) || cfg == 90, "gemm: split-K needs a ring kernel or the weight-streaming kernel (tile cfg %d)", cfg);
+    LTX_REQUIRE(a.split_k <= 1 || (cfg >= 20 && cfg < 32) || cfg == 90, "gemm: split-K needs a ring kernel or the weight-streaming kernel (tile cfg %d)", cfg);
     LTX_REQUIRE(!a.Bq || cfg == 90, "gemm: quantised codes are read by the weight-streaming kernel only (tile cfg %d)", cfg);
     ProfScope prof(a.conv ? PROF_CONV : PROF_GEMM, 2.0 * (a.win_rows ? a.win_rows : a.M) * a.N * a.K, stream);  // a tile window's rows
     // cfg 0..2: v1 (2-stage, one barrier + full drain per K-tile); cfg 10..: v2 (ring + counted vmcnt)
@@ -1372,6 +1608,7 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 29: launch_v2<128, 64, 4, false, 2, 2>(a, stream); break;  // few rows: narrow column tiles, 4 waves, one workgroup per CU
             case 75: launch_dtl(a, stream); break;  // 192x256, one wave per SIMD, fragments of a whole K-tile in registers, 2 + 3 LDS slots
 #ifdef LTX_EXPERIMENTS  // measured, not selected (gemm_experiments.inc)
+            case 31: launch_m32<192, 128, 4>(a, stream); break;  // the 192x128 ring tile on 32x32x16 MFMAs (2 x 4 waves of 96 x 32): 951 vs 1021 TFLOP/s
             case 90: launch_stream(a, stream); break;  // weight-streaming kernel for M <= 128 (bf16 weights or 8-bit codes): 1.4x slower than the ring split-K path
             case 71: launch_asm<256>(a, stream); break;      // one wave per SIMD, assembly main loop, 192x256
             case 72: launch_asm<128>(a, stream); break;      // the same, 192x128

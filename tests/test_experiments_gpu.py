@@ -65,7 +65,7 @@ def test_gemm_assembly_kernel_epilogue_matches_ring_kernel(gpu_ctx, ltx):
         gpu_ctx.op_gemm(A[:100], B, bias, tile_cfg=71, out_bf16=o2[:100])
 
 
-@pytest.mark.parametrize("cfg", [41, 42])
+@pytest.mark.parametrize("cfg", [41, 42, 31])  # 31: the ring tile on 32x32x16 MFMAs (2 x 4 waves of 96 x 32), same staging as the product ring
 @pytest.mark.parametrize("M,N,K,reps", [(192, 256, 128, 1), (256, 256, 192, 1), (100, 60, 320, 1), (500, 700, 256, 2),
                                         (777, 1000, 448, 2), (1536, 1024, 4096, 6), (1536, 2048, 1024, 6), (3000, 768, 2112, 3)])
 def test_gemm_pingpong_integer_exact(gpu_ctx, cfg, M, N, K, reps):
