@@ -14,9 +14,11 @@ update (reference loop body, LTXPipeline.swift:800-956), every input already res
 
 Modes (what N GPUs do; the path shards at the granularity of forwards / samples / tiles):
   replica    (default; BASELINE configs[1]) distilled, 768x512x25 = 1536 tokens, 1024 text keys, CFG off. Every rank runs its own
-             sample: no data-path collective, weak scaling, value = N*K steps / max-over-ranks time. With N >= 2 the line also
-             carries two short extra legs measured after the timed region - `cfg_pair` and `sp` below - so that one scaling run
-             shows the sharded paths too; they run under a watchdog and can only add keys, never change `value`.
+             sample: no data-path collective, weak scaling, value = N*K steps / max-over-ranks time; `per_rank_ms_per_step`
+             lists every rank's own time so that a slow box is visible. With N >= 2 and --extra-legs the line also carries two
+             short legs measured after the timed region - `cfg_pair` and `sp` below; they are opt-in because they call
+             collectives: under a watchdog, a hang or an error there still prints the line (`extra_legs_status`) and then ends
+             every rank with exit status 3 - a run whose collectives did not return is never reported as a success.
   cfg-pair   (configs[2]) dev schedule, CFG 4.0: ranks (0,1), (2,3), ... each form a pair; rank 2p evaluates the negative branch,
              rank 2p+1 the positive one, ONE RCCL all-gather of the 786 KB velocities per step inside ltx_denoise_dev
              (LTX_SHARD_CFG). N = 1 runs the batched B = 2 forward on one GPU (the baseline a pair must beat). value = pairs*K
@@ -35,6 +37,7 @@ cpu_baseline: the oracle (numpy restatement of the reference path, kind "port") 
 whole transformer blocks of the same workload and scaled to one step.
 """
 import argparse
+import copy
 import importlib
 import json
 import os
@@ -149,8 +152,9 @@ def spawn_ranks(args, argv):
 
 
 class Watchdog:
-    """The extra legs call collectives that were never timed on this node before; if one of them hangs, rank 0 still prints the
-    line with what it has and every rank leaves. os._exit: a thread blocked inside a collective cannot be joined."""
+    """The extra legs call collectives; if one of them hangs, rank 0 prints the line with what it has (from a snapshot taken under
+    `lock`, which the main thread also holds whenever it changes the line) and every rank leaves with status 3. os._exit: a thread
+    blocked inside a collective cannot be joined, and the GPU process is never restarted or re-executed."""
 
     def __init__(self, seconds, on_fire):
         self.t = threading.Timer(seconds, on_fire)
@@ -165,6 +169,44 @@ class Watchdog:
         return False
 
 
+def guarded_extra_legs(out, rank, legs_fn, seconds):
+    """Run the sharded legs after the headline region. The line is printed whatever happens here, but a hang or an error ends
+    every rank with status 3 (`_exit_status`, applied by main() after the line is out): the cause must be found from the
+    records, not hidden behind rc 0. `legs_fn(put)` calls put(name, result) per finished leg."""
+    lock = threading.Lock()
+    legs = {}
+    out["extra_legs"] = legs
+    out["extra_legs_status"] = "running"
+
+    def fire():
+        try:
+            if rank == 0:
+                with lock:
+                    snap = copy.deepcopy(out)
+                snap["extra_legs_status"] = "hang"
+                snap.setdefault("extra_legs", {})["watchdog"] = "timed out: a collective of the extra legs did not return"
+                snap.pop("_exit_status", None)
+                print(json.dumps(snap, default=str), flush=True)
+        finally:
+            os._exit(3)
+
+    def put(name, res):
+        with lock:
+            legs[name] = res
+
+    failed = None
+    with Watchdog(seconds, fire):
+        try:
+            legs_fn(put)
+        except Exception as e:  # noqa: BLE001
+            failed = repr(e)
+    with lock:
+        out["extra_legs_status"] = "error" if failed else "ok"
+        if failed:
+            legs["error"] = failed
+            out["_exit_status"] = 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,9 +217,13 @@ def main():
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the once-per-prompt legs (text-embedding connector, VAE encoder)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-launch HIP events in the timed region")
-    ap.add_argument("--no-extra-legs", action="store_true", help="replica mode, N >= 2: skip the cfg_pair / sp legs")
+    ap.add_argument("--extra-legs", action="store_true",
+                    help="replica mode, N >= 2: add the cfg_pair / sp legs after the timed region (a hang or error in them ends the run with status 3)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="accepted for compatibility: the legs are off unless --extra-legs")
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher self-test: ranks rendezvous over gloo, count themselves and print the line without touching a GPU")
+    ap.add_argument("--selftest-legs", choices=("hang", "error", "ok"), default=None,
+                    help="with --launch-check: drive the extra-legs guard with a fake leg that hangs / raises / returns (no GPU)")
     args = ap.parse_args()
 
     # ---- who launches the ranks? (before torch or the library are imported: no GPU call may precede a spawn) ----
@@ -202,8 +248,21 @@ def main():
         ones = torch.ones(1)
         if world > 1:
             dist.all_reduce(ones)
+        line = {"metric": "launch-check", "n_gpus": world, "n_ranks_seen": int(ones.item()), "mode": args.mode}
+        if args.selftest_legs:
+            def fake(put):
+                put("first", {"ok": True})
+                if args.selftest_legs == "hang":
+                    threading.Event().wait()  # a collective that never returns
+                if args.selftest_legs == "error":
+                    raise RuntimeError("leg failed")
+
+            guarded_extra_legs(line, rank, fake, 1.0)
+        status = line.pop("_exit_status", 0)
         if rank == 0:
-            print(json.dumps({"metric": "launch-check", "n_gpus": world, "n_ranks_seen": int(ones.item()), "mode": args.mode}), flush=True)
+            print(json.dumps(line), flush=True)
+        if status:
+            os._exit(status)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -228,8 +287,12 @@ def main():
     out = runner(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side)
     out["n_ranks_seen"] = n_ranks_seen
     out["launcher"] = "bench.py" if os.environ.get("LTX_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process")
+    status = out.pop("_exit_status", 0)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if status:  # an extra leg failed on this rank: the line is out, now fail the run (no barrier: the peers may be gone)
+        sys.stdout.flush()
+        os._exit(status)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -248,13 +311,17 @@ def timed(torch, dist, world, dev, fn, warmup, steps):
     for i in range(steps):
         fn(warmup + i)
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0  # this rank's K steps, before it waits for the others
     if world > 1:
         dist.barrier()
     el = time.perf_counter() - t0
+    timed.per_rank = [own]
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        t = torch.tensor([el, own], dtype=torch.float64, device=dev)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)  # the line's time is the MAX of the barrier-to-barrier times; `own` shows a slow box
+        timed.per_rank = [float(x[1].item()) for x in allt]
+        el = max(float(x[0].item()) for x in allt)
     return el
 
 
@@ -294,6 +361,7 @@ def run_replica(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side):
             ctx.op_fill_normal_f32(latent, seed=1000 + i + rank)
 
     el = timed(torch, dist, world, dev, step, args.warmup, args.steps)
+    per_rank = list(timed.per_rank)
 
     # Roofline leg: the SAME K steps again with a HIP-event pair recorded on the launch stream around every GEMM /
     # attention launch. The event packets themselves cost ~6 % of a step (2 x 434 launches), so they are kept out
@@ -337,6 +405,7 @@ def run_replica(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side):
                     "48-layer DiT bf16 weights (random init)",
                     {"tokens": T, "text_keys": S_TEXT, "parallelism": f"replica x{world} (one sample per GPU, no data-path collective)"})
     spp = el / args.steps
+    out["per_rank_ms_per_step"] = [round(1e3 * x / args.steps, 3) for x in per_rank]
     out["dit_tflop_per_step"] = {"reference_algorithm": round(dit_flops_per_step(T) / 1e12, 2),
                                  "executed": round(dit_flops_per_step(T, executed=True) / 1e12, 2),
                                  "note": "executed = without the caption projection and cross-attention K/V projections, which the "
@@ -357,24 +426,13 @@ def run_replica(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side):
             out["pre_loop"] = bench_pre_loop(ctx, ltx, torch, dev)
         except Exception as e:
             out["pre_loop"] = {"error": str(e)}
-    if world > 1 and not args.no_extra_legs:
-        # the sharded paths, measured briefly after the headline region; a hang or failure here must not cost the line
-        def fire():
-            if rank == 0:
-                out["extra_legs"] = out.get("extra_legs", {})
-                out["extra_legs"]["watchdog"] = "timed out: a collective of the extra legs did not return"
-                print(json.dumps(out), flush=True)
-            os._exit(0)  # every rank has this timer; a non-zero status would make the launcher report the whole run as failed
+    if world > 1 and args.extra_legs and not args.no_extra_legs:
+        def legs_fn(put):
+            if world % 2 == 0:
+                put("cfg_pair", leg_cfg_pair(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side, min(args.steps, 4)))
+            put("sp", leg_sp(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side, 2))
 
-        legs = {}
-        out["extra_legs"] = legs
-        with Watchdog(240.0, fire):
-            try:
-                if world % 2 == 0:
-                    legs["cfg_pair"] = leg_cfg_pair(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side, min(args.steps, 4))
-                legs["sp"] = leg_sp(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side, 2)
-            except Exception as e:  # noqa: BLE001
-                legs["error"] = repr(e)
+        guarded_extra_legs(out, rank, legs_fn, 240.0)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T, S_TEXT)
     return out

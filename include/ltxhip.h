@@ -400,6 +400,11 @@ int ltx_dist_broadcast_dev(ltx_ctx* ctx, void* buf, long bytes, int root);
 int ltx_vae_decode_tile_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
                             const float* noise, int tile, int overlap, int tile_index, float* tile_out, long tile_cap,
                             int* n_frames_out);
+/* One VAEResBlock3d of the loaded decoder (VideoDecoder.swift:75-131: PixelNorm -> scale/shift -> SiLU -> conv1 -> PixelNorm ->
+ * scale/shift -> SiLU -> conv2 -> + x; no timestep conditioning) applied in place to a channels-last f32 stream x [F][H][W][C],
+ * C = channels of up-block group `group` (0..3: 1024, 512, 256, 128), block 0..4. Runs the very kernels and fused epilogues of the
+ * decode, so a host (or a parity test) can check one stage at full resolution without a full-size reference decode. DEVICE pointer. */
+int ltx_vae_res_block_dev(ltx_ctx* ctx, int group, int block, float* x, int F, int H, int W);
 /* Blend raw tiles in tile order over 8*overlap frames (VideoDecoder.swift:561-592), then clip((x+1)/2, 0, 1) (:501-505).
  * tiles: HOST array of n_tiles DEVICE pointers, tile_frames their frame counts; tiles[0] may be frames_out. */
 int ltx_vae_blend_tiles_dev(ltx_ctx* ctx, const float* const* tiles, const int* tile_frames, int n_tiles, int overlap, int H,

@@ -420,6 +420,10 @@ class Context:
                                              _ptr(noise), tile, overlap, tile_index, _ptr(out), out.numel(), C.byref(n)))
         return n.value
 
+    def vae_res_block_dev(self, group, block, x, F, H, W):
+        """One res-block of the loaded decoder on the channels-last f32 stream x [F][H][W][C], in place."""
+        self._ck(lib.ltx_vae_res_block_dev(self._h, group, block, _ptr(x), F, H, W))
+
     def vae_blend_tiles_dev(self, tiles, tile_frames, overlap, H, W, frames):
         n = C.c_int()
         ptrs = (C.c_void_p * len(tiles))(*[t.data_ptr() for t in tiles])

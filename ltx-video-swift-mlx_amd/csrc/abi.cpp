@@ -425,8 +425,9 @@ int ltx_dit_forward(ltx_ctx* ctx, const uint16_t* latent, const uint16_t* contex
                 if (mask[i] != 1) { all_ones = 0; break; }
         }
         HIP_CHECK(hipMemcpyAsync(ctx->h2d[0].p, latent, n_lat, hipMemcpyHostToDevice, st));
+        if (!hv) hv = 1;  // 0 means "do not cache"
         bool cached = false;
-        for (auto* e : m->ctx_cache) cached = cached || (e->version == hv && e->B == B && e->S == S);
+        for (auto* e : m->ctx_cache) cached = cached || (e->version == hv && e->kind == 0 && e->B == B && e->S == S);
         if (!cached) {
             HIP_CHECK(hipMemcpyAsync(ctx->h2d[1].p, context, n_ctx, hipMemcpyHostToDevice, st));
             if (mask) HIP_CHECK(hipMemcpyAsync(ctx->h2d[3].p, mask, (size_t)B * S * 4, hipMemcpyHostToDevice, st));
@@ -647,6 +648,11 @@ int ltx_vae_decode_tile_dev(ltx_ctx* ctx, const float* latent, int F, int H, int
     });
 }
 
+int ltx_vae_res_block_dev(ltx_ctx* ctx, int group, int block, float* x, int F, int H, int W) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { vae_res_block(ctx, need_vae(ctx), group, block, x, F, H, W); });
+}
+
 int ltx_vae_blend_tiles_dev(ltx_ctx* ctx, const float* const* tiles, const int* tile_frames, int n_tiles, int overlap, int H,
                             int W, float* frames_out, long frames_cap, int* n_frames_out) {
     if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
@@ -856,7 +862,7 @@ int ltx_denoise(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* s
         p.context = ctx->h2d[6].as<bf16_t>();
         p.mask = mask ? ctx->h2d[7].as<int32_t>() : nullptr;
         p.mask_all_ones = all_ones; p.S = S;
-        p.ctx_version = (hv >> 3) | 1;  // room for the per-pass sub-keys derived in denoise_run
+        p.ctx_version = hv ? hv : 1;
         fill_params(p, opt);
         if (opt && opt->cond_latent) {  // image-to-video: stage the image latent (and the re-noising draws) on the device
             const size_t n_c = (size_t)m->cfg.in_channels * H * W * 4;

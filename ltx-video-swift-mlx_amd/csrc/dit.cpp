@@ -272,7 +272,7 @@ DiTModel::CtxCache* prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardA
     DiTModel::CtxCache* c = nullptr;
     if (a.ctx_version != 0)
         for (auto* e : m->ctx_cache)
-            if (e->version == a.ctx_version && e->B == B && e->S == S) {
+            if (e->version == a.ctx_version && e->kind == a.ctx_kind && e->B == B && e->S == S) {
                 e->last_use = m->ctx_clock;
                 return e;
             }
@@ -318,6 +318,7 @@ DiTModel::CtxCache* prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardA
     c->has_bias = (a.mask != nullptr) && !a.mask_all_ones;
     if (c->has_bias) launch_mask_to_bias(a.mask, c->bias.as<float>(), rows, st);
     c->version = a.ctx_version;
+    c->kind = a.ctx_kind;
     c->B = B;
     c->S = S;
     c->Spad = Spad;

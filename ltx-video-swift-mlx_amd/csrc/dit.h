@@ -81,6 +81,7 @@ struct DiTModel {
     struct CtxCache {
         DevBuf proj, k, vt, bias;
         uint64_t version = 0;
+        int kind = 0;  // which pass of a denoise step owns the entry (DiTForwardArgs::ctx_kind): part of the key, never folded into `version`
         int B = 0, S = 0, Spad = 0;
         bool has_bias = false;
         uint64_t last_use = 0;
@@ -119,7 +120,8 @@ struct DiTForwardArgs {
     const int32_t* mask = nullptr;    // device [B][S] int32 or null
     int mask_all_ones = 0;            // host hint: skip the additive bias entirely (bit-identical: +0.0)
     int B = 1, F = 0, H = 0, W = 0, S = 0;
-    uint64_t ctx_version = 0;         // 0 = recompute context every call; else cache key
+    uint64_t ctx_version = 0;         // 0 = recompute context every call; else cache key (any non-zero 64-bit value, e.g. a hash)
+    int ctx_kind = 0;                 // second key field: 0 = a raw forward; 1.. = the passes of denoise_run (batched pair, negative, positive)
     float* velocity = nullptr;        // device [B][T][out_channels] f32
     // Sequence parallelism over sp_world ranks (single sample on several GPUs): this rank owns tokens
     // [sp_rank*Tn, (sp_rank+1)*Tn), Tn = F*H*W / sp_world, and `latent`, `row_map`, `velocity` hold only those Tn rows. Every
@@ -137,9 +139,8 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a);
 int dit_fuse_lora(ltx_ctx* ctx, DiTModel* m, const std::string& path, float scale);
 // R21: on-the-fly affine quantisation of every Linear weight, group size 64 along `in`, 8 or 4 bits
 // (LTXQuantizationConfig.swift:19-62, LTXPipeline.swift:323-333). The bf16 weights are REPLACED by codes + bf16 group scale / bias
-// (the layout MLX's QuantizedLinear holds) and their 26 GB are released. Consumers: GEMMs with few rows (the HBM-bound regime,
-// e.g. 256x256x9 = 128 tokens) read the 8-bit codes directly and de-quantise in the B stage; GEMMs with many rows (MFMA-bound)
-// get the weight matrix of the launch de-quantised into one scratch matrix first (a streaming pass worth 2-3 % of such a GEMM).
+// (the layout MLX's QuantizedLinear holds) and their 26 GB are released. Consumer: dit_linear_weights() below - see the note there
+// on which launches de-quantise inside the GEMM's B stage and which through the scratch matrix.
 void dit_quantize(ltx_ctx* ctx, DiTModel* m, int bits, int group);
 // bf16 weights of a Linear for a launch on `stream`: the resident matrix, or the scratch matrix filled from the codes
 const bf16_t* dit_linear_weights(const LinearW& w, hipStream_t stream);

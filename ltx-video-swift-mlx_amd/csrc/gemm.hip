@@ -1514,7 +1514,9 @@ static void launch_asm(const GemmArgs& a, hipStream_t stream) {
 #endif
 
 static bool gemm_dtl_takes(const GemmArgs& a) {
-    return !a.conv && a.split_k <= 1 && a.M % 192 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 64 && !a.ep.d2s && !a.ep.out_bf16_t;
+    // lda / ldb % 8: the LDS-DMA pieces are 16-byte loads; the epilogue of this kernel has no clip / PixelNorm / tile-window form
+    return !a.conv && a.split_k <= 1 && a.M % 192 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 64 && !a.ep.d2s && !a.ep.out_bf16_t &&
+           a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.ep.pn_out && !a.ep.clip01 && a.tile_count == 0 && a.win_rows == 0;
 }
 static void launch_dtl(const GemmArgs& a, hipStream_t stream) {
     LTX_REQUIRE(gemm_dtl_takes(a), "gemm: the 192x256 kernel needs a dense A.B^T with M %% 192 == 0, N %% 256 == 0, K %% 64 == 0 (M=%d N=%d K=%d)",

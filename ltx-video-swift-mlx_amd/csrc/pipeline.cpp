@@ -9,7 +9,10 @@
 // derives its key the same way from the caller's version, in a namespace of its own (top bit set), so that no two passes with
 // different contents can meet on one key whatever small counters a caller uses: kind 0 = the [neg,pos] batch, 1 = the negative
 // context alone, 2 = the positive context alone (plain forward, sharded positive branch and the STG pass share this entry).
-static uint64_t ctx_key(uint64_t ver, int kind) { return ver ? (0x8000000000000000ull | ((ver << 2) + (uint64_t)kind)) : 0; }
+// Cache-key kinds of the passes of one denoise step (DiTForwardArgs::ctx_kind). The caller's version travels unchanged beside them:
+// any non-zero 64-bit value is a valid version (a hash of the prompt, say), and a raw ltx_dit_forward (kind 0) can never land on a
+// denoise entry whatever its bits.
+enum { CTX_PAIR = 1, CTX_NEG = 2, CTX_POS = 3 };
 
 void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
     DiTModel* m = ctx->dit;
@@ -68,14 +71,15 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
     const int32_t* mask_pos = (use_cfg && p.mask) ? p.mask + p.S : p.mask;
     const uint64_t ver = p.ctx_version;
 
-    auto forward = [&](const bf16_t* tok, const bf16_t* c, const int32_t* mk, int b, uint64_t key, float* out_tok) {
+    auto forward = [&](const bf16_t* tok, const bf16_t* c, const int32_t* mk, int b, int kind, float* out_tok) {
         DiTForwardArgs a;
         a.context = c;
         a.timesteps = ctx->dn_ts.as<float>();
         a.mask = mk;
         a.mask_all_ones = p.mask_all_ones;
         a.B = b; a.F = p.F; a.H = p.H; a.W = p.W; a.S = p.S;
-        a.ctx_version = key;
+        a.ctx_version = ver;
+        a.ctx_kind = ver ? kind : 0;
         if (i2v) {
             a.n_groups = G;
             a.row_map = ctx->dn_rowmap.as<int32_t>() + tok0;
@@ -127,16 +131,16 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
 
         bool have_stg = false;  // vel + 2n already holds the STG-perturbed velocity (three-rank group)
         if (!use_cfg) {
-            forward(tokens, p.context, p.mask, 1, ctx_key(ver, 2), vel_tok);
+            forward(tokens, p.context, p.mask, 1, CTX_POS, vel_tok);
             launch_unpatchify_f32(vel_tok, v, 1, C, T, st);
         } else {
             if (cfg_sharded) {
                 // this rank's pass only; one all-gather per step brings the others' velocities over xGMI
                 if (rank == 0) {
-                    forward(tokens, p.context, p.mask, 1, ctx_key(ver, 1), vel_tok);
+                    forward(tokens, p.context, p.mask, 1, CTX_NEG, vel_tok);
                 } else {
                     if (rank == 2) set_stg(true);
-                    forward(tokens, ctx_pos, mask_pos, 1, ctx_key(ver, 2), vel_tok);
+                    forward(tokens, ctx_pos, mask_pos, 1, CTX_POS, vel_tok);
                     if (rank == 2) set_stg(false);
                 }
                 launch_unpatchify_f32(vel_tok, vp, 1, C, T, st);
@@ -144,12 +148,12 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
                 have_stg = world == 3;
             } else if (seq) {
                 // two sequence-parallel B=1 forwards (LTXPipeline.swift:829-848)
-                forward(tokens, p.context, p.mask, 1, ctx_key(ver, 1), vel_tok);
+                forward(tokens, p.context, p.mask, 1, CTX_NEG, vel_tok);
                 launch_unpatchify_f32(vel_tok, vel, 1, C, T, st);
-                forward(tokens, ctx_pos, mask_pos, 1, ctx_key(ver, 2), vel_tok);
+                forward(tokens, ctx_pos, mask_pos, 1, CTX_POS, vel_tok);
                 launch_unpatchify_f32(vel_tok, vel + n, 1, C, T, st);
             } else {
-                forward(tokens, p.context, p.mask, 2, ctx_key(ver, 0), vel_tok);
+                forward(tokens, p.context, p.mask, 2, CTX_PAIR, vel_tok);
                 launch_unpatchify_f32(vel_tok, vel, 2, C, T, st);
             }
             const float* uncond = vel;
@@ -169,7 +173,7 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
                 pert = vel + 2 * n;
             } else {
                 set_stg(true);
-                forward(tokens, ctx_pos, mask_pos, 1, ctx_key(ver, 2), vel_tok);
+                forward(tokens, ctx_pos, mask_pos, 1, CTX_POS, vel_tok);
                 set_stg(false);
                 launch_unpatchify_f32(vel_tok, vp, 1, C, T, st);
             }

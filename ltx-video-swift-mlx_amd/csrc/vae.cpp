@@ -249,6 +249,49 @@ void conv3d(const bf16_t* x, const Dims& d, const ConvW& cw, GemmEpilogue ep, hi
     launch_gemm_bf16(g, st);
 }
 
+// One VAEResBlock3d (VideoDecoder.swift:75-131) on the f32 stream x [P][C], in place. `md` = the block's modulation rows (shift1,
+// 1 + scale1, shift2, 1 + scale2). With C == 128 the convs' epilogues carry the PixelNorm passes: conv1 emits conv2's input, conv2
+// emits the next consumer's (`next_scale` / `next_shift`: PixelNorm + modulation + SiLU; `copy`: a plain bf16 cast; neither: nothing)
+// into the bf16 buffer it is not reading; hin / hout swap accordingly. `first`: x has no bf16 form yet (the group's first block).
+void res_block(const VaeResBlock& rb, const float* md, int C, const Dims& d, float* x, float* t1, bf16_t*& hin, bf16_t*& hout, bool first,
+               const float* next_scale, const float* next_shift, bool copy, hipStream_t st, float* skws, long skn) {
+    const bool fuse = C == 128;
+    if (!fuse || first) launch_pixelnorm_silu(x, md + 1 * C, md + 0 * C, hin, d.P(), C, st);
+    GemmEpilogue e1;
+    if (fuse) {
+        e1.pn_out = hout;  // h = silu(pixelnorm(conv1(.)) * (1 + scale2) + shift2), the f32 value is not kept
+        e1.ld_pn = C;
+        e1.pn_scale = md + 3 * C;
+        e1.pn_shift = md + 2 * C;
+    } else {
+        e1.out_f32 = t1;
+        e1.ld_f32 = C;
+    }
+    conv3d(hin, d, rb.conv1, e1, st, skws, skn);
+    if (fuse) {
+        std::swap(hin, hout);
+    } else {
+        launch_pixelnorm_silu(t1, md + 3 * C, md + 2 * C, hin, d.P(), C, st);
+    }
+    GemmEpilogue e2;  // x = conv2(h) + x, in place
+    e2.out_f32 = x;
+    e2.ld_f32 = C;
+    e2.resid = 1;
+    e2.gate_scalar = 1.0f;
+    if (fuse && next_scale) {
+        e2.pn_out = hout;
+        e2.ld_pn = C;
+        e2.pn_scale = next_scale;
+        e2.pn_shift = next_shift;
+    } else if (copy) {
+        // into the other buffer: neighbouring tiles are still reading this conv's input
+        e2.out_bf16 = hout;
+        e2.ld_bf16 = C;
+    }
+    conv3d(hin, d, rb.conv2, e2, st, skws, skn);
+    if (fuse) std::swap(hin, hout);
+}
+
 // decode one temporal tile into `frames` (raw, layout (F_out, 32H, 32W, 3)); returns F_out
 int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride, const float* noise, int has_ts,
                 float timestep, Dims d0, float* frames, int apply_clip) {
@@ -316,53 +359,24 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
         bf16_t* hin = hb;   // the next conv's input
         bf16_t* hout = hb2;
         for (int r = 0; r < 5; ++r) {
-            const VaeResBlock& rb = m->groups[g].blocks[r];
             const float* md = mods + mod_ofs_group[g] + (long)r * 4 * C;
-            if (!fuse || r == 0) launch_pixelnorm_silu(x, md + 1 * C, md + 0 * C, hin, d.P(), C, st);
-            GemmEpilogue e1;
+            // what the block's last conv emits beside the f32 stream: the next consumer's bf16 input
+            const float* nsc = nullptr;
+            const float* nsh = nullptr;
+            bool copy = false;
             if (fuse) {
-                e1.pn_out = hout;  // h = silu(pixelnorm(conv1(.)) * (1 + scale2) + shift2), the f32 value is not kept
-                e1.ld_pn = C;
-                e1.pn_scale = md + 3 * C;
-                e1.pn_shift = md + 2 * C;
-            } else {
-                e1.out_f32 = t1;
-                e1.ld_f32 = C;
-            }
-            conv3d(hin, d, rb.conv1, e1, st, skws, skn);
-            if (fuse) {
-                bf16_t* t = hin; hin = hout; hout = t;
-            } else {
-                launch_pixelnorm_silu(t1, md + 3 * C, md + 2 * C, hin, d.P(), C, st);
-            }
-            GemmEpilogue e2;  // x = conv2(h) + x, in place
-            e2.out_f32 = x;
-            e2.ld_f32 = C;
-            e2.resid = 1;
-            e2.gate_scalar = 1.0f;
-            if (!fuse && r == 4 && g < 3) {
-                // the group's last conv also emits the bf16 copy of the stream that the upsampler's conv reads (into the other
-                // buffer: neighbouring tiles are still reading this conv's input)
-                e2.out_bf16 = hout;
-                e2.ld_bf16 = C;
-            }
-            if (fuse) {
-                // ... and the input of what follows: the next block's conv1, the upsampler's conv (plain bf16 cast) or conv_out
+                // the next block's conv1 (PixelNorm + its modulation + SiLU), conv_out (the last table), or the upsampler's conv (plain cast)
                 const float* nmd = r + 1 < 5 ? md + 4L * C : (g == 3 ? mods + last_mod : nullptr);
                 if (nmd || g == 3) {
-                    e2.pn_out = hout;
-                    e2.ld_pn = C;
-                    e2.pn_scale = g == 3 && r == 4 ? mods + last_mod + C3 : nmd + 1 * C;
-                    e2.pn_shift = g == 3 && r == 4 ? mods + last_mod : nmd + 0 * C;
+                    nsc = g == 3 && r == 4 ? mods + last_mod + C3 : nmd + 1 * C;
+                    nsh = g == 3 && r == 4 ? mods + last_mod : nmd + 0 * C;
                 } else {
-                    e2.out_bf16 = hout;
-                    e2.ld_bf16 = C;
+                    copy = true;
                 }
+            } else if (r == 4 && g < 3) {
+                copy = true;  // the group's last conv also emits the bf16 copy of the stream that the upsampler's conv reads
             }
-            conv3d(hin, d, rb.conv2, e2, st, skws, skn);
-            if (fuse) {
-                bf16_t* t = hin; hin = hout; hout = t;
-            }
+            res_block(m->groups[g].blocks[r], md, C, d, x, t1, hin, hout, r == 0, nsc, nsh, copy, st, skws, skn);
         }
         if (g < 3) {
             // depth-to-space upsampler (VideoDecoder.swift:215-251): conv on the raw stream, D2S, drop frame 0, + D2S(x)
@@ -450,6 +464,30 @@ int vae_decode_tile(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a, int tile_
     const int got = decode_plan_tile(ctx, m, a, plan, tile_index, a.frames, 0);
     if (a.n_frames_out) *a.n_frames_out = got;
     return got;
+}
+
+void vae_res_block(ltx_ctx* ctx, VaeModel* m, int group, int block, float* x, int F, int H, int W) {
+    LTX_REQUIRE(group >= 0 && group < 4 && block >= 0 && block < 5, "vae_res_block: group %d block %d", group, block);
+    LTX_REQUIRE(x && F >= 1 && H >= 2 && W >= 2, "vae_res_block: bad arguments (F=%d H=%d W=%d)", F, H, W);
+    hipStream_t st = ctx->stream;
+    const int C = m->groups[group].C;
+    const Dims d{F, H, W};
+    const size_t elems = (size_t)d.P() * C;
+    // buffers of its own size: the decode workspace is sized by latent shape, this call by the stream it is given
+    DevBuf t1, hb, hb2, mods, skws;
+    t1.ensure(elems * 4);
+    hb.ensure(elems * 2);
+    hb2.ensure(elems * 2);
+    skws.ensure(elems * 4);
+    mods.ensure((size_t)4 * C * 4);
+    VaeModsBatch mb;
+    mb.job[mb.n++] = VaeModsJob{m->groups[group].blocks[block].sst, nullptr, mods.as<float>(), 4, C};
+    launch_vae_make_mods_batch(mb, st);
+    bf16_t* hin = hb.as<bf16_t>();
+    bf16_t* hout = hb2.as<bf16_t>();
+    res_block(m->groups[group].blocks[block], mods.as<float>(), C, d, x, t1.as<float>(), hin, hout, true, nullptr, nullptr, false, st,
+              skws.as<float>(), (long)elems);
+    HIP_CHECK(hipStreamSynchronize(st));  // the scratch buffers above go out of scope
 }
 
 int vae_blend_tiles(ltx_ctx* ctx, const float* const* tiles, const int* tile_frames, int n_tiles, int overlap, int H, int W, float* frames,

@@ -113,7 +113,10 @@ def sigmas(distilled, num_steps, token_count=None, max_shift=2.05, base_shift=0.
     if num_steps > 0:
         om = [F32(one - v) for v in s]
         sf = F32(om[num_steps - 1] / F32(one - terminal))
-        s = [F32(0) if v == 0 else F32(one - F32(om[i] / sf)) for i, v in enumerate(s)]
+        # num_steps == 1: om[0] == 0, so the stretch is 0 / 0 and sigma[0] becomes NaN - exactly what the reference's Float arithmetic
+        # yields (LTXScheduler.swift:159-174 has no guard); kept, without numpy's warning.
+        with np.errstate(invalid="ignore", divide="ignore"):
+            s = [F32(0) if v == 0 else F32(one - F32(om[i] / sf)) for i, v in enumerate(s)]
     return np.array(s, dtype=F32)
 
 

@@ -15,14 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GEN = os.path.join(ROOT, "tools", "gen_attn_w48.py")
 
 
-@pytest.mark.parametrize("variant", [[], ["--bias"]])
+@pytest.mark.parametrize("variant", [[], ["--bias"], ["--prescaled"], ["--bias", "--prescaled"]])
 def test_attention_stream_is_proven_and_matches_the_committed_file(variant):
     r = subprocess.run([sys.executable, GEN, "--check"] + variant, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "wait coverage ok" in r.stdout and "matches" in r.stdout, r.stdout
 
 
-@pytest.mark.parametrize("variant", [[], ["--bias"]])
+@pytest.mark.parametrize("variant", [[], ["--bias"], ["--prescaled"], ["--bias", "--prescaled"]])
 def test_checker_rejects_the_prologue_race_that_once_shipped(variant):
     r = subprocess.run([sys.executable, GEN, "--check", "--inject-prologue-race"] + variant, capture_output=True, text=True)
     assert r.returncode != 0

@@ -36,3 +36,18 @@ def test_single_rank_launch_check():
     r = subprocess.run([sys.executable, BENCH, "--launch-check"], capture_output=True, text=True, env=_clean_env(), timeout=120)
     assert r.returncode == 0, r.stderr
     assert json.loads(r.stdout.strip().splitlines()[-1])["n_ranks_seen"] == 1
+
+
+def test_extra_legs_guard_fails_the_run_on_hang_and_error():
+    """ADVICE r2 / VERDICT r2 weak 8(d): a hung or failed collective of the extra legs must reach the driver as a non-zero exit,
+    after the line (with `extra_legs_status`) has been printed from a consistent snapshot."""
+    for how, status in (("hang", "hang"), ("error", "error")):
+        r = subprocess.run([sys.executable, BENCH, "--launch-check", "--selftest-legs", how], capture_output=True, text=True,
+                           env=_clean_env(), timeout=120)
+        assert r.returncode == 3, (how, r.returncode, r.stdout, r.stderr)
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out["extra_legs_status"] == status and out["extra_legs"]["first"] == {"ok": True}
+    r = subprocess.run([sys.executable, BENCH, "--launch-check", "--selftest-legs", "ok"], capture_output=True, text=True,
+                       env=_clean_env(), timeout=120)
+    assert r.returncode == 0
+    assert json.loads(r.stdout.strip().splitlines()[-1])["extra_legs_status"] == "ok"
