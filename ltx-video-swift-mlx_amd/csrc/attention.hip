@@ -735,6 +735,96 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     (void)smem;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 32x32x16 stream, 48 queries per wave (round 3): one 32-query block per wave + half of a block shared by a wave pair, split by
+// keys (tools/gen_attn_x32.py: layout, register map, pipeline). The LDS images and the K-row permutation are those of
+// attn_fwd_kernel above (the plain-HIP 32x32 kernel pins them through the parity tests); C++ only prepares per-lane offsets.
+// Takes unmasked launches with prescaled Q and Tk % 64 == 0; any Tq (rows past Tq are clamped on load and dropped by the O
+// descriptor).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int X32_Q = 192;
+constexpr int X32_LDS = 4 * STAGE_BYTES;
+constexpr int X32_XSZ = 0x2400;  // epilogue exchange area per wave (gen_attn_x32.py XSZ)
+#ifdef X32_STAMPS
+__device__ unsigned long long g_x32_stamps[8][16];
+#endif
+
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel_x32_asm(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int hwv = wave & 1, pair = wave >> 1;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const bf16_t* Qb = a.Q + (long)b * a.q_bstride + head * 128;
+    const bf16_t* Kb = a.K + (long)b * a.k_bstride + head * 128;
+    const bf16_t* Vb = a.Vt + (long)b * a.vt_bstride + (long)head * 128 * a.ldvt;
+    bf16_t* Ob = a.O + (long)b * a.o_bstride + head * 128;
+    const int q0 = blockIdx.x * X32_Q;
+    const int qi_own = q0 + 32 * wave + r, qi_sh = q0 + 128 + 32 * pair + r;
+    const int qoo = ((qi_own < a.Tq ? qi_own : a.Tq - 1) * (int)a.ldq + h * 8) * 2;
+    const int qos = ((qi_sh < a.Tq ? qi_sh : a.Tq - 1) * (int)a.ldq + h * 8) * 2;
+    const int oow = (qi_own * (int)a.ldo + h * 4) * 2, oos = (qi_sh * (int)a.ldo + h * 4) * 2;
+    // LDS-DMA pieces: wave w stages pieces w, w+4, w+8, w+12 of each image (1 KB each: 4 keys x 256 B / 8 d-rows x 128 B); the bank
+    // swizzle sits on the SOURCE address: physical chunk p of key k holds logical chunk p ^ (k & 15), of d-row d chunk p ^ ((d>>1)&7)
+    int ko[4], vo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kl = (wave + 4 * i) * 4 + (lane >> 4);
+        ko[i] = (kl * (int)a.ldk + (((lane & 15) ^ (kl & 15)) << 3)) * 2;
+        const int d = (wave + 4 * i) * 8 + (lane >> 3);
+        vo[i] = (d * (int)a.ldvt + (((lane & 7) ^ ((d >> 1) & 7)) << 3)) * 2;
+    }
+    // fragment addresses. K: MFMA row r reads key pi(r) (bits 2 and 3 swapped) of a 32-key half; half A = this wave's own (hw)
+    const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+    const int ksw = pr & 15;
+    const int kbase = pr * 256 + ((h ^ (ksw & 1)) << 4);
+    const int kbA = kbase + hwv * 8192, kbB = kbase + (1 - hwv) * 8192;
+    const int kx5 = (ksw >> 1) << 5;
+    const int vsw = (r >> 1) & 7;
+    int va[4];  // A0 A1 B0 B1: k-step (2 * half + s2) of the PV product
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int half = (i >> 1) ? 1 - hwv : hwv;
+        const int kst = 2 * half + (i & 1);
+        va[i] = K_TILE_BYTES + r * 128 + ((((kst << 1) + h) ^ vsw) << 4);
+    }
+    const int xout = wave * X32_XSZ + lane * 16, xin = (wave ^ 1) * X32_XSZ + lane * 16;
+    const uint32_t nt = (uint32_t)(a.Tk / KV_TILE);
+    const uint32_t oblo = (uint32_t)(uintptr_t)Ob, obhi = (uint32_t)((uintptr_t)Ob >> 32);
+    const uint32_t orec = (uint32_t)(((long)(a.Tq - 1) * a.ldo + 128) * 2);
+    const uint32_t kblo = (uint32_t)(uintptr_t)Kb, kbhi = (uint32_t)((uintptr_t)Kb >> 32);
+    const uint32_t vblo = (uint32_t)(uintptr_t)Vb, vbhi = (uint32_t)((uintptr_t)Vb >> 32);
+    const uint32_t krec = (uint32_t)(((long)(a.Tk - 1) * a.ldk + 128) * 2), vrec = (uint32_t)((long)128 * a.ldvt * 2);
+    const uint32_t ktb = (uint32_t)(KV_TILE * a.ldk * 2);
+    const uint32_t wlds = (uint32_t)wave * 1024u;
+    const uint32_t hws = (uint32_t)hwv;
+    const float tau = 8.0f;
+#ifdef X32_STAMPS
+    unsigned long long* dbg = (blockIdx.x == 1 && blockIdx.y == 3) ? &g_x32_stamps[wave][0] : &g_x32_stamps[4 + (wave & 3)][0];
+#endif
+    asm volatile(
+#ifdef X32_STAMPS
+#include "attention_x32_asm_stamps.inc"
+#else
+#include "attention_x32_asm.inc"
+#endif
+        :
+        : [qbase] "s"(Qb), [oblo] "s"(oblo), [obhi] "s"(obhi), [orec] "s"(orec), [kblo] "s"(kblo), [kbhi] "s"(kbhi), [vblo] "s"(vblo),
+          [vbhi] "s"(vbhi), [krec] "s"(krec), [vrec] "s"(vrec), [ktb] "s"(ktb), [nt] "s"(nt), [tau] "s"(tau), [wlds] "s"(wlds),
+          [hw] "s"(hws), [qoo] "v"(qoo), [qos] "v"(qos), [oow] "v"(oow), [oos] "v"(oos), [ko0] "v"(ko[0]), [ko1] "v"(ko[1]),
+          [ko2] "v"(ko[2]), [ko3] "v"(ko[3]), [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [kbA] "v"(kbA),
+          [kbB] "v"(kbB), [kx5] "v"(kx5), [vaA0] "v"(va[0]), [vaA1] "v"(va[1]), [vaB0] "v"(va[2]), [vaB1] "v"(va[3]), [xout] "v"(xout),
+          [xin] "v"(xin)
+#ifdef X32_STAMPS
+          , [dbg] "s"(dbg)
+#endif
+        :
+#include "attention_x32_clobbers.inc"
+    );
+    (void)smem;
+}
+
 }  // namespace
 
 void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
@@ -770,7 +860,7 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
         const long wgpp = (long)((a.Tq + PP_Q - 1) / PP_Q) * a.H * a.B;
         const double costpp = (double)((wgpp + 255) / 256) * 2.18;
         const char* impl = getenv("LTX_ATTN_IMPL");
-        const bool forced = impl && impl[0] >= '1' && impl[0] <= '4';
+        const bool forced = impl && impl[0] >= '1' && impl[0] <= '5';
         bool use_pp = forced ? impl[0] == '2' : (!a.bias && costpp < cost4);
         // the 48-query kernels cover unmasked launches whose query count is a multiple of 192 and key count a multiple of 256
         const bool w48_ok = !a.bias && a.Tq % W48_Q == 0 && a.Tk % (4 * KV_TILE) == 0;
@@ -788,6 +878,18 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
 #endif
         const long wg48 = (long)((a.Tq + W48_Q - 1) / W48_Q) * a.H * a.B;
         const double cost48 = (double)((wg48 + 255) / 256) * 1.25;
+        // the 32x32 stream: unmasked launches with prescaled Q and whole 64-key tiles; 1.0 us per tile step at T = 6144 (LTX_ATTN_IMPL=5)
+        const bool x32_ok = !a.bias && a.q_prescaled && a.Tk % KV_TILE == 0;
+        const double costx = (double)((wg48 + 255) / 256) * 1.0;
+        const bool use_x32 = (impl && impl[0] == '5') || (!forced && x32_ok && costx < cost4 && costx < costpp);
+        if (use_x32) {
+            LTX_REQUIRE(x32_ok, "attention: LTX_ATTN_IMPL=5 takes unmasked launches with prescaled Q and Tk %% 64 == 0 (Tq=%d Tk=%d)", a.Tq, a.Tk);
+            static PerDeviceOnce attr5_set;
+            attr5_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_x32_asm, hipFuncAttributeMaxDynamicSharedMemorySize, X32_LDS)); });
+            hipLaunchKernelGGL(attn_fwd_kernel_x32_asm, dim3((a.Tq + X32_Q - 1) / X32_Q, a.H, a.B), dim3(256), X32_LDS, stream, a);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         const bool asm_ok = !a.bias || a.Tk <= 4096;  // any Tq, Tk (ragged tails in the kernel); masked: the bias vector must fit 16 KB of LDS
         const bool use_asm = forced ? impl[0] == '4' : (asm_ok && cost48 < cost4 && cost48 < costpp);
         if (use_asm) {

@@ -14,7 +14,7 @@ ltx = importlib.import_module("ltx-video-swift-mlx_amd")
 
 SHAPES = [("self  T=1536 S=1536", 1, 1536, 1536, False), ("cross T=1536 S=1024", 1, 1536, 1024, False),
           ("cross+mask S=1024", 1, 1536, 1024, True), ("self B=2 T=1536", 2, 1536, 1536, False),
-          ("self T=6144 (hi-res)", 1, 6144, 6144, False)]
+          ("self T=6144 (hi-res)", 1, 6144, 6144, False), ("self T=9984 (201 fr)", 1, 9984, 9984, False)]
 
 
 def main():
@@ -25,7 +25,7 @@ def main():
     ctx = ltx.Context(0)
     H = 32
     for name, B, T, S, masked in SHAPES:
-        Q = torch.randn(B, T, H * 128, device="cuda").to(torch.bfloat16)
+        Q = (torch.randn(B, T, H * 128, device="cuda") * 0.1275).to(torch.bfloat16)  # (1/sqrt(128)) * log2(e) folded in
         K = torch.randn(B, S, H * 128, device="cuda").to(torch.bfloat16)
         Sp = (S + 63) // 64 * 64
         Vt = torch.randn(B, H * 128, Sp, device="cuda").to(torch.bfloat16)
@@ -37,7 +37,7 @@ def main():
         fl = 4.0 * B * H * T * S * 128
         n = 3 if args.once else 20
         line = f"{name:24s}"
-        impls = ["1", "2", "4", "0"]  # 1 = 4-wave kernel, 2 = ping-pong kernel, 0 = the launcher's choice
+        impls = ["1", "2", "4", "5", "0"]  # 1 = 4-wave, 2 = ping-pong, 4 = 48-query 16x16 assembly, 5 = 32x32 assembly, 0 = the launcher's choice
         best = {i: [] for i in impls}
         bad = set()
         for r in range(1 if args.once else args.rounds + 1):
@@ -46,14 +46,14 @@ def main():
                     continue
                 os.environ["LTX_ATTN_IMPL"] = impl
                 try:
-                    ctx.op_attention(Q, K, Vt, bias, H, O)
+                    ctx.op_attention(Q, K, Vt, bias, H, O, 0.0)  # prescaled Q, as the DiT launches it
                 except Exception:
                     bad.add(impl)  # this kernel does not take the shape (e.g. masked launches on the 48-query kernels)
                     continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(n):
-                    ctx.op_attention(Q, K, Vt, bias, H, O)
+                    ctx.op_attention(Q, K, Vt, bias, H, O, 0.0)  # prescaled Q, as the DiT launches it
                 e1.record()
                 torch.cuda.synchronize()
                 if r > 0 or args.once:
