@@ -64,3 +64,20 @@ def test_gemm_192x256_stream_is_proven_and_matches_the_committed_file():
 def test_gemm_192x256_checker_rejects_injected_races(flag, kind):
     r = subprocess.run([sys.executable, DTL, "--check", flag], capture_output=True, text=True)
     assert r.returncode != 0 and "WaitCoverageError: " + kind in r.stderr, r.stderr[-400:]
+
+
+X32 = os.path.join(ROOT, "tools", "gen_attn_x32.py")
+
+
+def test_attention_x32_stream_is_proven_and_matches_the_committed_file():
+    """The 32x32x16 stream keeps fragment reads in flight ACROSS the step barrier and ends every step with vmcnt(0): the proof is
+    what says that the reads issued ahead only ever touch slots that were visible one barrier earlier."""
+    r = subprocess.run([sys.executable, X32, "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "wait coverage ok" in r.stdout and "matches" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("flag,kind", [("--inject-raw-race", "RAW"), ("--inject-war-race", "WAR")])
+def test_attention_x32_checker_rejects_injected_races(flag, kind):
+    r = subprocess.run([sys.executable, X32, "--check", flag], capture_output=True, text=True)
+    assert r.returncode != 0 and "WaitCoverageError: " + kind in r.stderr, r.stderr[-400:]
