@@ -501,6 +501,28 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_kernel_pp(const AttnArgs a) {
 // to the compiler (which parks half the state in AGPRs and moves it back and forth): it exists to pin the layout with the
 // parity tests; the fast path is the assembly main loop generated from the same layout (attention_w48_asm.inc).
 // ---------------------------------------------------------------------------------------------------------------
+// Workgroup -> (query block, head, batch element) for the one-workgroup-per-CU kernels. Workgroups are dealt round-robin over the
+// 8 XCDs (blocks b and b + 8 share an L2: observed, for speed only), so with the plain (x, head, b) grid the query blocks of ONE head
+// land on eight different L2s and every XCD pulls every head's K / V^T through the fabric: 8 x the bytes. Here a 1-D grid is decoded
+// so that all query blocks of a head instance sit on one XCD (heads xcd, xcd + 8, ... per XCD), when the head count allows it.
+struct AttnBlock {
+    int x, head, b;
+};
+LTX_DEVFN AttnBlock attn_block(int nqb, int H, int B) {
+    const int id = blockIdx.x;
+    const int G = H * B;
+    int x, hb;
+    if ((G & 7) == 0) {
+        const int xcd = id & 7, j = id >> 3;
+        hb = xcd + 8 * (j / nqb);
+        x = j % nqb;
+    } else {
+        hb = id / nqb;
+        x = id % nqb;
+    }
+    return AttnBlock{x, hb % H, hb / H};
+}
+
 constexpr int W48_Q = 192;
 constexpr int W48_SLOTS = 4;
 constexpr int W48_LDS = W48_SLOTS * STAGE_BYTES;
@@ -631,12 +653,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c16 = lane & 15, g = lane >> 4;
-    const int head = blockIdx.y, b = blockIdx.z;
+    const AttnBlock blk = attn_block((a.Tq + W48_Q - 1) / W48_Q, a.H, a.B);
+    const int head = blk.head, b = blk.b;
     const bf16_t* Qb = a.Q + (long)b * a.q_bstride + head * 128;
     const bf16_t* Kb = a.K + (long)b * a.k_bstride + head * 128;
     const bf16_t* Vb = a.Vt + (long)b * a.vt_bstride + (long)head * 128 * a.ldvt;
     bf16_t* Ob = a.O + (long)b * a.o_bstride + head * 128;
-    const int q0 = blockIdx.x * W48_Q + wave * 48;
+    const int q0 = blk.x * W48_Q + wave * 48;
     const W48Lane L = w48_lane(lane, wave, a.ldk, a.ldvt);
     // any Tq / Tk: query rows past Tq read row Tq-1 and their stores fall outside the O descriptor; key rows past Tk read zeros
     // through the K descriptor and are masked to -inf in the last tile (tmask: bit kb*4+j = this lane's key (kb, j) is invalid)
@@ -673,7 +696,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     const int bvo = lane * 16;
     const int ba = W48_LDS + g * 32;
 #ifdef W48_STAMPS  // tools/ubench/attn_stamps.hip: per-wave s_memtime stamps of one tile step -> g_w48_stamps[wave][5]
-    unsigned long long* dbg = (blockIdx.x == 1 && blockIdx.y == 3) ? &g_w48_stamps[wave][0] : &g_w48_stamps[4 + (wave & 3)][0];
+    unsigned long long* dbg = (blk.x == 1 && head == 3) ? &g_w48_stamps[wave][0] : &g_w48_stamps[4 + (wave & 3)][0];
 #endif
 #define W48_OPERANDS                                                                                                                  \
     [qbase] "s"(Qb), [oblo] "s"(oblo), [obhi] "s"(obhi), [orec] "s"(orec), [rag] "s"(rag), [tmask] "v"(tmask), [kblo] "s"(kblo),         \
@@ -735,12 +758,15 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     (void)smem;
 }
 
+#ifdef LTX_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------
 // 32x32x16 stream, 48 queries per wave (round 3): one 32-query block per wave + half of a block shared by a wave pair, split by
 // keys (tools/gen_attn_x32.py: layout, register map, pipeline). The LDS images and the K-row permutation are those of
 // attn_fwd_kernel above (the plain-HIP 32x32 kernel pins them through the parity tests); C++ only prepares per-lane offsets.
 // Takes unmasked launches with prescaled Q and Tk % 64 == 0; any Tq (rows past Tq are clamped on load and dropped by the O
-// descriptor).
+// descriptor). MEASURED, NOT SELECTED (experiments build, LTX_ATTN_IMPL=5): its tile step takes 2071 cycles against 2428 of the
+// 16x16x32 stream, but the part holds 1.47 GHz under it against 1.86 GHz (32x32x16 MFMAs draw more per FLOP): 495 vs 459 us at
+// T = 6144, 40.2 vs 38.5 us at T = 1536, 3.65 vs 3.40 ms per DiT step (profiles/r03_attn_x32_stamps.txt).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int X32_Q = 192;
 constexpr int X32_LDS = 4 * STAGE_BYTES;
@@ -755,12 +781,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_x32_asm(const AttnArgs
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int hwv = wave & 1, pair = wave >> 1;
-    const int head = blockIdx.y, b = blockIdx.z;
+    const AttnBlock blk = attn_block((a.Tq + X32_Q - 1) / X32_Q, a.H, a.B);
+    const int head = blk.head, b = blk.b;
     const bf16_t* Qb = a.Q + (long)b * a.q_bstride + head * 128;
     const bf16_t* Kb = a.K + (long)b * a.k_bstride + head * 128;
     const bf16_t* Vb = a.Vt + (long)b * a.vt_bstride + (long)head * 128 * a.ldvt;
     bf16_t* Ob = a.O + (long)b * a.o_bstride + head * 128;
-    const int q0 = blockIdx.x * X32_Q;
+    const int q0 = blk.x * X32_Q;
     const int qi_own = q0 + 32 * wave + r, qi_sh = q0 + 128 + 32 * pair + r;
     const int qoo = ((qi_own < a.Tq ? qi_own : a.Tq - 1) * (int)a.ldq + h * 8) * 2;
     const int qos = ((qi_sh < a.Tq ? qi_sh : a.Tq - 1) * (int)a.ldq + h * 8) * 2;
@@ -801,7 +828,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_x32_asm(const AttnArgs
     const uint32_t hws = (uint32_t)hwv;
     const float tau = 8.0f;
 #ifdef X32_STAMPS
-    unsigned long long* dbg = (blockIdx.x == 1 && blockIdx.y == 3) ? &g_x32_stamps[wave][0] : &g_x32_stamps[4 + (wave & 3)][0];
+    unsigned long long* dbg = (blk.x == 1 && head == 3) ? &g_x32_stamps[wave][0] : &g_x32_stamps[4 + (wave & 3)][0];
 #endif
     asm volatile(
 #ifdef X32_STAMPS
@@ -824,6 +851,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_x32_asm(const AttnArgs
     );
     (void)smem;
 }
+
+#endif  // LTX_EXPERIMENTS
 
 }  // namespace
 
@@ -860,7 +889,7 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
         const long wgpp = (long)((a.Tq + PP_Q - 1) / PP_Q) * a.H * a.B;
         const double costpp = (double)((wgpp + 255) / 256) * 2.18;
         const char* impl = getenv("LTX_ATTN_IMPL");
-        const bool forced = impl && impl[0] >= '1' && impl[0] <= '5';
+        const bool forced = impl && impl[0] >= '1' && impl[0] <= '4';
         bool use_pp = forced ? impl[0] == '2' : (!a.bias && costpp < cost4);
         // the 48-query kernels cover unmasked launches whose query count is a multiple of 192 and key count a multiple of 256
         const bool w48_ok = !a.bias && a.Tq % W48_Q == 0 && a.Tk % (4 * KV_TILE) == 0;
@@ -878,18 +907,18 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
 #endif
         const long wg48 = (long)((a.Tq + W48_Q - 1) / W48_Q) * a.H * a.B;
         const double cost48 = (double)((wg48 + 255) / 256) * 1.25;
-        // the 32x32 stream: unmasked launches with prescaled Q and whole 64-key tiles; 1.0 us per tile step at T = 6144 (LTX_ATTN_IMPL=5)
-        const bool x32_ok = !a.bias && a.q_prescaled && a.Tk % KV_TILE == 0;
-        const double costx = (double)((wg48 + 255) / 256) * 1.0;
-        const bool use_x32 = (impl && impl[0] == '5') || (!forced && x32_ok && costx < cost4 && costx < costpp);
-        if (use_x32) {
+#ifdef LTX_EXPERIMENTS
+        // the 32x32 stream (LTX_ATTN_IMPL=5 only: measured slower than the 16x16 stream on every BASELINE shape)
+        if (impl && impl[0] == '5') {
+            const bool x32_ok = !a.bias && a.q_prescaled && a.Tk % KV_TILE == 0;
             LTX_REQUIRE(x32_ok, "attention: LTX_ATTN_IMPL=5 takes unmasked launches with prescaled Q and Tk %% 64 == 0 (Tq=%d Tk=%d)", a.Tq, a.Tk);
             static PerDeviceOnce attr5_set;
             attr5_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_x32_asm, hipFuncAttributeMaxDynamicSharedMemorySize, X32_LDS)); });
-            hipLaunchKernelGGL(attn_fwd_kernel_x32_asm, dim3((a.Tq + X32_Q - 1) / X32_Q, a.H, a.B), dim3(256), X32_LDS, stream, a);
+            hipLaunchKernelGGL(attn_fwd_kernel_x32_asm, dim3(((a.Tq + X32_Q - 1) / X32_Q) * a.H * a.B), dim3(256), X32_LDS, stream, a);
             HIP_CHECK(hipGetLastError());
             return;
         }
+#endif
         const bool asm_ok = !a.bias || a.Tk <= 4096;  // any Tq, Tk (ragged tails in the kernel); masked: the bias vector must fit 16 KB of LDS
         const bool use_asm = forced ? impl[0] == '4' : (asm_ok && cost48 < cost4 && cost48 < costpp);
         if (use_asm) {
@@ -901,7 +930,7 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS + 16384));
             });
-            const dim3 grid4((a.Tq + W48_Q - 1) / W48_Q, a.H, a.B);
+            const dim3 grid4(((a.Tq + W48_Q - 1) / W48_Q) * a.H * a.B);
             if (a.bias && a.q_prescaled)
                 hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<true, true>), grid4, dim3(256), W48_LDS + 16384, stream, a);
             else if (a.bias)

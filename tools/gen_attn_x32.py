@@ -351,50 +351,79 @@ class Gen:
         return stream, []
 
     def stamp(self, i):
+        """--stamps build with X32_PART_STAMPS=1: part boundaries of the slot-0 step (each stamp drains the LDS queue: it distorts)."""
+        if self.stamps and os.environ.get("X32_PART_STAMPS"):
+            self.e(f"s_memtime s[{84 + 2 * i}:{85 + 2 * i}]")
+            self.e("s_waitcnt lgkmcnt(0)")
+
+    def kstamp(self, i):
+        """--stamps build: whole-kernel stamps (start, loop entered, loop left, stores issued) in s[76+2i : 77+2i]."""
         if self.stamps:
-            self.e(f"s_memtime s[{64 + 2 * i}:{65 + 2 * i}]")
+            self.e(f"s_memtime s[{76 + 2 * i}:{77 + 2 * i}]")
+            self.e("s_waitcnt lgkmcnt(0)")
 
     # ------------------------------------------------------------------------------------------------------------
     # one tile step
     # ------------------------------------------------------------------------------------------------------------
+    def step_fillers(self, slot, cur, nxt):
+        """Everything of a step that is not an MFMA or a fragment read, as (target gap, latest gap, [instructions]).
+        Gap g = behind the step's g-th MFMA (0..47: 24 of K.Q^T, 16 of V^T.P over the own key half, 8 over the other half).
+
+        One exponential per gap is what a 32-cycle MFMA hides beside a few cheap instructions (v_exp_f32 holds the transcendental
+        unit for 16 cycles): the 48 exponentials of S(t) are laid over gaps 0..~41 in the order the PV product consumes them (own A
+        k-step 0, shared 0, own A 1, shared 1, own B 0, own B 1), each pair's row-sum adds and bf16 pack one gap behind it. A P
+        fragment must be complete before the first MFMA that reads it: that MFMA's index - 1 is the group's latest gap."""
+        items = []
+        squeeze = float(os.environ.get("X32_EXP_SQUEEZE", "0.875"))   # gaps per exponential
+        groups = [(OWN_A, 0, PF_OWN_A, L_OWN, 23), (SH, 0, PF_SH, L_SH, 24), (OWN_A, 1, PF_OWN_A, L_OWN, 31), (SH, 1, PF_SH, L_SH, 32),
+                  (OWN_B, 0, PF_OWN_B, L_OWN, 39), (OWN_B, 1, PF_OWN_B, L_OWN, 43)]
+        if "noexp" not in ABL:
+            i = 0
+            for blk, s2, pf, lreg, last in groups:
+                r = cur + blk + 8 * s2
+                for j in range(0, 8, 2):
+                    t0, t1 = i * squeeze, (i + 1) * squeeze
+                    items.append((t0, last - 1, [f"v_exp_f32 v{r + j}, v{r + j}"]))
+                    items.append((t1, last - 1, [f"v_exp_f32 v{r + j + 1}, v{r + j + 1}"]))
+                    post = float(os.environ.get("X32_POST_LAG", "1.0"))
+                    items.append((t1 + post, last, [f"v_add_f32 v{lreg}, v{lreg}, v{r + j}"]))
+                    items.append((t1 + post + 0.01, last, [f"v_add_f32 v{lreg}, v{lreg}, v{r + j + 1}"]))
+                    items.append((t1 + post + 0.02, last, [f"v_cvt_pk_bf16_f32 v{pf + 4 * s2 + j // 2}, v{r + j}, v{r + j + 1}"]))
+                    i += 2
+        if "nodma" not in ABL:
+            d0, dstep = float(os.environ.get("X32_DMA_FIRST", "2")), float(os.environ.get("X32_DMA_STEP", "4"))
+            for k, grp in enumerate(self.stage((slot + 3) & 3)):
+                items.append((d0 + dstep * k + 0.5, 40, grp))
+        mx = self.sm_max_groups(nxt)
+        m0 = float(os.environ.get("X32_MAX_FIRST", "28"))   # S(t+1) is complete behind MFMA 23; four MFMAs of distance to its readers
+        for k, g in enumerate(mx):
+            items.append((max(28.0, m0 + k * (47.9 - m0) / len(mx)), 47, g))
+        return items
+
     def step(self, slot, cur, nxt, uid):
         e = self.e
         e(f"; ---------------- tile step, ring slot {slot} ----------------")
         st = self.stamp if slot == 0 else (lambda i: None)
         st(0)
-        allst = self.step_stream(nxt, slot)
-        part_a, rest = self.split_stream(allst, 24)
-        part_b1, part_b2 = self.split_stream(rest, 16)
-        dma = [] if "nodma" in ABL else self.stage((slot + 3) & 3)
-        ga = self.sm_exp_groups(cur, OWN_A, PF_OWN_A, L_OWN)
-        gs = self.sm_exp_groups(cur, SH, PF_SH, L_SH)
-        fa = []
-        while ga or gs:   # own A and shared interleaved: two independent dependency chains
-            if ga:
-                fa.append(ga.pop(0))
-            if gs:
-                fa.append(gs.pop(0))
-        n_dma_a = int(os.environ.get("X32_DMA_A", "3"))
-        # LDS-DMA of tile t+3 early in the step (it must have landed by the step's closing vmcnt(0)): spread through part A
-        if dma:
-            stride = max(1, len(fa) // (n_dma_a + 1))
-            for k in range(n_dma_a):
-                fa.insert((k + 1) * stride + k, dma.pop(0))
-        self.spread(part_a, fa)
-        st(1)
-        fb = self.sm_exp_groups(cur, OWN_B, PF_OWN_B, L_OWN)
-        if dma:
-            stride = max(1, len(fb) // (len(dma) + 1))
-            k = 0
-            while dma:
-                fb.insert(min(len(fb), (k + 1) * stride + k), dma.pop(0))
-                k += 1
-        mx = self.sm_max_groups(nxt)
-        n_mx_b1 = int(os.environ.get("X32_MAX_B1", "8"))
-        # the maxima read S(t+1), whose last MFMA is the last one of part A: not within the first four MFMAs of part B1
-        self.spread(part_b1, fb + mx[:n_mx_b1], skip=4)
-        st(2)
-        self.spread(part_b2, mx[n_mx_b1:])
+        stream = self.step_stream(nxt, slot)
+        items = sorted(self.step_fillers(slot, cur, nxt), key=lambda it: it[0])
+        by_gap = {}
+        for t, last, grp in items:
+            g = min(int(t), last, 47)
+            by_gap.setdefault(g, []).append(grp)
+        n = -1
+        for kind, text in stream:
+            e(text)
+            if kind == "mfma":
+                n += 1
+                for grp in by_gap.get(n, []):
+                    for ins in grp:
+                        e(ins)
+                if n == 23:
+                    st(1)
+                if n == 39:
+                    st(2)
+        assert n == 47
         # tile t was the last one: leave before the reference check of a tile that does not exist
         e("s_sub_u32 s46, s46, 1")
         e("s_cmp_eq_u32 s46, 0")
@@ -412,6 +441,7 @@ class Gen:
     # ------------------------------------------------------------------------------------------------------------
     def build(self):
         e = self.e
+        self.kstamp(0)
         e("; ---- descriptors, constants ----")
         for i, v in enumerate(("%[kblo]", "%[kbhi]", "%[krec]", "0x00020000")):
             e(f"s_mov_b32 s{36 + i}, {v}")
@@ -475,14 +505,34 @@ class Gen:
         e("s_barrier")
         for r in self.first_reads(1):   # the first step's K fragments (tile 1), seven ahead
             e(r)
+        self.kstamp(1)
         e("10:")
+        if self.stamps:   # s[64:65] = start of this loop iteration (4 tile steps), s[66:67] = start of the previous one
+            e("s_mov_b64 s[66:67], s[64:65]")
+            e("s_memtime s[64:65]")
+            e("s_waitcnt lgkmcnt(0)")
         self.step(0, SBUF[0], SBUF[1], 11)
         self.step(1, SBUF[1], SBUF[0], 12)
         self.step(2, SBUF[0], SBUF[1], 13)
         self.step(3, SBUF[1], SBUF[0], 14)
         e("s_branch 10b")
         e("30:")
+        self.kstamp(2)
         self.epilogue()
+        if self.stamps:
+            e("s_waitcnt vmcnt(0)")
+            self.kstamp(3)
+            T = SBUF[0]
+            for i in range(4):     # s[64:67] loop-iteration stamps
+                e(f"v_mov_b32 v{T + i}, s{64 + i}")
+            for i in range(8):     # s[76:83] kernel stamps
+                e(f"v_mov_b32 v{T + 4 + i}, s{76 + i}")
+            for i in range(10):    # s[84:93] part stamps
+                e(f"v_mov_b32 v{T + 12 + i}, s{84 + i}")
+            e(f"v_mov_b32 v{T + 24}, 0")
+            for i in range(11):
+                e(f"global_store_dwordx2 v{T + 24}, v[{T + 2 * i}:{T + 2 * i + 1}], %[dbg] offset:{i * 8}")
+            e("s_waitcnt vmcnt(0)")
         return self.lines
 
     def epilogue(self):
@@ -717,6 +767,9 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     csrc = os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc")
     name = "attention_x32_asm" + ("_stamps" if stamps else "") + ".inc"
+    if stamps:
+        for i in range(10):
+            lines.insert(0, f"s_mov_b32 s{84 + i}, 0")
     out = os.path.join(csrc, name)
     if "--inject-raw-race" in sys.argv:
         # leave the LDS-DMA of the step in flight across its barrier: the next step but one reads a slot that may be empty
@@ -737,7 +790,10 @@ def main():
         sys.exit(0 if same or stamps else 4)
     with open(out, "w") as f:
         f.write("".join(body))
-    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in range(36, 76)] + ["m0", "vcc", "scc", "memory"]
+    if stamps:
+        print(f"{len(lines)} lines -> {os.path.normpath(out)} (stamps build)")
+        return
+    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in range(36, 96)] + ["m0", "vcc", "scc", "memory"]
     with open(os.path.join(csrc, "attention_x32_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_x32.py - do not edit. Registers the assembly body assigns by hand.\n")
         for i in range(0, len(clob), 12):

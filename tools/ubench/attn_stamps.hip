@@ -52,6 +52,32 @@ int main() {
         return 0;
     }
 #endif
+#ifdef X32_STAMPS   // -DX32_STAMPS: the 32x32 stream (tools/gen_attn_x32.py --stamps), ATTN_PS is implied
+    a.q_prescaled = 1;
+    setenv("LTX_ATTN_IMPL", "5", 1);
+    for (int it = 0; it < 3; ++it) launch_attention(a, 0);
+    hipDeviceSynchronize();
+    {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        for (int it = 0; it < 20; ++it) launch_attention(a, 0);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("T = %d: %.1f us per launch (stamps build)\n", T, ms * 1000 / 20);
+        unsigned long long st[8][16];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_x32_stamps), sizeof(st));
+        for (int w = 0; w < 4; ++w) {
+            printf("wave %d: last full loop iteration (4 tile steps) %llu cycles = %llu per step | prologue %llu, tile loop %llu (%d tiles: %llu per tile), epilogue %llu",
+                   w, st[w][0] - st[w][1], (st[w][0] - st[w][1]) / 4, st[w][3] - st[w][2], st[w][4] - st[w][3], T / 64,
+                   (st[w][4] - st[w][3]) / (unsigned long long)(T / 64), st[w][5] - st[w][4]);
+            if (st[w][7]) printf(" | parts A %llu B1 %llu B2 %llu check+wait+barrier %llu", st[w][7] - st[w][6], st[w][8] - st[w][7], st[w][9] - st[w][8], st[w][10] - st[w][9]);
+            printf("\n");
+        }
+        return 0;
+    }
+#endif
 #ifdef PP_STAMPS
     for (int it = 0; it < 3; ++it) launch_attention(a, 0);
     hipDeviceSynchronize();
