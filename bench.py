@@ -215,6 +215,8 @@ def main():
     ap.add_argument("--mode", choices=("replica", "cfg-pair", "sp", "vae-tiles"), default="replica")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--vae-to", choices=("all", "root"), default="all",
+                    help="--mode vae-tiles: raw tiles broadcast to every rank (all) or sent once to rank 0, which blends (root)")
     ap.add_argument("--no-aux", action="store_true", help="skip the once-per-prompt legs (text-embedding connector, VAE encoder)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-launch HIP events in the timed region")
     ap.add_argument("--extra-legs", action="store_true",
@@ -566,7 +568,9 @@ def run_vae_tiles(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side
         dmod.bootstrap(ctx, side)
 
     def step(i):
-        if world > 1:
+        if world > 1 and args.vae_to == "root":
+            ctx.vae_decode_gathered_dev(lat, F, H, W, frames if rank == 0 else None, root=0, tile=tile, overlap=ov)
+        elif world > 1:
             ctx.vae_decode_sharded_dev(lat, F, H, W, frames, tile=tile, overlap=ov)
         else:
             ctx.vae_decode_dev(lat, F, H, W, frames, tile=tile, overlap=ov)
@@ -574,16 +578,20 @@ def run_vae_tiles(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side
     el = timed(torch, dist, world, dev, step, args.warmup, args.steps)
     out = base_line(args, world, el, args.steps / el, "strong",
                     f"VAE decode of 26 latent frames at 768x512, temporal tiles {plan} (tile 8, overlap 1) -> {nf} frames, tiles "
-                    f"round-robin over {world} rank(s), raw tiles broadcast, blend + clip on every rank",
+                    f"round-robin over {world} rank(s), raw tiles " + ("broadcast, blend + clip on every rank" if args.vae_to == "all" else
+                                                                         "sent once to rank 0, which blends and clips") +
+                    f"; the plan has {len(plan)} tiles (VideoDecoder.swift:534-548), so at most {len(plan)} ranks decode",
                     {"latent": [F, H, W], "tiles": len(plan), "frames": nf})
     out["metric"] = "tiled VAE decodes/sec, 768x512x201 (BASELINE configs[4])"
     out["unit"] = "decodes/s"
     out["decode_ms"] = out.pop("ms_per_step")
     if world > 1:
-        chk = torch.stack([frames.double().sum()]).to(dev)
-        allv = [torch.empty_like(chk) for _ in range(world)]
-        dist.all_gather(allv, chk)
-        out["rank_frames_identical"] = bool(all(torch.equal(allv[0], v) for v in allv))
+        if args.vae_to == "all":
+            chk = torch.stack([frames.double().sum()]).to(dev)
+            allv = [torch.empty_like(chk) for _ in range(world)]
+            dist.all_gather(allv, chk)
+            out["rank_frames_identical"] = bool(all(torch.equal(allv[0], v) for v in allv))
+        out["busy_ranks"] = min(world, len(plan))
         ctx.dist_shutdown()
     return out
 

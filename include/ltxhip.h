@@ -415,6 +415,15 @@ int ltx_vae_blend_tiles_dev(ltx_ctx* ctx, const float* const* tiles, const int* 
 int ltx_vae_decode_sharded_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
                                const float* noise, int tile, int overlap, float* frames_out, long frames_cap,
                                int* n_frames_out);
+/* The gather form of the same: every raw tile travels ONCE, from its owner to rank `root` (ncclSend / ncclRecv over xGMI), and only
+ * `root` blends, clips and fills frames_out (bit-identical to ltx_vae_decode_dev); the other ranks pass frames_out = NULL and get the
+ * frame count. This is what a host that exports one video wants (decodeVideo returns ONE tensor, VideoDecoder.swift:466-507): with
+ * the 4 tiles of 768x512x201 (tile 8, overlap 1 - the plan is fixed by VideoDecoder.swift:534-548 and must not be changed to fill
+ * more GPUs: it decides the blended frames) on 8 ranks, 0.8 GB reach one rank instead of 1 GB reaching all eight. Every rank of the
+ * group must call it with the same arguments. */
+int ltx_vae_decode_gathered_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
+                                const float* noise, int tile, int overlap, int root, float* frames_out, long frames_cap,
+                                int* n_frames_out);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Live kernel timing (replaces the reference's wall-clock GenerationTimings, LTXVideo.swift:255-297, with HIP

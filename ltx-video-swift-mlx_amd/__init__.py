@@ -413,6 +413,13 @@ class Context:
                                                 _ptr(noise), tile, overlap, _ptr(frames), frames.numel(), C.byref(n)))
         return n.value
 
+    def vae_decode_gathered_dev(self, latent, F, H, W, frames, root=0, timestep=None, noise=None, tile=0, overlap=1):
+        """Tiles decoded round-robin by the group's ranks, raw tiles sent to `root` only, which blends; frames=None elsewhere."""
+        n = C.c_int()
+        self._ck(lib.ltx_vae_decode_gathered_dev(self._h, _ptr(latent), F, H, W, int(timestep is not None), float(timestep or 0.0),
+                                                 _ptr(noise), tile, overlap, root, _ptr(frames), 0 if frames is None else frames.numel(), C.byref(n)))
+        return n.value
+
     def vae_decode_tile_dev(self, latent, F, H, W, tile, overlap, tile_index, out, timestep=None, noise=None):
         """RAW frames (pre-blend, pre-clip) of one tile of the plan -> out; returns its frame count."""
         n = C.c_int()

@@ -112,6 +112,7 @@ SIGNATURES = {
     "ltx_vae_res_block_dev": (_i, [_vp, _i, _i, _vp, _i, _i, _i]),
     "ltx_vae_blend_tiles_dev": (_i, [_vp, C.POINTER(_vp), _ip, _i, _i, _i, _i, _vp, _l, _ip]),
     "ltx_vae_decode_sharded_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _l, _ip]),
+    "ltx_vae_decode_gathered_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp, _l, _ip]),
     "ltx_dit_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ltx_dit_forward_tokens": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ltx_dit_forward_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _vp]),

@@ -633,6 +633,24 @@ int ltx_vae_decode_sharded_dev(ltx_ctx* ctx, const float* latent, int F, int H, 
     });
 }
 
+int ltx_vae_decode_gathered_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
+                                const float* noise, int tile, int overlap, int root, float* frames_out, long frames_cap,
+                                int* n_frames_out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        VaeModel* m = need_vae(ctx);
+        LTX_REQUIRE(ctx->dist, "ltx_vae_decode_gathered_dev: no group on this context (ltx_dist_init / ltx_dist_set_transport)");
+        VaeDecodeArgs a;
+        a.latent = latent; a.F = F; a.H = H; a.W = W;
+        a.has_timestep = has_timestep; a.timestep = timestep; a.noise = noise;
+        a.tile = tile; a.overlap = overlap;
+        a.frames = frames_out; a.frames_cap = frames_cap; a.n_frames_out = n_frames_out;
+        a.shard = 2;
+        a.root = root;
+        vae_decode(ctx, m, a);
+    });
+}
+
 int ltx_vae_decode_tile_dev(ltx_ctx* ctx, const float* latent, int F, int H, int W, int has_timestep, float timestep,
                             const float* noise, int tile, int overlap, int tile_index, float* tile_out, long tile_cap,
                             int* n_frames_out) {

@@ -18,6 +18,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -46,6 +48,8 @@ Rccl& rccl() {
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
         r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     });
     if (!r.error.empty()) LTX_THROW(LTXS_HIP_ERROR, "%s", r.error.c_str());
@@ -60,11 +64,16 @@ Rccl& rccl() {
 
 void reset(ltx_ctx* ctx) {
     if (!ctx->dist) return;
-    if (ctx->dist->comm) {
+    DistState* d = ctx->dist;
+    if (d->side) (void)hipStreamSynchronize(d->side);
+    if (d->comm) {
         (void)hipStreamSynchronize(ctx->stream);
-        (void)rccl().CommDestroy((ncclComm_t)ctx->dist->comm);
+        (void)rccl().CommDestroy((ncclComm_t)d->comm);
     }
-    delete ctx->dist;
+    for (hipEvent_t e : d->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (d->side) (void)hipStreamDestroy(d->side);
+    delete d;
     ctx->dist = nullptr;
 }
 
@@ -102,13 +111,40 @@ void dist_set_transport(ltx_ctx* ctx, int rank, int world, ltx_dist_gather_fn ga
 
 void dist_shutdown(ltx_ctx* ctx) { reset(ctx); }
 
-void dist_allgather(ltx_ctx* ctx, const void* send, void* recv, long bytes) {
+bool dist_can_overlap(const ltx_ctx* ctx) { return ctx->dist && ctx->dist->comm; }
+
+hipStream_t dist_side_stream(ltx_ctx* ctx) {
+    DistState* d = ctx->dist;
+    LTX_REQUIRE(d, "multi-GPU call without ltx_dist_init / ltx_dist_set_transport on this context");
+    if (!d->side) {
+        HIP_CHECK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+        for (hipEvent_t& e : d->ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    return d->side;
+}
+
+void dist_fork(ltx_ctx* ctx, int ev) {
+    hipStream_t side = dist_side_stream(ctx);
+    HIP_CHECK(hipEventRecord(ctx->dist->ev[ev], ctx->stream));
+    HIP_CHECK(hipStreamWaitEvent(side, ctx->dist->ev[ev], 0));
+}
+
+void dist_join(ltx_ctx* ctx, int ev) {
+    hipStream_t side = dist_side_stream(ctx);
+    HIP_CHECK(hipEventRecord(ctx->dist->ev[ev], side));
+    HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->dist->ev[ev], 0));
+}
+
+void dist_allgather(ltx_ctx* ctx, const void* send, void* recv, long bytes) { dist_allgather_on(ctx, send, recv, bytes, ctx->stream); }
+
+void dist_allgather_on(ltx_ctx* ctx, const void* send, void* recv, long bytes, hipStream_t stream) {
     DistState* d = ctx->dist;
     LTX_REQUIRE(d, "multi-GPU call without ltx_dist_init / ltx_dist_set_transport on this context");
     LTX_REQUIRE(send && recv && bytes > 0, "dist_allgather: bad arguments");
+    LTX_REQUIRE(stream == ctx->stream || d->comm, "dist_allgather: only the native transport can run beside the context's stream");
     d->n_collectives++;
     if (d->comm) {
-        RCCL_CHECK(rccl().AllGather(send, recv, (size_t)bytes, ncclUint8, (ncclComm_t)d->comm, ctx->stream));
+        RCCL_CHECK(rccl().AllGather(send, recv, (size_t)bytes, ncclUint8, (ncclComm_t)d->comm, stream));
     } else if (d->cb) {
         // a failing host transport must stop the call: carrying on would hand unfilled buffers to the next kernel while the peer
         // rank waits inside its collective
@@ -134,4 +170,27 @@ void dist_broadcast(ltx_ctx* ctx, void* buf, long bytes, int root) {
     dist_allgather(ctx, buf, d->stage.p, bytes);
     if (d->rank != root)
         HIP_CHECK(hipMemcpyAsync(buf, (const char*)d->stage.p + (size_t)root * bytes, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+void dist_send_to_root(ltx_ctx* ctx, void* buf, long bytes, int owner, int root) {
+    DistState* d = ctx->dist;
+    LTX_REQUIRE(d, "multi-GPU call without ltx_dist_init / ltx_dist_set_transport on this context");
+    LTX_REQUIRE(buf && bytes > 0 && owner >= 0 && owner < d->world && root >= 0 && root < d->world, "dist_send_to_root: bad arguments");
+    if (d->world == 1 || owner == root) return;
+    if (d->comm) {
+        // point to point over xGMI: the bytes cross one link once (a broadcast would put them on every rank)
+        if (d->rank == owner) {
+            d->n_collectives++;
+            RCCL_CHECK(rccl().Send(buf, (size_t)bytes, ncclUint8, root, (ncclComm_t)d->comm, ctx->stream));
+        } else if (d->rank == root) {
+            d->n_collectives++;
+            RCCL_CHECK(rccl().Recv(buf, (size_t)bytes, ncclUint8, owner, (ncclComm_t)d->comm, ctx->stream));
+        }
+        return;
+    }
+    // host transport (tests): it only has an all-gather, in which every rank must take part; the root keeps the owner's slot
+    d->stage.ensure((size_t)bytes * d->world);
+    dist_allgather(ctx, buf, d->stage.p, bytes);
+    if (d->rank == root)
+        HIP_CHECK(hipMemcpyAsync(buf, (const char*)d->stage.p + (size_t)owner * bytes, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
 }

@@ -21,6 +21,10 @@ struct DistState {
     ltx_dist_gather_fn cb = nullptr;
     void* cb_user = nullptr;
     DevBuf stage;  // broadcast over the host transport = all-gather into this, then copy the root's slot
+    // second stream + events of the native transport: a collective runs beside the kernels that do not need its result
+    // (dist_fork / dist_join order it against the context's stream; created on first use)
+    hipStream_t side = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     long n_collectives = 0;  // collectives enqueued so far (reported by ltx_dist_info; lets tests see the exchange happen)
 };
 
@@ -35,3 +39,14 @@ inline int dist_rank(const ltx_ctx* ctx) { return ctx->dist ? ctx->dist->rank : 
 void dist_allgather(ltx_ctx* ctx, const void* send, void* recv, long bytes);
 // in place on every rank; root's bytes win
 void dist_broadcast(ltx_ctx* ctx, void* buf, long bytes, int root);
+// `buf` of rank `owner` -> `buf` of rank `root` (same address range on both; every other rank's buffer is untouched). Native
+// transport: one ncclSend / ncclRecv pair, ranks that are neither owner nor root do nothing. Every rank must call it.
+void dist_send_to_root(ltx_ctx* ctx, void* buf, long bytes, int owner, int root);
+// Overlap (native transport only; dist_can_overlap): dist_fork(ev) makes the side stream wait for everything enqueued on the
+// context's stream so far, dist_allgather_on(..., dist_side_stream()) enqueues the collective there, dist_join(ev) makes the
+// context's stream wait for the side stream. ev = 0..3 (one event object per fork / join site; re-recorded every use).
+bool dist_can_overlap(const ltx_ctx* ctx);
+hipStream_t dist_side_stream(ltx_ctx* ctx);
+void dist_fork(ltx_ctx* ctx, int ev);
+void dist_join(ltx_ctx* ctx, int ev);
+void dist_allgather_on(ltx_ctx* ctx, const void* send, void* recv, long bytes, hipStream_t stream);

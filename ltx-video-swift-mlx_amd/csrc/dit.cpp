@@ -1,6 +1,7 @@
 // dit.cpp - see dit.h. One forward = reference LTXTransformer.callAsFunction (LTXTransformer.swift:235-486).
 #include "dit.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include "attention.h"
@@ -345,6 +346,9 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             dist_allgather(ctx, send, recv, bytes);
         }
     };
+    // Self-test hook: LTX_SP_SELFTEST=1 sends a ONE-rank group of the native transport through the sequence-parallel branch (gathers of
+    // one part, side stream, events): the only way to execute that code where a single GPU is all there is. Output bits == NW = 1 path.
+    const bool sp = NW > 1 || (B == 1 && !a.sp_gather && dist_can_overlap(ctx) && dist_world(ctx) == 1 && getenv("LTX_SP_SELFTEST") != nullptr);
     const int T = Tfull / NW;            // rows this rank evaluates
     const int tok0 = a.sp_rank * T;      // first global token of this rank (NW == 1: 0)
     LTX_REQUIRE(B >= 1 && B <= 8 && T >= 1 && a.S >= 1, "dit_forward: bad shapes B=%d T=%d S=%d", B, T, a.S);
@@ -381,7 +385,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     const int TfullPad = ((Tfull + 63) / 64) * 64;
     bf16_t* k_full = k;
     bf16_t* vt_full = vt;
-    if (NW > 1) {
+    if (sp) {
         m->ws_sp_k.ensure((size_t)Tfull * D * 2);
         if (m->ws_sp_vt.ensure((size_t)D * TfullPad * 2)) HIP_CHECK(hipMemsetAsync(m->ws_sp_vt.p, 0, m->ws_sp_vt.bytes, st));
         m->ws_sp_vtg.ensure((size_t)NW * D * T * 2);
@@ -419,13 +423,26 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
         const float* ml = mod + (long)l * 6 * D;  // rows: 0 shift_msa 1 scale_msa 2 gate_msa 3 shift_mlp 4 scale_mlp 5 gate_mlp
         if (!blk.skip_attn) {
             launch_norm_mod(x, D, ml + 1 * D, ml + 0 * D, mod_bs, T, xn, D, (int)rows, D, LTX_NORM_RMS, eps, l == 0 ? 1 : 0, st, rmap);
+            // Sequence parallelism on the native transport: the V^T gather (and its interleave) runs on the side stream under
+            // the q|k projection and its norm + RoPE pass; only the K gather stays on the critical path. Same kernels, same
+            // operands, same order of every reduction: the bits do not depend on which stream carried a collective.
+            const bool overlap = sp && !a.sp_gather && dist_can_overlap(ctx);
+            if (sp) {
+                gemm_vt(xn, D, T, blk.v1, vt, T, st, sk);  // V^T of the local tokens, dense [D][T]
+                if (overlap) {
+                    hipStream_t side = dist_side_stream(ctx);
+                    dist_fork(ctx, 0);
+                    dist_allgather_on(ctx, vt, m->ws_sp_vtg.p, (long)D * T * 2, side);
+                    launch_sp_vt_interleave(m->ws_sp_vtg.as<bf16_t>(), vt_full, NW, D, T, TfullPad, side);
+                }
+            }
             GemmEpilogue eqk;
             eqk.out_f32 = qk;
             eqk.ld_f32 = 2 * D;
             gemm_linear(xn, D, blk.qk1, (int)rows, eqk, st, sk);
             launch_qknorm_rope2(qk, blk.qn1, q, qk + D, blk.kn1, k, 2 * D, D, rope_c, rope_s, T, (int)rows, D, eps, st, kAttnQueryPrescale);
             AttnArgs at;
-            if (NW == 1) {
+            if (!sp) {
                 for (int b = 0; b < B; ++b) gemm_vt(xn + (size_t)b * T * D, D, T, blk.v1, vt + (size_t)b * D * Tpad, Tpad, st, sk);
                 at.Vt = vt; at.ldvt = Tpad; at.vt_bstride = (long)D * Tpad;
                 at.K = k; at.k_bstride = (long)T * D;
@@ -433,10 +450,13 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             } else {
                 // keys / values of every rank's tokens: K rows gather straight into global token order; V^T blocks [D][T] of
                 // the ranks are interleaved into [D][Tfull] after the gather
-                gemm_vt(xn, D, T, blk.v1, vt, T, st, sk);  // V^T of the local tokens, dense [D][T]
                 sp_allgather(k, k_full, (long)T * D * 2);
-                sp_allgather(vt, m->ws_sp_vtg.p, (long)D * T * 2);
-                launch_sp_vt_interleave(m->ws_sp_vtg.as<bf16_t>(), vt_full, NW, D, T, TfullPad, st);
+                if (overlap) {
+                    dist_join(ctx, 1);
+                } else {
+                    sp_allgather(vt, m->ws_sp_vtg.p, (long)D * T * 2);
+                    launch_sp_vt_interleave(m->ws_sp_vtg.as<bf16_t>(), vt_full, NW, D, T, TfullPad, st);
+                }
                 at.Vt = vt_full; at.ldvt = TfullPad; at.vt_bstride = (long)D * TfullPad;
                 at.K = k_full; at.k_bstride = (long)Tfull * D;
                 at.Tk = Tfull;

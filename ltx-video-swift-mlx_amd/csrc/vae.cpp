@@ -525,15 +525,19 @@ int vae_blend_tiles(ltx_ctx* ctx, const float* const* tiles, const int* tile_fra
 
 void vae_decode(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a) {
     const TilePlan plan = checked_plan(a);
-    LTX_REQUIRE(a.frames, "vae_decode: null output");
+    // gather form (shard == 2): only the root rank produces frames
+    LTX_REQUIRE(a.shard != 2 || (a.root >= 0 && a.root < dist_world(ctx)), "vae_decode: root %d of %d ranks", a.root, dist_world(ctx));
+    const bool makes_frames = a.shard != 2 || dist_rank(ctx) == a.root;
+    LTX_REQUIRE(a.frames || !makes_frames, "vae_decode: null output");
     hipStream_t st = ctx->stream;
     const long HWpix = (long)a.H * 32 * a.W * 32 * 3;
-    LTX_REQUIRE(a.frames_cap >= (long)plan.out_frames * HWpix, "vae_decode: output buffer too small (%ld < %ld floats)",
+    LTX_REQUIRE(!makes_frames || a.frames_cap >= (long)plan.out_frames * HWpix, "vae_decode: output buffer too small (%ld < %ld floats)",
                 a.frames_cap, (long)plan.out_frames * HWpix);
     ensure_decode_workspace(ctx, m, plan, a.H, a.W);
     const int n_tiles = (int)plan.start.size();
     if (n_tiles == 1) {
-        const int nf = decode_plan_tile(ctx, m, a, plan, 0, a.frames, 1);
+        int nf = plan.out_frames;
+        if (makes_frames) nf = decode_plan_tile(ctx, m, a, plan, 0, a.frames, 1);
         if (a.n_frames_out) *a.n_frames_out = nf;
         return;
     }
@@ -580,6 +584,21 @@ void vae_decode(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a) {
     float* raw = m->tile_frames.as<float>();
     for (int i = rank; i < n_tiles; i += world) decode_plan_tile(ctx, m, a, plan, i, raw + off[i], 0);
     std::vector<const float*> ptrs(n_tiles);
+    if (a.shard == 2) {
+        // gather form: every raw tile travels ONCE, from its owner to the rank that blends (a.root); the other ranks return the frame
+        // count only. With 4 tiles on 8 ranks the broadcast form puts 1 GB on every rank, this one 0.8 GB on one.
+        LTX_REQUIRE(a.root >= 0 && a.root < world, "vae_decode: root %d of %d ranks", a.root, world);
+        for (int i = 0; i < n_tiles; ++i) {
+            dist_send_to_root(ctx, raw + off[i], (long)nfs[i] * HWpix * 4, i % world, a.root);
+            ptrs[i] = raw + off[i];
+        }
+        if (rank == a.root) {
+            const int total = vae_blend_tiles(ctx, ptrs.data(), nfs.data(), n_tiles, a.overlap, a.H, a.W, a.frames, a.frames_cap);
+            LTX_REQUIRE(total == plan.out_frames, "vae_decode: blended %d frames, the plan says %d", total, plan.out_frames);
+        }
+        if (a.n_frames_out) *a.n_frames_out = plan.out_frames;
+        return;
+    }
     for (int i = 0; i < n_tiles; ++i) {
         dist_broadcast(ctx, raw + off[i], (long)nfs[i] * HWpix * 4, i % world);
         ptrs[i] = raw + off[i];

@@ -80,7 +80,9 @@ struct VaeDecodeArgs {
     float* frames = nullptr;  // device (n_frames, 32H, 32W, 3) f32
     long frames_cap = 0;      // capacity in floats
     int* n_frames_out = nullptr;
-    int shard = 0;  // 1: temporal tiles are decoded round-robin by the context's ranks (dist.h) and broadcast raw before the blend
+    int shard = 0;  // 1: temporal tiles are decoded round-robin by the context's ranks (dist.h) and broadcast raw before the blend;
+                    // 2: ... and sent raw to rank `root` only, which blends (the other ranks' `frames` may be null)
+    int root = 0;
 };
 void vae_decode(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a);
 // Building blocks of the tiled decode (decodeWithTemporalTiling, VideoDecoder.swift:517-602), exposed so that a host can place

@@ -119,6 +119,11 @@ def _worker(rank, world, port, scenario, wpath, dims, q):
             out["single"] = fr1[:n1].cpu().numpy()
             out["collectives"] = ctx.dist_info()["collectives"]
             out["tiles"] = len(plan)
+            # gather form: raw tiles travel to rank 1 only, which blends; rank 0 passes no output buffer
+            fg = torch.full_like(fr, 7.0) if rank == 1 else None
+            ng = ctx.vae_decode_gathered_dev(lat, F, H, W, fg, root=1, tile=tile, overlap=ov)
+            out["gathered_n"] = ng
+            out["gathered"] = fg[:ng].cpu().numpy() if rank == 1 else None
         elif scenario == "fail":
             # a transport that raises on one rank: that rank's call must fail with the original error (not return OK on unfilled
             # buffers); the healthy rank is released by the gloo timeout of its peer's abort, so it only attempts a local call
@@ -232,6 +237,9 @@ def test_tile_sharded_vae_decode_two_ranks(ltx, weights):
     assert np.array_equal(r0["sharded"], r1["sharded"])
     assert np.array_equal(r0["sharded"], r0["single"]), "sharded tiles + blend differ from the single-process tiled decode"
     assert r0["collectives"] == 3  # one broadcast (as an all-gather on the host transport) per tile
+    # ltx_vae_decode_gathered_dev: only the root holds frames, bit-identical to the single-process decode; every rank gets the count
+    assert r0["gathered"] is None and r0["gathered_n"] == r1["gathered_n"] == r0["single"].shape[0]
+    assert np.array_equal(r1["gathered"], r0["single"])
 
 
 def test_failing_transport_aborts_the_call(ltx, weights):
@@ -277,6 +285,29 @@ def test_native_rccl_group_of_one(ltx, oracle, gpu_ctx, weights, tmp_path):
         assert ctx.vae_decode_sharded_dev(latv, 5, 2, 2, f0, tile=3, overlap=1) == nf
         assert ctx.vae_decode_dev(latv, 5, 2, 2, f1, tile=3, overlap=1) == nf
         assert torch.equal(f0, f1)
+        f2 = torch.empty_like(f0)
+        assert ctx.vae_decode_gathered_dev(latv, 5, 2, 2, f2, root=0, tile=3, overlap=1) == nf
+        assert torch.equal(f2, f1)
+        # the sequence-parallel branch of the forward on the native transport (V^T gather + interleave on the side stream under the
+        # q|k projection, K gather on the context's stream, fork / join events), driven through a one-rank group by the
+        # self-test hook: the bits must be those of the plain forward
+        T = F * H * W
+        tokens = torch.from_numpy(lat.reshape(128, T).T.copy()).cuda().to(torch.bfloat16).reshape(1, T, 128)
+        ts = torch.full((1,), 0.7, dtype=torch.float32, device="cuda")
+        va = torch.empty((1, T, 128), dtype=torch.float32, device="cuda")
+        vb = torch.empty_like(va)
+        n0 = ctx.dist_info()["collectives"]
+        ctx.dit_forward_dev(tokens, cdev, ts, None, F, H, W, va, ctx_version=0)
+        assert ctx.dist_info()["collectives"] == n0
+        os.environ["LTX_SP_SELFTEST"] = "1"
+        try:
+            for _ in range(3):
+                ctx.dit_forward_dev(tokens, cdev, ts, None, F, H, W, vb, ctx_version=0)
+                torch.cuda.synchronize()
+                assert torch.equal(va, vb)
+        finally:
+            del os.environ["LTX_SP_SELFTEST"]
+        assert ctx.dist_info()["collectives"] == n0 + 3 * 2 * 3  # K and V^T gathers of three blocks, three forwards
         with pytest.raises(ltx.LTXError):  # CFG sharding needs two ranks
             ctx.denoise_dev(l0, sig, torch.cat([cdev, cdev]), None, F, H, W, cfg_scale=2.0, shard=ltx.SHARD_CFG)
         ctx.dist_shutdown()
