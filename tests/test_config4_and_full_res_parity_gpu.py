@@ -89,7 +89,7 @@ def test_conv3d_128ch_at_25x256x384_integer_exact(gpu_ctx):
 def vae_from_oracle_weights(ltx, oracle, tmp_path_factory):
     from safetensors.torch import save_file
 
-    w = oracle.synth_vae_weights(seed=5, timestep_conditioning=False)
+    w = oracle.synth_vae_weights(seed=5, timestep_conditioning=True)   # the file carries the time embedders; config.json switches them off
     d = tmp_path_factory.mktemp("vae_full")
     path = d / "diffusion_pytorch_model.safetensors"
     save_file({k: torch.from_numpy(np.ascontiguousarray(v)).to(torch.bfloat16 if v.ndim == 5 else torch.float32)
@@ -168,9 +168,16 @@ def test_fuse_lora_rank_384_at_full_width(ltx, oracle, tmp_path, quant):
                 if k in wf:
                     wf[k] = oracle.fake_quant(wf[k], 8)
         else:
-            # the merged weights themselves, bit for bit: bf16(W + bf16(bf16(up @ down) * eff))
+            # the merged weights themselves: bf16(W + bf16(bf16(up @ down) * eff)). The 384-term f32 sums are accumulated in another
+            # order on the MFMA than in numpy, so a bf16 rounding of a sum may fall the other way: at most one bf16 ulp, on few elements
             k = "transformer_blocks.1.attn1.to_v.weight"
-            assert np.array_equal(ctx.dit_export_param(k).reshape(4096, 4096), wf[k]), "merged to_v differs from the oracle rule"
+            got_w, ref_w = ctx.dit_export_param(k).reshape(4096, 4096), wf[k]
+            diff = np.abs(got_w - ref_w)
+            ulp = np.maximum(np.abs(ref_w), 2.0 ** -10) * 2.0 ** -7
+            frac = float((diff > 0).mean())
+            print(f"merged to_v: {frac:.2e} of the elements differ from the oracle rule, max {float((diff / ulp).max()):.2f} bf16 ulp")
+            assert (diff <= ulp).all() and frac <= 2e-2, (frac, float((diff / ulp).max()))
+            assert not np.array_equal(got_w, w[k]), "the LoRA did not change to_v"
         ts = np.array([0.725], np.float32)
         ref = oracle.dit_forward(wf, ocfg, lat, cx, ts, None, F, H, W)
         ref0 = oracle.dit_forward(base, ocfg, lat, cx, ts, None, F, H, W)
