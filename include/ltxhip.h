@@ -130,6 +130,11 @@ int ltx_dit_load(ltx_ctx* ctx, const char* safetensors_path, const ltx_transform
 int ltx_dit_init_synthetic(ltx_ctx* ctx, const ltx_transformer_config* cfg, uint64_t seed);
 /* quantize(model:groupSize:bits:) applied to an already loaded / synthetic model (LTXPipeline.swift:329). */
 int ltx_dit_quantize(ltx_ctx* ctx, int bits, int group_size);
+/* Device memory the resident transformer holds, by arena (what MLX's memory statistics would show the host, LTXPipeline.swift:3176-3187
+ * estimateMemory): the bf16 Linear weights (0 once quantised: ltx_dit_quantize RELEASES them, as MLXNN.quantize replaces the
+ * modules), the codes + group scales / biases, the one de-quantisation scratch matrix, and everything else (biases, norm weights,
+ * tables). Any pointer may be NULL. */
+int ltx_dit_memory_info(ltx_ctx* ctx, long* bf16_weight_bytes, long* quantised_weight_bytes, long* scratch_bytes, long* other_bytes);
 /* Reads one parameter of the resident model back to the HOST as f32 (bf16 values widened; of a quantised model the de-quantised
  * value the GEMMs use). module_key: the reference's module path, e.g. "transformer_blocks.3.attn1.to_q.weight".
  * Returns the element count (written only if <= cap; out NULL = query) or <0. Parity tests use it to hand the on-device
@@ -446,6 +451,14 @@ int ltx_prof_collect(ltx_ctx* ctx, int kind, double* total_ms, long* launches, d
 int ltx_op_gemm_bf16(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb, const float* bias, int M,
                      int N, int K, int act, int tile_cfg, float* out_f32, long ld_f32, uint16_t* out_bf16,
                      long ld_bf16);
+/* out = A . dequant(codes)^T + bias for a few-row launch (M <= 256) on an affine-quantised Linear as MLX's QuantizedLinear holds it
+ * (LTXQuantizationConfig.swift:19-62): 8-bit codes [N][K], bf16 scale / bias per 64-wide group [N][K/64], w' = bf16(q * scale + bias).
+ * via_scratch = 0: the codes are de-quantised in the GEMM's B stage (what a quantised DiT does at few tokens, e.g. 256x256x9);
+ * via_scratch = 1: codes -> bf16 scratch matrix -> the same kernel (what every other launch does). Same bits either way.
+ * split_k >= 1: deterministic split of the K reduction. tile_cfg: 30 = the few-row kernel (M <= 128; operand rings of their own, codes
+ * staged 15 K-tiles ahead), 29 = the 128x64 ring kernel. */
+int ltx_op_gemm_q8(ltx_ctx* ctx, const uint16_t* A, long lda, const uint8_t* codes, const uint16_t* scales, const uint16_t* biases,
+                   const float* bias, int M, int N, int K, int split_k, int via_scratch, int tile_cfg, float* out_f32, long ld_f32);
 /* vt[n][t] = bf16(sum_k X[t][k] W[n][k] + bias[n]): the value projection in the transposed layout the attention op takes
  * (to_v of LTXAttention.swift:100-104 followed by the head split; columns t >= tokens of vt are left untouched), ldvt % 4 == 0 */
 int ltx_op_value_projection_t(ltx_ctx* ctx, const uint16_t* X, long ldx, int tokens, const uint16_t* W, const float* bias, int out_features,

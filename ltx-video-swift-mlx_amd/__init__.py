@@ -307,6 +307,11 @@ class Context:
     def dit_quantize(self, bits, group_size=64):
         self._ck(lib.ltx_dit_quantize(self._h, bits, group_size))
 
+    def dit_memory_info(self):
+        v = [C.c_long() for _ in range(4)]
+        self._ck(lib.ltx_dit_memory_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("bf16_weights", "quantised_weights", "scratch", "other"), (x.value for x in v)))
+
     def fuse_lora(self, path, scale=1.0):
         """``LTXPipeline.fuseLoRA(from:scale:)`` -> number of fused layers."""
         n = C.c_int()
@@ -591,6 +596,13 @@ class Context:
         self._ck(lib.ltx_op_gemm_bf16(self._h, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(bias), M, N, K, act, tile_cfg,
                                       _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
                                       _ptr(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0))
+
+    def op_gemm_q8(self, A, codes, scales, biases, bias, out, split_k=1, via_scratch=False, tile_cfg=30):
+        """out[M][N] f32 = A[M][K] bf16 . dequant(codes [N][K] u8, scales / biases [N][K/64] bf16)^T + bias"""
+        M, K = A.shape
+        N = codes.shape[0]
+        self._ck(lib.ltx_op_gemm_q8(self._h, _ptr(A), A.stride(0), _ptr(codes), _ptr(scales), _ptr(biases), _ptr(bias), M, N, K, split_k,
+                                    int(via_scratch), tile_cfg, _ptr(out), out.stride(0)))
 
     def op_value_projection_t(self, X, W, bias, vt):
         tokens, K = X.shape

@@ -109,6 +109,8 @@ SIGNATURES = {
     "ltx_dist_allgather_dev": (_i, [_vp, _vp, _vp, _l]),
     "ltx_dist_broadcast_dev": (_i, [_vp, _vp, _l, _i]),
     "ltx_vae_decode_tile_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp, _l, _ip]),
+    "ltx_dit_memory_info": (_i, [_vp, C.POINTER(_l), C.POINTER(_l), C.POINTER(_l), C.POINTER(_l)]),
+    "ltx_op_gemm_q8": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _l]),
     "ltx_vae_res_block_dev": (_i, [_vp, _i, _i, _vp, _i, _i, _i]),
     "ltx_vae_blend_tiles_dev": (_i, [_vp, C.POINTER(_vp), _ip, _i, _i, _i, _i, _vp, _l, _ip]),
     "ltx_vae_decode_sharded_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _l, _ip]),

@@ -339,6 +339,18 @@ int ltx_dit_quantize(ltx_ctx* ctx, int bits, int group_size) {
     return guarded(ctx, [&] { dit_quantize(ctx, need_dit(ctx), bits, group_size); });
 }
 
+int ltx_dit_memory_info(ltx_ctx* ctx, long* bf16_weight_bytes, long* quantised_weight_bytes, long* scratch_bytes, long* other_bytes) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        DiTModel* m = ctx->dit;
+        if (!m) LTX_THROW(LTXS_MODEL_NOT_LOADED, "Model component not loaded: transformer");
+        if (bf16_weight_bytes) *bf16_weight_bytes = m->warena.buf.p ? (long)m->warena.buf.bytes : 0;
+        if (quantised_weight_bytes) *quantised_weight_bytes = m->qarena.buf.p ? (long)m->qarena.buf.bytes : 0;
+        if (scratch_bytes) *scratch_bytes = m->dq.buf.p ? (long)m->dq.buf.bytes : 0;
+        if (other_bytes) *other_bytes = m->arena.buf.p ? (long)m->arena.buf.bytes : 0;
+    });
+}
+
 int ltx_dit_fuse_lora(ltx_ctx* ctx, const char* path, float scale, int* n_fused) {
     if (!ctx || !path) return LTX_ERR_INVALID_CONFIGURATION;
     return guarded(ctx, [&] {
@@ -997,6 +1009,35 @@ int ltx_op_gemm_bf16(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* 
             g.split_ws = ctx->op_ws.as<float>();
         }
         if (tile_cfg < 0) launch_gemm_bf16(g, ctx->stream); else launch_gemm_bf16_cfg(g, tile_cfg, ctx->stream);
+    });
+}
+
+int ltx_op_gemm_q8(ltx_ctx* ctx, const uint16_t* A, long lda, const uint8_t* codes, const uint16_t* scales, const uint16_t* biases,
+                   const float* bias, int M, int N, int K, int split_k, int via_scratch, int tile_cfg, float* out_f32, long ld_f32) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        LTX_REQUIRE(A && codes && scales && biases && out_f32 && split_k >= 1, "ltx_op_gemm_q8: null argument");
+        LTX_REQUIRE(gemm_takes_codes(M, N, K), "ltx_op_gemm_q8: few-row launches only (M <= 256, K %% 64 == 0, K >= 256, N %% 4 == 0; M=%d N=%d K=%d)", M, N, K);
+        GemmArgs g;
+        g.A = A; g.lda = lda; g.ldb = K; g.M = M; g.N = N; g.K = K;
+        g.ep.bias_n = bias;
+        g.ep.out_f32 = out_f32; g.ep.ld_f32 = ld_f32;
+        DevBuf scratch;
+        if (via_scratch) {  // the path every other launch of a quantised Linear takes: codes -> bf16 scratch matrix -> the same kernel
+            scratch.ensure((size_t)N * K * 2);
+            launch_dequant(codes, scales, biases, N, K, 8, scratch.as<bf16_t>(), ctx->stream);
+            g.B = scratch.as<bf16_t>();
+        } else {
+            g.Bq = codes; g.Bqs = scales; g.Bqb = biases;
+        }
+        if (split_k > 1) {
+            g.split_k = split_k;
+            if (ctx->op_ws.ensure((size_t)split_k * M * N * 4)) HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            g.split_ws = ctx->op_ws.as<float>();
+        }
+        LTX_REQUIRE(tile_cfg == 29 || (tile_cfg == 30 && gemm_fewrow_takes(M, N, K, split_k)), "ltx_op_gemm_q8: tile_cfg 29 (ring kernel) or 30 (few-row kernel: M <= 128, N %% 64 == 0, whole 256-wide macro-tiles of K per split)");
+        launch_gemm_bf16_cfg(g, tile_cfg, ctx->stream);
+        if (via_scratch) HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
 }
 

@@ -89,8 +89,9 @@ struct GemmArgs {
     int tile0 = 0, tile_count = 0;
     int win_row0 = 0, win_rows = 0;
     int group_m = 4;  // row-tiles per supertile of the workgroup order (0 = column-major tile order); see tile_coords()
-    // B as affine-quantised codes (experimental weight-streaming kernel only, M <= 128): 8-bit codes [N][K] (one per byte) and bf16 scale / bias
-    // per 64-wide group along K, [N][K/64]; w' = bf16(q * scale + bias). When set, B may be null.
+    // B as affine-quantised codes: 8-bit codes [N][K] (one per byte) and bf16 scale / bias per 64-wide group along K, [N][K/64];
+    // w' = bf16(q * scale + bias). Few-row launches only (gemm_takes_codes: M <= 256, with a split-K workspace): the 128x64 ring
+    // kernel de-quantises in its B stage. When set, B may be null.
     const uint8_t* Bq = nullptr;
     const bf16_t* Bqs = nullptr;
     const bf16_t* Bqb = nullptr;
@@ -106,6 +107,9 @@ int gemm_suggest_split_k(int M, int N, int K);
 
 // Launches on `stream`. Picks the tile shape from (M,N). Throws LtxError on invalid shapes.
 void launch_gemm_bf16(const GemmArgs& args, hipStream_t stream);
+// can a launch of this shape take B as 8-bit codes (GemmArgs::Bq)?
+bool gemm_takes_codes(int M, int N, int K);
+bool gemm_fewrow_takes(int M, int N, int K, int splits);
 // Force a tile config (v1: 0 128x128, 1 192x128, 3 96x128, 4 128x96; v2 ring: 21 192x128, 23 256x128, 25 128x192) -
 // used by tests/bench sweeps.
 void launch_gemm_bf16_cfg(const GemmArgs& args, int cfg, hipStream_t stream);

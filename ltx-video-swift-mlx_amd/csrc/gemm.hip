@@ -639,14 +639,24 @@ LTX_DEVFN void wait_vmcnt_barrier() {
 #if defined(GEMM_ASM_STAMPS) || defined(GEMM_V2_STAMPS) || defined(DTL_STAMPS)
 __device__ unsigned long long g_gemm_stamps[5][8];  // diagnostic builds only (tools/ubench/gemm_stamps.hip)
 #endif
-template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2>
+// QB (few-row launches on a quantised Linear, round 3): B arrives as 8-bit codes + bf16 scale / bias per 64-wide group (one group =
+// one K-tile) and is de-quantised IN the B stage: stage(t) brings A(t), the codes of tile t+1 (BN x 64 B, a quarter of the bf16
+// bytes plus its 2 x BN scalars) into a code ring; the first half of K-tile t converts the codes of tile t+1 into the bf16 image of
+// ring slot t+1 (w' = bf16(q * scale + bias), the arithmetic of quant_decode_kernel: the result is bit-identical to the scratch
+// path), and the mid-tile barrier that already orders tile t+1's LDS-DMA makes the converted image visible before its first
+// fragment read. The codes are read from HBM once and nothing is written back: a few-row GEMM streams half the bytes of the bf16 one.
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2, bool QB = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WGM * WGN;  // waves per workgroup
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_PER_WAVE = BM / 8 / NW, B_PER_WAVE = BN / 8 / NW;
-    static_assert(A_PER_WAVE * 8 * NW == BM && B_PER_WAVE * 8 * NW == BN, "tile rows must split evenly over the waves");
+    constexpr int A_PER_WAVE = BM / 8 / NW, B_PER_WAVE = QB ? BN / 16 / NW + 1 : BN / 8 / NW;  // QB: code pieces of 16 rows + one scale / bias piece
+    static_assert(A_PER_WAVE * 8 * NW == BM && (QB || B_PER_WAVE * 8 * NW == BN), "tile rows must split evenly over the waves");
+    static_assert(!QB || (!CONV && BN % (16 * NW) == 0 && NW * 64 * 16 == BN * 64), "QB: one 16-byte conversion unit per thread");
+    constexpr int NQ = NSTAGE + 1;                          // code / scalar ring slots (a tile's codes live from stage(t-1) to K-tile t-1)
+    constexpr int Q_BYTES = BN * 64, SB_BYTES = NW * 256;   // codes [BN][64 B]; scalars: one dword per lane of one piece per wave
+    constexpr int Q_OFF = NSTAGE * STAGE, SB_OFF = Q_OFF + NQ * Q_BYTES;
     constexpr int LPT = A_PER_WAVE + B_PER_WAVE;  // LDS-DMA instructions per wave per K-tile
     constexpr int PD = NSTAGE - 1;                // prefetch distance in tiles
     static_assert(NSTAGE >= 3, "ring needs >= 3 slots");
@@ -735,13 +745,28 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
             a_src[i] = g.A + (long)gm * g.lda + lch * 8;
         }
     }
+    const uint8_t* q_src[QB ? BN / 16 / NW : 1];  // QB: this lane's 16 codes of a K-tile: row 16 (wave + NW i) + lane / 4, bytes 16 (lane % 4) ..
+    const bf16_t* sb_src = nullptr;               // QB: this lane's scalar of a K-tile: lanes 0-15 scale, 16-31 bias of row 16 wave + (lane & 15)
+    const int groups = g.K / BK;
+    if constexpr (QB) {
 #pragma unroll
-    for (int i = 0; i < B_PER_WAVE; ++i) {
-        const int row = (wave + NW * i) * 8 + srow;
-        const int lch = pch ^ ((row >> 1) & 7);
-        int gn = n0 + row;
+        for (int i = 0; i < BN / 16 / NW; ++i) {
+            int gn = n0 + (wave + NW * i) * 16 + (lane >> 2);
+            gn = gn < g.N ? gn : g.N - 1;
+            q_src[i] = g.Bq + (long)gn * g.K + (lane & 3) * 16;
+        }
+        int gn = n0 + wave * 16 + (lane & 15);
         gn = gn < g.N ? gn : g.N - 1;
-        b_src[i] = g.B + (long)gn * g.ldb + lch * 8;
+        sb_src = ((lane & 16) ? g.Bqb : g.Bqs) + (long)gn * groups;
+    } else {
+#pragma unroll
+        for (int i = 0; i < B_PER_WAVE; ++i) {
+            const int row = (wave + NW * i) * 8 + srow;
+            const int lch = pch ^ ((row >> 1) & 7);
+            int gn = n0 + row;
+            gn = gn < g.N ? gn : g.N - 1;
+            b_src[i] = g.B + (long)gn * g.ldb + lch * 8;
+        }
     }
     int nk = g.K / BK, kt0 = 0;  // this workgroup's K-tiles: [kt0, kt0 + nk)
     if (g.split_k > 1) {
@@ -750,6 +775,43 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         nk = (int)((long)nk * (z + 1) / g.split_k) - kt0;
     }
     const int cpt = CONV ? (g.geom.C / BK) : 1;
+    // QB: codes + scalars of absolute K-tile `kt` (clamped: a tile past the end is staged into a free slot and never converted)
+    auto stage_q = [&](int kt) {
+        if constexpr (QB) {
+            const int t = kt < groups ? kt : groups - 1;
+            const int qslot = (kt - kt0 + NQ) % NQ;
+#pragma unroll
+            for (int i = 0; i < BN / 16 / NW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(q_src[i] + (long)t * BK),
+                                                 (__attribute__((address_space(3))) void*)(smem + Q_OFF + qslot * Q_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb_src + t),
+                                             (__attribute__((address_space(3))) void*)(smem + SB_OFF + qslot * SB_BYTES + wave * 256), 2, 0, 0);
+        }
+    };
+    // QB: codes of tile index `j` (relative to kt0) -> bf16 image of ring slot `slot` (B part). Thread = (row tid / 4, 16 codes tid % 4).
+    auto convert_q = [&](int slot, int j) {
+        if constexpr (QB) {
+            const int qslot = (j + NQ) % NQ;
+            const int row = tid >> 2, c4 = tid & 3;
+            const uint4 raw = *(const uint4*)(smem + Q_OFF + qslot * Q_BYTES + row * 64 + c4 * 16);
+            const char* sbp = smem + SB_OFF + qslot * SB_BYTES + (row >> 4) * 256 + (row & 15) * 4;
+            const float scale = bf16_to_f32((bf16_t)(*(const uint32_t*)sbp & 0xffffu));
+            const float bias = bf16_to_f32((bf16_t)(*(const uint32_t*)(sbp + 64) & 0xffffu));
+            const uint32_t wd[4] = {raw.x, raw.y, raw.z, raw.w};
+            uint32_t out[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float q0 = (float)((wd[i] >> (16 * jj)) & 0xffu), q1 = (float)((wd[i] >> (16 * jj + 8)) & 0xffu);
+                    out[i * 2 + jj] = pack_bf16x2(q0 * scale + bias, q1 * scale + bias);
+                }
+            char* brow = smem + slot * STAGE + A_BYTES + row * ROW_BYTES;
+            const int sw = (row >> 1) & 7;
+            *(uint4*)(brow + (((2 * c4) ^ sw) << 4)) = uint4{out[0], out[1], out[2], out[3]};
+            *(uint4*)(brow + (((2 * c4 + 1) ^ sw) << 4)) = uint4{out[4], out[5], out[6], out[7]};
+        }
+    };
 
     // conv mode: the gathered source pointers only change when the 3x3x3 tap changes (every C/64 K-tiles); inside a
     // tap they just advance by one K-tile. K-tiles are staged in increasing order, so the pointers are loop state.
@@ -824,11 +886,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
                     (__attribute__((address_space(3))) void*)(base + (wave + NW * i) * 1024), 16, 0, 0);
             }
         }
+        if constexpr (QB) {
+            stage_q(kt + 1);  // the codes run one tile ahead of the activations: they are converted during K-tile kt
+        } else {
 #pragma unroll
-        for (int i = 0; i < B_PER_WAVE; ++i) {
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(b_src[i] + (long)kt * BK),
-                (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
+            for (int i = 0; i < B_PER_WAVE; ++i) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(b_src[i] + (long)kt * BK),
+                    (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -873,10 +939,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     if constexpr (CONV) {
         conv_tap_ptrs(conv_tap);  // absolute pointers of the first tap (a K split may begin at any tap, in the middle of one)
     }
+    if constexpr (QB) stage_q(kt0);  // codes of the first tile (stage(t) brings the codes of tile t + 1)
 #pragma unroll
     for (int s = 0; s < PD; ++s)
         if (s < nk) stage(s, kt0 + s);
     if (nk >= PD) wait_vmcnt_barrier<(PD - 1) * LPT>(); else wait_vmcnt_barrier<0>();
+    if constexpr (QB) {
+        convert_q(0, 0);  // the first tile's weights, visible behind a barrier of their own
+        wait_lgkm_barrier();
+    }
 #ifdef GEMM_V2_STAMPS
     const unsigned long long st1 = wall_clock64();
 #endif
@@ -898,16 +969,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         mfma_first(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         load_frags(slot, foff1, fa1, fb1);
-        mfma_rest(fa0, fb0);
-#pragma unroll
-        for (int q = 0; q < MI + NI; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one ds_read
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+        if constexpr (QB) {
+            if (kt + 1 < nk) convert_q(nslot, kt + 1);  // codes of tile kt+1 (visible since the previous mid-tile barrier) -> its bf16 image
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - 1 - (MI + NI), 0);
+        mfma_rest(fa0, fb0);
+        if constexpr (!QB) {
+#pragma unroll
+            for (int q = 0; q < MI + NI; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one ds_read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - 1 - (MI + NI), 0);
+        }
         // ---- tile kt+1 must have landed for every wave; tiles kt+2 .. kt+PD-1 may stay in flight. The first tail tile drains the
         // ring (every remaining tile visible to every wave); the tail tiles after it stage nothing and need neither wait nor barrier.
-        if constexpr (STEADY) wait_vmcnt_barrier<(PD - 2) * LPT>(); else if (!drained) wait_vmcnt_barrier<0>();
+        // QB: the barrier also publishes the image just converted (its ds_writes are retired first), so every tile has one.
+        if constexpr (QB) {
+            if constexpr (STEADY) wait_lgkm_vmcnt_barrier<(PD - 2) * LPT>(); else wait_lgkm_vmcnt_barrier<0>();
+        } else {
+            if constexpr (STEADY) wait_vmcnt_barrier<(PD - 2) * LPT>(); else if (!drained) wait_vmcnt_barrier<0>();
+        }
         // ---- second half
         mfma_first(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
@@ -915,17 +996,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
             stage(pslot, kt0 + kt + PD);
             load_frags(nslot, foff0, fa0, fb0);
             mfma_rest(fa1, fb1);
+            if constexpr (!QB) {
 #pragma unroll
-            for (int q = 0; q < LPT; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);  // one LDS-DMA (VMEM read)
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            }
+                for (int q = 0; q < LPT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);  // one LDS-DMA (VMEM read)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                }
 #pragma unroll
-            for (int q = 0; q < MI + NI; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                for (int q = 0; q < MI + NI; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - 1 - (MI + NI) - LPT, 1);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - 1 - (MI + NI) - LPT, 1);
         } else {
             if (kt + 1 < nk) load_frags(nslot, foff0, fa0, fb0);
             mfma_rest(fa1, fb1);
@@ -975,6 +1058,251 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
 #endif
 }
 
+
+#ifdef LTX_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------------------------
+// Few-row launches (M <= 128: the DiT at 256x256x9 = 128 tokens), round 3. Such a GEMM streams its weights once and is bound by
+// how many bytes a CU keeps in flight against the HBM latency, not by MFMAs (16 per wave and K-tile). The ring kernel above stages
+// activations and weights through ONE ring with one in-order counter: three K-tiles = 72 KB in flight, two thirds of them the
+// activation tile, which comes from L2 and needs no such cover. Here the two operands have rings of their own and waves of their own:
+//   waves 0, 1 stage the activation tile (128 x 64 bf16 = 16 pieces) two K-tiles ahead: 3 slots, 48 KB;
+//   waves 2, 3 stage the weights in MACRO-tiles of four K-tiles, two macro-tiles ahead: a piece is 2 rows x 512 contiguous bytes
+//              (8 rows x 128 B pieces fetch a quarter of a DRAM page per row visit: the ring kernel streams weights at ~3 TB/s);
+//              3 slots of 32 KB - or, QB, the 8-bit codes of a quantised Linear: pieces of 4 rows x 256 B, 4 slots of 16 KB, three
+//              macro-tiles ahead, plus the group scales / biases of the macro-tile (two dwords per row and wave);
+// each role waits on its own vmcnt (the counter is per wave), one workgroup barrier per K-tile publishes both. All four waves run the
+// MFMAs (wave tile 64 x 32). QB: the codes of tile t+1 are converted to the bf16 image (two slots) during K-tile t, w' = bf16(q * scale
+// + bias) - quant_decode_kernel's arithmetic, bit-identical to the scratch path - so a quantised few-row GEMM reads half the bytes.
+// Split-K (grid.y) and the epilogue are the ring kernel's.
+// MEASURED, NOT SELECTED (tile_cfg 30, experiments build): bit-exact (tests/test_experiments_gpu.py), and 9 % SLOWER than the 128x64
+// ring kernel at 128 tokens - 22.9 / 25.9 / 45.0 us against 20.95 / 23.3 / 41.1 us for the N = 4096 / 8192 / 16384 launches of a block
+// (rocprofv3, profiles/r03_config1_fewrow.txt); forward 12.7 against 11.9 ms. Both kernels stream the weights at ~3 TB/s whatever the
+// bytes in flight (72 KB or 136 KB per CU) and whatever the run length per DRAM row (128 B or 512 B): what a CU takes in per K-tile
+// is 16 KB of ACTIVATIONS (from L2) beside 8 KB of weights, 37 GB/s per CU through LDS-DMA in all - the operand that is re-fetched
+// by every column tile, not HBM, bounds a 128-row GEMM with 64-column tiles.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+LTX_DEVFN void wait_vmcnt_only() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// s_waitcnt vmcnt(n) for a run-time n (immediates only): n is wave-uniform, <= 45
+LTX_DEVFN void wait_vmcnt_dyn(int n) {
+    switch (n) {
+#define LTX_W(K) case K: wait_vmcnt_only<K>(); break;
+        LTX_W(0) LTX_W(1) LTX_W(2) LTX_W(3) LTX_W(4) LTX_W(5) LTX_W(6) LTX_W(7) LTX_W(8) LTX_W(9) LTX_W(10) LTX_W(11) LTX_W(12) LTX_W(13) LTX_W(14)
+        LTX_W(15) LTX_W(16) LTX_W(17) LTX_W(18) LTX_W(19) LTX_W(20) LTX_W(21) LTX_W(22) LTX_W(23) LTX_W(24) LTX_W(25) LTX_W(26) LTX_W(27) LTX_W(28)
+        LTX_W(29) LTX_W(30) LTX_W(31) LTX_W(32) LTX_W(33) LTX_W(34) LTX_W(35) LTX_W(36) LTX_W(37) LTX_W(38) LTX_W(39) LTX_W(40) LTX_W(41) LTX_W(42)
+        LTX_W(43) LTX_W(44) LTX_W(45)
+#undef LTX_W
+        default: wait_vmcnt_only<0>(); break;
+    }
+}
+
+template <bool QB>
+__global__ __launch_bounds__(256, 1) void gemm_fewrow_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 128, BN = 64, WGM = 2, WGN = 2, WM = 64, WN = 32, MI = 4, NI = 2;
+    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+    constexpr int NA = 3, PA = NA - 1;                       // activation ring (K-tiles)
+    constexpr int MT = 4;                                    // K-tiles per weight macro-tile: 256 elements = 512 B (256 B of codes) of a row
+    constexpr int NBM = QB ? 4 : 3, PBM = NBM - 1;           // weight ring (macro-tiles)
+    constexpr int BM_BYTES = QB ? BN * MT * 64 : BN * MT * ROW_BYTES;   // 16 KB of codes / 32 KB of bf16 weights
+    constexpr int SB_BYTES = 1024;                           // QB: [scale dword 0][scale dword 1][bias dword 0][bias dword 1] x 64 rows
+    constexpr int A_OFF = 0, B_OFF = NA * A_BYTES;           // bf16 macro ring, or (QB) the two-slot bf16 image of single K-tiles
+    constexpr int Q_OFF = B_OFF + 2 * B_BYTES, SB_OFF = Q_OFF + NBM * BM_BYTES;
+    constexpr int APW = 8;                                   // LDS-DMA pieces per K-tile of an activation wave
+    constexpr int BPW = QB ? 10 : 16;                        // ... per MACRO-tile of a weight wave
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WGN, wc = wave % WGN;
+    const bool a_role = wave < 2;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = bid * BN, m0 = 0;
+    int nk = g.K / BK, kt0 = 0;
+    const int groups = g.K / BK;
+    if (g.split_k > 1) {  // the launcher guarantees whole macro-tiles per split
+        const int z = blockIdx.y;
+        kt0 = (int)((long)nk * z / g.split_k);
+        nk = (int)((long)nk * (z + 1) / g.split_k) - kt0;
+    }
+    const int nm = nk / MT;  // macro-tiles of this workgroup
+    // ---- staging sources ----
+    const bf16_t* asrc[APW];
+    const char* bsrc = nullptr;   // weight wave: this lane's 16 bytes of piece 0 of macro-tile 0; piece i is `bstep` rows further down
+    long bstep = 0;
+    const bf16_t* sbsrc = nullptr;
+    if (a_role) {
+        const int srow = lane >> 3, pch = lane & 7;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int row = (wave + 2 * i) * 8 + srow;
+            const int gm = row < g.M ? row : g.M - 1;
+            asrc[i] = g.A + (long)gm * g.lda + (pch ^ ((row >> 1) & 7)) * 8;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < APW; ++i) asrc[i] = nullptr;
+        if constexpr (QB) {
+            // piece = 4 rows x 256 B of codes; wave w-2 takes pieces (w-2), (w-2)+2, ...: rows 4 piece + lane / 16, chunk lane % 16
+            const int row = (wave - 2) * 4 + (lane >> 4);
+            int gn = n0 + row;
+            gn = gn < g.N ? gn : g.N - 1;
+            bsrc = (const char*)(g.Bq + (long)gn * g.K + (long)kt0 * BK + (lane & 15) * 16);
+            bstep = 8L * g.K;   // two pieces = 8 rows further (ragged N is handled by the caller: N % 64 == 0 for this instance)
+            int gs = n0 + lane;
+            gs = gs < g.N ? gs : g.N - 1;
+            sbsrc = (wave == 2 ? g.Bqs : g.Bqb) + (long)gs * groups + kt0;
+        } else {
+            // piece = 2 rows x 512 B; physical chunk p of row r holds logical chunk p ^ (r & 15) (fragment reads: 16 rows, one chunk);
+            // the source addresses are formed in stage_b
+        }
+    }
+    auto stage_a = [&](int j) {  // relative K-tile j -> activation slot j % NA
+        char* base = smem + A_OFF + (j % NA) * A_BYTES;
+#pragma unroll
+        for (int i = 0; i < APW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (long)(kt0 + j) * BK),
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 2 * i) * 1024), 16, 0, 0);
+    };
+    auto stage_b = [&](int m) {  // relative macro-tile m -> weight slot m % NBM
+        if constexpr (QB) {
+            char* base = smem + Q_OFF + (m % NBM) * BM_BYTES;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + i * bstep + (long)m * MT * BK),
+                                                 (__attribute__((address_space(3))) void*)(base + ((wave - 2) + 2 * i) * 1024), 16, 0, 0);
+            char* sb = smem + SB_OFF + (m % NBM) * SB_BYTES + (wave - 2) * 512;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbsrc + m * MT + 2 * i),
+                                                 (__attribute__((address_space(3))) void*)(sb + i * 256), 4, 0, 0);
+        } else {
+            char* base = smem + B_OFF + (m % NBM) * BM_BYTES;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                // piece (wave - 2) + 2 i = rows 2 piece, 2 piece + 1; the swizzle term (row & 15) changes from piece to piece
+                const int row = ((wave - 2) + 2 * i) * 2 + (lane >> 5);
+                const bf16_t* src = g.B + (long)(n0 + row) * g.ldb + (long)(kt0 + m * MT) * BK + (((lane & 31) ^ (row & 15)) * 8);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(base + ((wave - 2) + 2 * i) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // QB: codes of relative K-tile j -> bf16 image slot j & 1. Thread = (row tid / 4, 16 codes tid % 4).
+    auto convert_q = [&](int j) {
+        if constexpr (QB) {
+            const int row = tid >> 2, c4 = tid & 3;
+            const int m = j / MT, sub = j % MT;
+            const uint4 raw = *(const uint4*)(smem + Q_OFF + (m % NBM) * BM_BYTES + row * 256 + sub * 64 + c4 * 16);
+            const char* sbp = smem + SB_OFF + (m % NBM) * SB_BYTES + (sub >> 1) * 256 + row * 4;
+            const uint32_t sw_ = *(const uint32_t*)sbp, bw_ = *(const uint32_t*)(sbp + 512);
+            const float scale = bf16_to_f32((bf16_t)((sub & 1) ? (sw_ >> 16) : (sw_ & 0xffffu)));
+            const float bias = bf16_to_f32((bf16_t)((sub & 1) ? (bw_ >> 16) : (bw_ & 0xffffu)));
+            const uint32_t wd[4] = {raw.x, raw.y, raw.z, raw.w};
+            uint32_t out[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float q0 = (float)((wd[i] >> (16 * jj)) & 0xffu), q1 = (float)((wd[i] >> (16 * jj + 8)) & 0xffu);
+                    out[i * 2 + jj] = pack_bf16x2(q0 * scale + bias, q1 * scale + bias);
+                }
+            char* brow = smem + B_OFF + (j & 1) * B_BYTES + row * ROW_BYTES;
+            const int sw = (row >> 1) & 7;
+            *(uint4*)(brow + (((2 * c4) ^ sw) << 4)) = uint4{out[0], out[1], out[2], out[3]};
+            *(uint4*)(brow + (((2 * c4 + 1) ^ sw) << 4)) = uint4{out[4], out[5], out[6], out[7]};
+        }
+    };
+    auto role_wait = [&](int need_through, int issued_through, int per) {
+        int keep = issued_through - need_through;
+        keep = keep < 0 ? 0 : keep;
+        wait_vmcnt_dyn(keep * per);
+    };
+
+    const int frow = lane & 15;
+    const int fsw = (lane >> 1) & 7;
+    const int foff0 = frow * ROW_BYTES + ((((lane >> 4) + 0) ^ fsw) << 4);
+    const int foff1 = frow * ROW_BYTES + ((((lane >> 4) + 4) ^ fsw) << 4);
+    const int a_wave_off = (wr * WM) * ROW_BYTES;
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue ----
+    int a_issued = -1, b_issued = -1;  // last relative K-tile / macro-tile this role has staged
+    if (a_role) {
+        for (int j = 0; j < PA && j < nk; ++j) { stage_a(j); a_issued = j; }
+    } else {
+        for (int m = 0; m < PBM && m < nm; ++m) { stage_b(m); b_issued = m; }
+    }
+    if constexpr (QB) {  // the first tile's image needs a barrier of its own
+        if (!a_role) role_wait(0, b_issued, BPW);
+        raw_barrier();
+        convert_q(0);
+        wait_lgkm_barrier();
+    }
+    ResidualTile<BM, BN, WGM, WGN> rt;
+    for (int t = 0; t < nk; ++t) {
+        const int m = t / MT, sub = t % MT;
+        // K-tile t of the activations and macro-tile m of the weights (QB: the macro-tile of K-tile t+1, converted below) must have landed
+        if (a_role) role_wait(t, a_issued, APW);
+        else role_wait(QB ? ((t + 1 < nk ? t + 1 : t) / MT) : m, b_issued, BPW);
+        if constexpr (QB) wait_lgkm_barrier(); else raw_barrier();   // QB: also publishes the image converted during K-tile t-1
+        // refill what K-tile t-1 / macro-tile m-1 occupied: every wave is past its reads (QB: past the conversion of its last K-tile)
+        if (a_role) {
+            if (t + PA < nk) { stage_a(t + PA); a_issued = t + PA; }
+        } else if (sub == (QB ? 1 : 0)) {
+            if (m + PBM < nm) { stage_b(m + PBM); b_issued = m + PBM; }
+        }
+        if (t == nk - 1 && !g.ep.d2s && g.split_k <= 1 && n0 + BN <= g.N) {  // residual / bias under the last tile's MFMAs
+            gemm_bias_prefetch<BM, BN, WGM, WGN>(g, n0, wc, lane, rt);
+            if (g.ep.resid) gemm_residual_prefetch<BM, BN, WGM, WGN>(g, m0, n0, wr, wc, lane, rt);
+        }
+        const char* abase = smem + A_OFF + (t % NA) * A_BYTES + a_wave_off;
+        s16x8 fa[2][MI], fb[2][NI];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[k][i] = *(const s16x8*)(abase + i * 16 * ROW_BYTES + (k ? foff1 : foff0));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                if constexpr (QB) {
+                    fb[k][j] = *(const s16x8*)(smem + B_OFF + (t & 1) * B_BYTES + (wc * WN + j * 16) * ROW_BYTES + (k ? foff1 : foff0));
+                } else {
+                    // macro image: row stride 512 B, logical chunk sub*8 + 4k + (lane >> 4) at physical chunk ^ (row & 15)
+                    const int row = wc * WN + j * 16 + frow;
+                    fb[k][j] = *(const s16x8*)(smem + B_OFF + (m % NBM) * BM_BYTES + row * (MT * ROW_BYTES) +
+                                               (((sub * 8 + 4 * k + (lane >> 4)) ^ frow) << 4));
+                }
+            }
+        }
+        if constexpr (QB) {
+            if (t + 1 < nk) convert_q(t + 1);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[k][i]), __builtin_bit_cast(bf16x8_t, fb[k][j]),
+                                                                        acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the epilogue reuses the LDS
+    if (g.split_k > 1) {
+        GemmArgs gs = g;  // raw partial tile -> workspace slice of this split
+        gs.ep = GemmEpilogue{};
+        gs.ep.out_f32 = g.split_ws + (long)blockIdx.y * g.M * g.N;
+        gs.ep.ld_f32 = g.N;
+        gemm_epilogue<BM, BN, WGM, WGN>(acc, gs, m0, n0, wr, wc, lane, wave, smem);
+        return;
+    }
+    gemm_epilogue<BM, BN, WGM, WGN>(acc, g, m0, n0, wr, wc, lane, wave, smem, &rt);
+}
+#endif  // LTX_EXPERIMENTS (few-row kernel)
 
 #ifdef LTX_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------
@@ -1425,14 +1753,15 @@ void launch_m32(const GemmArgs& a, hipStream_t stream) {
 }
 #endif
 
-template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2>
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int WGN = 2, bool QB = false>
 void launch_v2(const GemmArgs& a, hipStream_t stream) {
-    constexpr int smem = NSTAGE * (BM + BN) * ROW_BYTES;
+    constexpr int smem = NSTAGE * (BM + BN) * ROW_BYTES + (QB ? (NSTAGE + 1) * (BN * 64 + WGM * WGN * 256) : 0);
     static PerDeviceOnce attr_set;
     attr_set.run([&] {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN>,
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN, QB>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     });
+    LTX_REQUIRE(QB == (a.Bq != nullptr), "gemm: quantised codes need the de-quantising instance of the ring kernel");
     const int all_tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int tiles = a.tile_count ? a.tile_count : all_tiles;
     LTX_REQUIRE(a.tile0 >= 0 && a.tile0 + tiles <= all_tiles, "gemm: tile window [%d, %d) outside %d tiles", a.tile0, a.tile0 + tiles, all_tiles);
@@ -1443,7 +1772,7 @@ void launch_v2(const GemmArgs& a, hipStream_t stream) {
         LTX_REQUIRE(!a.win_rows || (!e.gate && !e.bias_m && !e.out_bf16_t && a.win_row0 + a.win_rows <= a.M),
                     "gemm split-K: a row window takes neither per-row gates / biases nor the transposed output");
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN>), dim3(tiles, a.split_k > 1 ? a.split_k : 1),
+    hipLaunchKernelGGL((gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN, QB>), dim3(tiles, a.split_k > 1 ? a.split_k : 1),
                        dim3(WGM * WGN * 64), smem, stream, a);
     HIP_CHECK(hipGetLastError());
     if (a.split_k > 1) {
@@ -1460,6 +1789,29 @@ void launch_v2(const GemmArgs& a, hipStream_t stream) {
         HIP_CHECK(hipGetLastError());
     }
 }
+
+#ifdef LTX_EXPERIMENTS
+template <bool QB>
+void launch_fewrow(const GemmArgs& a, hipStream_t stream) {
+    constexpr int smem = 3 * 128 * ROW_BYTES + (QB ? 2 * 64 * ROW_BYTES + 4 * (64 * 256 + 1024) : 3 * 64 * 4 * ROW_BYTES);
+    static PerDeviceOnce attr_set;
+    attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_fewrow_kernel<QB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
+    LTX_REQUIRE(QB == (a.Bq != nullptr), "gemm: quantised codes need the de-quantising instance of the few-row kernel");
+    LTX_REQUIRE(gemm_fewrow_takes(a.M, a.N, a.K, a.split_k) && !a.conv && !a.tile_count && !a.win_rows && !a.ep.d2s && !a.ep.pn_out,
+                "gemm: the few-row kernel takes dense launches with M <= 128, N %% 64 == 0 and whole 256-wide macro-tiles of K per split "
+                "(M=%d N=%d K=%d splits=%d)", a.M, a.N, a.K, a.split_k);
+    const int tiles = (a.N + 63) / 64;
+    if (a.split_k > 1) LTX_REQUIRE(a.split_ws && a.N % 4 == 0 && a.split_k <= a.K / BK, "gemm split-K: needs a workspace and N %% 4 == 0");
+    hipLaunchKernelGGL(gemm_fewrow_kernel<QB>, dim3(tiles, a.split_k > 1 ? a.split_k : 1), dim3(256), smem, stream, a);
+    HIP_CHECK(hipGetLastError());
+    if (a.split_k > 1) {
+        const long total = (long)a.M * (a.N / 4);
+        const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+        HIP_CHECK(hipGetLastError());
+    }
+}
+#endif
 
 void validate(const GemmArgs& a) {
     LTX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -1575,12 +1927,12 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     if (a.ep.out_bf16_t) {
         const GemmEpilogue& e = a.ep;
         LTX_REQUIRE(!e.out_f32 && !e.out_bf16 && !e.resid && !e.d2s && !e.bias_m && e.act == LTX_ACT_NONE && !e.round_bf16 &&
-                        (cfg == 90 || (a.split_k <= 1 && !a.split_ws)) && e.ld_bf16_t % 4 == 0 && e.ld_bf16_t >= a.M && (cfg < 41 || cfg == 90),
+                        (cfg == 90 || cfg == 29 || cfg == 30 || (a.split_k <= 1 && !a.split_ws)) && e.ld_bf16_t % 4 == 0 && e.ld_bf16_t >= a.M && (cfg < 41 || cfg == 90),
                     "gemm: the transposed bf16 output takes bias_n only, no split-K, ld %% 4 == 0 (ld=%ld M=%d cfg=%d)", e.ld_bf16_t, a.M, cfg);
     }
     validate(a);
     LTX_REQUIRE(a.split_k <= 1 || (cfg >= 20 && cfg < 32) || cfg == 90, "gemm: split-K needs a ring kernel or the weight-streaming kernel (tile cfg %d)", cfg);
-    LTX_REQUIRE(!a.Bq || cfg == 90, "gemm: quantised codes are read by the weight-streaming kernel only (tile cfg %d)", cfg);
+    LTX_REQUIRE(!a.Bq || cfg == 90 || cfg == 29 || cfg == 30, "gemm: quantised codes are read by the few-row ring kernel only (tile cfg %d)", cfg);
     ProfScope prof(a.conv ? PROF_CONV : PROF_GEMM, 2.0 * (a.win_rows ? a.win_rows : a.M) * a.N * a.K, stream);  // a tile window's rows
     // cfg 0..2: v1 (2-stage, one barrier + full drain per K-tile); cfg 10..: v2 (ring + counted vmcnt)
     if (a.conv) {
@@ -1607,7 +1959,14 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 22: { GemmArgs b = a; b.group_m = 0; launch_v2<192, 128, 4, false, 4, 2>(b, stream); break; }  // A/B: column-major order
             case 23: launch_v2<256, 128, 3, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
-            case 29: launch_v2<128, 64, 4, false, 2, 2>(a, stream); break;  // few rows: narrow column tiles, 4 waves, one workgroup per CU
+            case 29:  // few rows: narrow column tiles, 4 waves, one workgroup per CU; 8-bit codes de-quantised in the B stage
+                if (a.Bq) launch_v2<128, 64, 4, false, 2, 2, true>(a, stream); else launch_v2<128, 64, 4, false, 2, 2>(a, stream);
+                break;
+#ifdef LTX_EXPERIMENTS
+            case 30:  // few rows (M <= 128), operand rings of their own, weights in macro-tiles: measured, not selected
+                if (a.Bq) launch_fewrow<true>(a, stream); else launch_fewrow<false>(a, stream);
+                break;
+#endif
             case 75: launch_dtl(a, stream); break;  // 192x256, one wave per SIMD, fragments of a whole K-tile in registers, 2 + 3 LDS slots
 #ifdef LTX_EXPERIMENTS  // measured, not selected (gemm_experiments.inc)
             case 31: launch_m32<192, 128, 4>(a, stream); break;  // the 192x128 ring tile on 32x32x16 MFMAs (2 x 4 waves of 96 x 32): 951 vs 1021 TFLOP/s
@@ -1622,6 +1981,13 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
         }
     }
+}
+
+bool gemm_takes_codes(int M, int N, int K) { return M >= 1 && M <= 256 && K % BK == 0 && K >= 4 * BK && N % 4 == 0; }
+// the few-row kernel (tile_cfg 30): one 128-row tile, whole 64-column tiles, K of every split a whole number of 256-wide macro-tiles
+bool gemm_fewrow_takes(int M, int N, int K, int splits) {
+    if (splits < 1) splits = 1;
+    return M >= 1 && M <= 128 && N % 64 == 0 && K % 256 == 0 && (K / 256) % splits == 0;
 }
 
 int gemm_suggest_split_k(int M, int N, int K) {
@@ -1709,7 +2075,8 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         return;
     }
     LTX_REQUIRE(!a.ep.pn_out, "gemm: the fused PixelNorm output exists for conv launches only");
-    LTX_REQUIRE(!a.Bq, "gemm: quantised codes are only read by the experimental weight-streaming kernel");
+    LTX_REQUIRE(!a.Bq || (gemm_takes_codes(a.M, a.N, a.K) && a.split_ws && a.split_k == 0),
+                "gemm: 8-bit codes are de-quantised in the B stage of few-row launches only (M=%d N=%d K=%d)", a.M, a.N, a.K);
     if (a.split_ws && a.split_k == 0) {
         // caller-provided workspace, split count left to the launcher: few output tiles and a long reduction (the DiT at
         // small token counts, e.g. 256x256x9 -> 128 tokens: 32 tiles of weights to stream with 256 CUs) -> split K over the idle CUs
@@ -1718,15 +2085,17 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         // few rows (<= 128, e.g. 256x256x9): narrow 128x64 ring tiles - 64 column tiles at N = 4096, so 4 splits fill the chip and
         // the partial slices are a quarter of the weights (128x192 tiles needed 16 splits: as many partial bytes as weight bytes),
         // and the FFN's first GEMM (256 column tiles) needs no split at all. Config 1: 12.04 ms per forward against 12.25 (cfg 25).
-        static const int smallm_cfg = getenv("LTX_SMALLM_CFG") ? atoi(getenv("LTX_SMALLM_CFG")) : 29;
-        const int cfg = (a.M <= 128 && b.split_k > 1) ? smallm_cfg : 21;
-        if (cfg == 29) {
+        static const int smallm_cfg = getenv("LTX_SMALLM_CFG") ? atoi(getenv("LTX_SMALLM_CFG")) : 29;  // 30 (experiments build): the few-row kernel, 9 % slower
+        int cfg = a.Bq ? (a.M <= 128 ? smallm_cfg : 29) : ((a.M <= 128 && b.split_k > 1) ? smallm_cfg : 21);
+        if (cfg == 29 || cfg == 30) {
             const long tiles = (long)((a.N + 63) / 64);
             long sk = 256 / tiles;
             const int nk = a.K / BK;
             if (sk > 16) sk = 16;
             if (sk > nk / 8) sk = nk / 8;
             b.split_k = sk < 1 ? 1 : (int)sk;
+            while (b.split_k > 1 && (long)b.split_k * a.M * a.N > a.split_ws_elems) --b.split_k;
+            if (cfg == 30 && !gemm_fewrow_takes(a.M, a.N, a.K, b.split_k)) cfg = 29;
         }
         if (cfg == 25) {
             const long tiles = (long)((a.N + 191) / 192);
@@ -1737,7 +2106,8 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
             b.split_k = sk < 1 ? 1 : (int)sk;
         }
         while (b.split_k > 1 && (long)b.split_k * a.M * a.N > a.split_ws_elems) --b.split_k;
-        if ((b.split_k > 1 || cfg == 29) && a.N % 4 == 0 && !a.ep.d2s) {
+        LTX_REQUIRE(!a.Bq || (a.N % 4 == 0 && !a.ep.d2s), "gemm: quantised few-row launch with N %% 4 != 0");
+        if ((b.split_k > 1 || cfg == 29 || cfg == 30) && a.N % 4 == 0 && !a.ep.d2s) {
             if (b.split_k <= 1) {
                 b.split_k = 1;  // enough column tiles to fill the chip without a split (the FFN's first GEMM)
                 b.split_ws = nullptr;

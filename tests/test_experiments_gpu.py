@@ -127,3 +127,58 @@ def test_gemm_weight_streaming_kernel_integer_exact(gpu_ctx, M, N, K, split):
     ref = A @ B.T + bias
     assert np.array_equal(as_f32(out), ref), f"{np.count_nonzero(as_f32(out) != ref)} wrong"
     assert np.array_equal(as_f32(outb), torch.from_numpy(ref).to(torch.bfloat16).float().numpy())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 256), (128, 64, 512), (100, 192, 256 * 3), (128, 16384, 4096), (128, 4096, 256 * 5), (17, 64, 256 * 7), (128, 256, 16384)])
+def test_gemm_few_row_kernel_integer_exact(gpu_ctx, M, N, K):
+    """tile_cfg 30: the few-row kernel (activation ring of 3 slots staged by waves 0-1, weight ring of 12 slots staged by waves 2-3,
+    each role on its own counted vmcnt, one barrier per K-tile; weights in macro-tiles of four K-tiles): bit-exact on integer data for
+    1 .. 64 macro-tiles (shorter and longer than both rings), ragged M, bias + f32 and bf16 outputs through the ring kernel's epilogue."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.integers(-3, 4, (M, K)).astype(np.float32)
+    B = rng.integers(-3, 4, (N, K)).astype(np.float32)
+    bias = rng.integers(-5, 6, (N,)).astype(np.float32)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    outb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.op_gemm(dev_bf16(A), dev_bf16(B), dev_f32(bias), tile_cfg=30, out_f32=out, out_bf16=outb)
+    torch.cuda.synchronize()
+    ref = A @ B.T + bias
+    assert np.array_equal(as_f32(out), ref)
+    assert np.array_equal(as_f32(outb), torch.from_numpy(ref).to(torch.bfloat16).float().numpy())
+
+
+@pytest.mark.parametrize("M,N,K,S", [(128, 4096, 4096, 4), (128, 256, 16384, 8), (77, 320, 256 * 9, 3), (1, 64, 256 * 2, 2)])
+def test_gemm_few_row_kernel_split_k_integer_exact(gpu_ctx, M, N, K, S):
+    rng = np.random.default_rng(M + N + K + S)
+    A = rng.integers(-3, 4, (M, K)).astype(np.float32)
+    B = rng.integers(-3, 4, (N, K)).astype(np.float32)
+    bias = rng.integers(-5, 6, (N,)).astype(np.float32)
+    out = torch.empty((M, N), device="cuda")
+    gpu_ctx.op_gemm(dev_bf16(A), dev_bf16(B), dev_f32(bias), tile_cfg=S * 100 + 30, out_f32=out)
+    torch.cuda.synchronize()
+    assert np.array_equal(as_f32(out), A @ B.T + bias)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(128, 256, 4096, 4), (128, 4096, 4096, 4), (128, 1024, 16384, 1), (77, 320, 256 * 9, 3), (128, 64, 256, 1),
+                                         (5, 128, 256 * 6, 2)])
+def test_q8_few_row_kernel_equals_the_scratch_path(ltx, oracle, gpu_ctx, M, N, K, split):
+    """The few-row kernel's de-quantising instance (codes in macro-tiles of 4 rows x 256 B, staged three macro-tiles ahead) against the
+    same kernel fed from the scratch matrix: bit-identical."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.integers(-3, 4, (M, K)).astype(np.float32)
+    codes = rng.integers(0, 256, (N, K)).astype(np.uint8)
+    scales = oracle.bf16_round((rng.random((N, K // 64)) * 0.01 + 0.002).astype(np.float32))
+    biases = oracle.bf16_round((-rng.random((N, K // 64)) * 1.0).astype(np.float32))
+    to_bf = lambda a: torch.from_numpy(ltx.f32_to_bf16_bits(a).astype(np.int16)).cuda().view(torch.bfloat16)
+    Ad, sd, bd = to_bf(A), to_bf(scales), to_bf(biases)
+    cd = torch.from_numpy(codes).cuda()
+    biasd = torch.from_numpy(rng.integers(-5, 6, (N,)).astype(np.float32)).cuda()
+    o1 = torch.full((M, N), float("nan"), device="cuda")
+    o2 = torch.full((M, N), float("nan"), device="cuda")
+    o3 = torch.full((M, N), float("nan"), device="cuda")
+    gpu_ctx.op_gemm_q8(Ad, cd, sd, bd, biasd, o1, split_k=split, tile_cfg=30)
+    gpu_ctx.op_gemm_q8(Ad, cd, sd, bd, biasd, o2, split_k=split, via_scratch=True, tile_cfg=30)
+    gpu_ctx.op_gemm_q8(Ad, cd, sd, bd, biasd, o3, split_k=split, tile_cfg=29)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and bool(torch.isfinite(o1).all())
+    assert float((o1 - o3).abs().max()) <= 1e-3 * max(1.0, float(o3.abs().max()))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One DiT forward at the other BASELINE.json configurations (full 48-layer architecture, synthetic weights): robustness +
-ms per forward. Usage: python tools/bench_dit_shapes.py"""
+ms per forward. Usage: python tools/bench_dit_shapes.py [config number] [--q8]   (--q8: qint8 transformer, LTXQuantizationConfig)"""
 import importlib
 import os
 import sys
@@ -10,9 +10,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ltx = importlib.import_module("ltx-video-swift-mlx_amd")
-only = sys.argv[1] if len(sys.argv) > 1 else None  # e.g. "1" -> only config 1
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+only = argv[0] if argv else None  # e.g. "1" -> only config 1
 ctx = ltx.Context(0)
 ctx.dit_init_synthetic(None, seed=1234)
+if "--q8" in sys.argv:
+    ctx.dit_quantize(8)
+    print("qint8 transformer" + (" (LTX_QB_OFF: every launch through the scratch matrix)" if os.environ.get("LTX_QB_OFF") else ""), flush=True)
 S = 1024
 for name, B, F, H, W in (("config 1  256x256x9   T=128 ", 1, 2, 8, 8), ("config 2  768x512x25  T=1536", 1, 4, 16, 24),
                          ("config 3  CFG pair    T=1536", 2, 4, 16, 24), ("config 4  1536x1024x25 T=6144", 1, 4, 32, 48),
