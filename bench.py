@@ -83,6 +83,39 @@ def dit_flops_per_step(T, S=1024, D=4096, L=48, B=1, executed=False):
     return B * per
 
 
+def vae_flops(F, H, W):
+    """2 * 27 * Cin * Cout * positions over the decoder's 42 convs: 12.96 TFLOP at the 4x16x24 latent."""
+    ch = (1024, 512, 256, 128)
+    fl = 2 * 27 * 128 * ch[0] * F * H * W
+    f, h, w = F, H, W
+    for g, c in enumerate(ch):
+        fl += 10 * 2 * 27 * c * c * f * h * w
+        if g < 3:
+            fl += 2 * 27 * c * 4 * c * f * h * w
+            f, h, w = 2 * f - 1, 2 * h, 2 * w
+    return fl + 2 * 27 * 128 * 48 * f * h * w
+
+
+def cpu_baseline_vae(F, H, W):
+    """The oracle's VAE decode (numpy) of a SMALL latent on the host cores, scaled by FLOPs to the bench's decode: the CPU side of
+    'VAE decode ms' (BASELINE.md section 3). A reported baseline, not a target."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ltx_oracle as o
+
+    w = o.synth_vae_weights(seed=5)
+    sf, sh, sw = 2, 4, 4
+    lat = np.random.default_rng(0).standard_normal((1, 128, sf, sh, sw)).astype(np.float32)
+    t0 = time.perf_counter()
+    frames = o.decode_video(w, lat)
+    el = time.perf_counter() - t0
+    ratio = vae_flops(F, H, W) / vae_flops(sf, sh, sw)
+    return {"decode_ms": round(1e3 * el * ratio, 1), "unit": "ms per decode of the 4x16x24 latent (scaled)",
+            "sample": f"oracle.decode_video of a {sf}x{sh}x{sw} latent -> {frames.shape[0]}x{frames.shape[1]}x{frames.shape[2]} frames in {el:.2f} s "
+                      f"({vae_flops(sf, sh, sw) / 1e12:.3f} TFLOP, numpy f32), scaled x{ratio:.1f} by conv FLOPs to {vae_flops(F, H, W) / 1e12:.2f} TFLOP"}
+
+
 def cpu_baseline(T, S, budget_s=20.0):
     """Oracle (numpy, f32 activations x bf16-rounded weights) on the host cores: time whole transformer blocks at
     the bench workload's shapes, extrapolate to 48 blocks. Bounded to ~budget_s seconds."""
@@ -126,7 +159,8 @@ def cpu_baseline(T, S, budget_s=20.0):
         nthreads = max([p.get("num_threads", 1) for p in threadpool_info()] or [ncores])
     except Exception:
         nthreads = ncores
-    return {"value": steps_per_s, "unit": "steps/s", "cores": int(min(ncores, nthreads)), "kind": "port",
+    return {"value": steps_per_s, "unit": "steps/s", "cores": int(min(ncores, nthreads)), "host_cores": int(ncores), "blas_threads": int(nthreads),
+            "kind": "port",
             "sample": f"{nblk} of the 48 transformer blocks of one 768x512x25 step (T={T}, S={S}, D=4096; the blocks are 99.7 % of a "
                       f"step's FLOPs) in {el:.1f} s of numpy/BLAS f32 on {nthreads} BLAS threads ({ncores} schedulable host cores), "
                       f"scaled x48/{nblk}; the reference recomputes the text K/V every step and so does this sample"}
@@ -437,6 +471,10 @@ def run_replica(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side):
         guarded_extra_legs(out, rank, legs_fn, 240.0)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T, S_TEXT)
+        try:
+            out["cpu_baseline"]["vae"] = cpu_baseline_vae(F, H, W)
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"]["vae"] = {"error": repr(e)}
     return out
 
 
