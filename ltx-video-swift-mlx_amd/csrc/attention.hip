@@ -663,13 +663,15 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     const W48Lane L = w48_lane(lane, wave, a.ldk, a.ldvt);
     // any Tq / Tk: query rows past Tq read row Tq-1 and their stores fall outside the O descriptor; key rows past Tk read zeros
     // through the K descriptor and are masked to -inf in the last tile (tmask: bit kb*4+j = this lane's key (kb, j) is invalid)
-    int qo[3], oo[3];
+    int qo[3];
 #pragma unroll
     for (int qb = 0; qb < 3; ++qb) {
         const int qi = q0 + 16 * qb + c16;
         qo[qb] = ((qi < a.Tq ? qi : a.Tq - 1) * (int)a.ldq + g * 8) * 2;
-        oo[qb] = (qi * (int)a.ldo + g * 4) * 2;
     }
+    // epilogue: the wave's [48 rows][256 B] output block goes through LDS so that the stores are whole rows (the assembly derives the
+    // lane geometry itself); eso = byte offset of the wave's first output row, o1 = one row, o4 = four rows
+    const uint32_t eso = (uint32_t)((long)q0 * a.ldo * 2), o1 = (uint32_t)(a.ldo * 2), o4 = (uint32_t)(4 * a.ldo * 2);
     const uint32_t nt = (uint32_t)((a.Tk + KV_TILE - 1) / KV_TILE);
     const uint32_t rag = (uint32_t)__builtin_amdgcn_readfirstlane((a.Tk % KV_TILE) != 0 ? 1 : 0);
     uint32_t tmask = 0;
@@ -701,8 +703,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
 #define W48_OPERANDS                                                                                                                  \
     [qbase] "s"(Qb), [oblo] "s"(oblo), [obhi] "s"(obhi), [orec] "s"(orec), [rag] "s"(rag), [tmask] "v"(tmask), [kblo] "s"(kblo),         \
         [kbhi] "s"(kbhi), [vblo] "s"(vblo), [vbhi] "s"(vbhi), [krec] "s"(krec), [vrec] "s"(vrec), [ktb] "s"(ktb), [nt] "s"(nt),          \
-        [c] "s"(c), [tau] "s"(tau), [wlds] "s"(wlds), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]), [qo2] "v"(qo[2]), [oo0] "v"(oo[0]),             \
-        [oo1] "v"(oo[1]), [oo2] "v"(oo[2]), [ko0] "v"(L.koff[0]), [ko1] "v"(L.koff[1]), [ko2] "v"(L.koff[2]), [ko3] "v"(L.koff[3]),       \
+        [c] "s"(c), [tau] "s"(tau), [wlds] "s"(wlds), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]), [qo2] "v"(qo[2]), [eso] "s"(eso),               \
+        [o1] "s"(o1), [o4] "s"(o4), [ko0] "v"(L.koff[0]), [ko1] "v"(L.koff[1]), [ko2] "v"(L.koff[2]), [ko3] "v"(L.koff[3]),       \
         [vo0] "v"(L.voff[0]), [vo1] "v"(L.voff[1]), [vo2] "v"(L.voff[2]), [vo3] "v"(L.voff[3]), [ka0] "v"(L.kaddr[0]),                  \
         [ka1] "v"(L.kaddr[1]), [ka2] "v"(L.kaddr[2]), [ka3] "v"(L.kaddr[3]), [va0] "v"(L.vaddr[0]), [va1] "v"(L.vaddr[1])
     if constexpr (HAS_BIAS) {

@@ -567,10 +567,46 @@ class Gen:
         e("s_branch 10b")
         e("30:")
         self.kstamp(2)
-        e("; ---- epilogue ----")
+        e("; ---- epilogue: normalise, stage the wave's 48 output rows in LDS, store whole rows ----")
+        # O leaves the accumulators as 8-byte pieces at a 8 KB row stride (a lane owns 4 consecutive d of one query): stored like that,
+        # every buffer_store touches 16 rows x 32 B and the kernel's tail is store-issue bound (~9 k cycles). Instead each wave writes
+        # its [48 rows][256 B] block to LDS (ring slots 0 / 1 are free behind the barrier; 16-byte chunks XOR-swizzled by the row so that
+        # both the 8-byte writes and the 16-byte row reads are conflict-free) and stores 4 full rows per instruction (dwordx4).
         e("s_waitcnt vmcnt(0)")
+        e("s_barrier")              # every wave has left the ring
         e("s_nop 7")
         e("s_nop 7")
+        # lane geometry in registers of its own (no operands: the compiler has few VGPRs left beside the ~225 this stream owns)
+        LN, C16, G, EST, ESX, ERB, ERX, ESO = (SB + 48 + k for k in range(8))   # v[144:151] (P fragments: dead)
+        e(f"v_mbcnt_lo_u32_b32 v{LN}, -1, 0")
+        e(f"v_mbcnt_hi_u32_b32 v{LN}, -1, v{LN}")
+        e(f"v_and_b32 v{C16}, 15, v{LN}")
+        e(f"v_lshrrev_b32 v{G}, 4, v{LN}")
+        e("s_mul_i32 s47, %[wlds], 12")                       # wave * 12288: the wave's staging block
+        # write side: lane (c16, g) holds 4 consecutive d of row 16 qb + c16 per (qb, db): 8 bytes at chunk (2 db + g / 2) ^ c16
+        #   est = wave * 12288 + c16 * 256 + (g & 1) * 8 ; esx = ((g >> 1) ^ c16) << 4 ; address = est + qb * 4096 + ((db << 5) ^ esx)
+        e(f"v_lshlrev_b32 v{EST}, 8, v{C16}")
+        e(f"v_and_b32 v{RT}, 1, v{G}")
+        e(f"v_lshl_add_u32 v{EST}, v{RT}, 3, v{EST}")
+        e(f"v_add_u32 v{EST}, s47, v{EST}")
+        e(f"v_lshrrev_b32 v{ESX}, 1, v{G}")
+        e(f"v_xor_b32 v{ESX}, v{ESX}, v{C16}")
+        e(f"v_lshlrev_b32 v{ESX}, 4, v{ESX}")
+        # read side: lane (lr = g, c = c16) takes chunk c of rows 4 i + lr: erb + (i & 3) * 1024 + (erx ^ ((i & 3) << 6)) + (i >> 2) * 4096
+        #   erb = wave * 12288 + lr * 256 ; erx = (c ^ lr) << 4
+        e(f"v_lshlrev_b32 v{ERB}, 8, v{G}")
+        e(f"v_add_u32 v{ERB}, s47, v{ERB}")
+        e(f"v_xor_b32 v{ERX}, v{C16}, v{G}")
+        e(f"v_lshlrev_b32 v{ERX}, 4, v{ERX}")
+        # global row offset of the lane's first row group: (q0w + lr) * ldo * 2 + c * 16, q0w * ldo * 2 = %[eso] (scalar), ldo * 2 = %[o1]
+        e(f"v_mul_lo_u32 v{ESO}, v{G}, %[o1]")
+        e(f"v_lshl_add_u32 v{ESO}, v{C16}, 4, v{ESO}")
+        e(f"v_add_u32 v{ESO}, %[eso], v{ESO}")
+        WA = SA                      # v[48:55]: write address per db
+        for db in range(8):
+            e(f"v_xor_b32 v{WA + db}, {db << 5}, v{ESX}")
+            e(f"v_add_u32 v{WA + db}, v{WA + db}, v{EST}")
+        T = SA + 8                   # temporaries v[56:...]
         for qb in range(3):
             e(f"v_accvgpr_read_b32 v{RT}, a{LACC + 4 * qb}")
             e("s_nop 1")
@@ -578,14 +614,32 @@ class Gen:
             e("s_nop 1")
             for db in range(8):
                 a = o_reg(db, qb)
+                t = T + 6 * ((qb * 8 + db) % 6)
                 for j in range(4):
-                    e(f"v_accvgpr_read_b32 v{RT + 1 + j}, a{a + j}")
-                e("s_nop 1")
+                    e(f"v_accvgpr_read_b32 v{t + j}, a{a + j}")
+                e("s_nop 0")
                 for j in range(4):
-                    e(f"v_mul_f32 v{RT + 1 + j}, v{RT + 1 + j}, v{RT}")
-                e(f"v_cvt_pk_bf16_f32 v{RT + 5}, v{RT + 1}, v{RT + 2}")   # v[192:193]: 64-bit aligned store data
-                e(f"v_cvt_pk_bf16_f32 v{RT + 6}, v{RT + 3}, v{RT + 4}")
-                e(f"buffer_store_dwordx2 v[{RT + 5}:{RT + 6}], %[oo{qb}], s[60:63], 0 offen offset:{db * 32}")
+                    e(f"v_mul_f32 v{t + j}, v{t + j}, v{RT}")
+                e(f"v_cvt_pk_bf16_f32 v{t + 4}, v{t}, v{t + 1}")
+                e(f"v_cvt_pk_bf16_f32 v{t + 5}, v{t + 2}, v{t + 3}")
+                e(f"ds_write_b64 v{WA + db}, v[{t + 4}:{t + 5}] offset:{qb * 4096}")
+        e("s_waitcnt lgkmcnt(0)")    # a wave reads back only what it wrote itself: no barrier
+        # read row group i, store 4 whole rows per instruction
+        R = SB                       # v[96:143]: 12 x 4 registers
+        RA4 = SA + 8                 # v[56:59]: read address per i & 3 (the write temporaries are dead)
+        for n in range(4):
+            e(f"v_xor_b32 v{RA4 + n}, {n << 6}, v{ERX}")
+            e(f"v_add_u32 v{RA4 + n}, v{RA4 + n}, v{ERB}")
+        for i in range(12):
+            e(f"ds_read_b128 v[{R + 4 * i}:{R + 4 * i + 3}], v{RA4 + (i & 3)} offset:{(i >> 2) * 4096 + (i & 3) * 1024}")
+        O0 = SA + 12                 # v60, v61: two offset registers (the store in flight keeps its own)
+        e(f"v_mov_b32 v{O0}, v{ESO}")
+        for i in range(12):
+            cur, nxt = O0 + (i & 1), O0 + ((i + 1) & 1)
+            if i < 11:
+                e(f"v_add_u32 v{nxt}, %[o4], v{cur}")
+            e(f"s_waitcnt lgkmcnt({11 - i})")
+            e(f"buffer_store_dwordx4 v[{R + 4 * i}:{R + 4 * i + 3}], v{cur}, s[60:63], 0 offen")
         # no wait for the stores: they may complete after the wave ends (the LDS-DMA issued past the last tile was waited for above)
         if self.stamps:
             e("s_waitcnt vmcnt(0)")
