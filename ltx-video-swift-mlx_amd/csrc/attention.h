@@ -19,6 +19,7 @@ struct AttnArgs {
     // exponents and `scale` is ignored. The assembly kernel then runs a stream without its 48 v_mul per key tile; the other
     // kernels run with scale = ln 2. The bias stays in the reference's units (added to score * scale).
     int q_prescaled = 0;
+    int plain_order = 0;  // 1: workgroups in (query block, head, batch) order instead of the XCD-aware order (A/B measurements only)
 };
 // what a producer multiplies q by for q_prescaled: (1 / sqrt(128)) * log2(e)
 constexpr float kAttnQueryPrescale = 0.08838834764831845f * 1.4426950408889634f;

@@ -508,11 +508,11 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_kernel_pp(const AttnArgs a) {
 struct AttnBlock {
     int x, head, b;
 };
-LTX_DEVFN AttnBlock attn_block(int nqb, int H, int B) {
+LTX_DEVFN AttnBlock attn_block(int nqb, int H, int B, int plain_order) {
     const int id = blockIdx.x;
     const int G = H * B;
     int x, hb;
-    if ((G & 7) == 0) {
+    if ((G & 7) == 0 && !plain_order) {
         const int xcd = id & 7, j = id >> 3;
         hb = xcd + 8 * (j / nqb);
         x = j % nqb;
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c16 = lane & 15, g = lane >> 4;
-    const AttnBlock blk = attn_block((a.Tq + W48_Q - 1) / W48_Q, a.H, a.B);
+    const AttnBlock blk = attn_block((a.Tq + W48_Q - 1) / W48_Q, a.H, a.B, a.plain_order);
     const int head = blk.head, b = blk.b;
     const bf16_t* Qb = a.Q + (long)b * a.q_bstride + head * 128;
     const bf16_t* Kb = a.K + (long)b * a.k_bstride + head * 128;
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_x32_asm(const AttnArgs
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int hwv = wave & 1, pair = wave >> 1;
-    const AttnBlock blk = attn_block((a.Tq + X32_Q - 1) / X32_Q, a.H, a.B);
+    const AttnBlock blk = attn_block((a.Tq + X32_Q - 1) / X32_Q, a.H, a.B, a.plain_order);
     const int head = blk.head, b = blk.b;
     const bf16_t* Qb = a.Q + (long)b * a.q_bstride + head * 128;
     const bf16_t* Kb = a.K + (long)b * a.k_bstride + head * 128;
@@ -863,6 +863,8 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
     // q_prescaled: every kernel but the prescaled assembly stream computes exp2(score * scale * log2(e)); with Q carrying
     // scale * log2(e) already that factor must be 1, i.e. scale = ln 2
     if (a.q_prescaled) a.scale = 0.6931471805599453f;
+    static const bool plain = getenv("LTX_ATTN_PLAIN_ORDER") != nullptr;  // A/B hook: (query block, head, batch) workgroup order as before round 3
+    if (plain) a.plain_order = 1;
     LTX_REQUIRE(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "attention: empty problem");
     LTX_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 4 == 0, "attention: leading dims");
     LTX_REQUIRE(a.ldvt >= ((a.Tk + 63) / 64) * 64, "attention: Vt row stride %ld must cover Tk=%d rounded up to 64", a.ldvt, a.Tk);
