@@ -258,6 +258,9 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="accepted for compatibility: the legs are off unless --extra-legs")
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher self-test: ranks rendezvous over gloo, count themselves and print the line without touching a GPU")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N ranks on ONE GPU over gloo (every rank on cuda:0, host-staged collectives): executes the multi-rank code of "
+                         "this script where a single GPU is all there is; the line is labelled and is not a scaling measurement")
     ap.add_argument("--selftest-legs", choices=("hang", "error", "ok"), default=None,
                     help="with --launch-check: drive the extra-legs guard with a fake leg that hangs / raises / returns (no GPU)")
     args = ap.parse_args()
@@ -304,10 +307,15 @@ def main():
             dist.destroy_process_group()
         return
 
+    if args.rehearse_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     side = None  # gloo side channel: carries the 128-byte RCCL ids of the library's own communicators
-    if world > 1:
+    if world > 1 and args.rehearse_one_gpu:
+        dist.init_process_group("gloo")
+        side = dist.group.WORLD
+    elif world > 1:
         dist.init_process_group("nccl", device_id=dev)
         side = dist.new_group(backend="gloo")
     ones = torch.ones(1, device=dev)
@@ -322,6 +330,8 @@ def main():
     runner = {"replica": run_replica, "cfg-pair": run_cfg_pair, "sp": run_sp, "vae-tiles": run_vae_tiles}[args.mode]
     out = runner(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side)
     out["n_ranks_seen"] = n_ranks_seen
+    if args.rehearse_one_gpu:
+        out["rehearsal"] = f"{world} ranks share ONE GPU over gloo: code-path rehearsal, not a scaling measurement"
     out["launcher"] = "bench.py" if os.environ.get("LTX_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process")
     status = out.pop("_exit_status", 0)
     if rank == 0:

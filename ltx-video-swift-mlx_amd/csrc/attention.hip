@@ -30,6 +30,28 @@ constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Workgroup -> (query block, head, batch element) for the one-workgroup-per-CU kernels. Workgroups are dealt round-robin over the
+// 8 XCDs (blocks b and b + 8 share an L2: observed, for speed only), so with the plain (x, head, b) grid the query blocks of ONE head
+// land on eight different L2s and every XCD pulls every head's K / V^T through the fabric: 8 x the bytes. Here a 1-D grid is decoded
+// so that all query blocks of a head instance sit on one XCD (heads xcd, xcd + 8, ... per XCD), when the head count allows it.
+struct AttnBlock {
+    int x, head, b;
+};
+LTX_DEVFN AttnBlock attn_block(int nqb, int H, int B, int plain_order) {
+    const int id = blockIdx.x;
+    const int G = H * B;
+    int x, hb;
+    if ((G & 7) == 0 && !plain_order) {
+        const int xcd = id & 7, j = id >> 3;
+        hb = xcd + 8 * (j / nqb);
+        x = j % nqb;
+    } else {
+        hb = id / nqb;
+        x = id % nqb;
+    }
+    return AttnBlock{x, hb % H, hb / H};
+}
+
 // One online-softmax update for this lane's query column over a 64-key tile: scores s (register e of s[kb] is key
 // k0 + kb*32 + 16*(e>>3) + 8*h + (e&7)) -> P as the PV product's bf16 B operand, running max / sum, O rescale.
 //
@@ -104,8 +126,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int head = blockIdx.y;
-    const int b = blockIdx.z;
+    const AttnBlock blk = attn_block((a.Tq + 127) / 128, a.H, a.B, a.plain_order);
+    const int head = blk.head;
+    const int b = blk.b;
     const int r = lane & 31, h = lane >> 5;
 
     const bf16_t* Qb = a.Q + (long)b * a.q_bstride + head * 128;
@@ -113,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     const bf16_t* Vb = a.Vt + (long)b * a.vt_bstride + (long)head * 128 * a.ldvt;
     const float* biasb = HAS_BIAS ? a.bias + (long)b * a.bias_bstride : nullptr;
 
-    const int q_base = blockIdx.x * 128 + wave * 32;
+    const int q_base = blk.x * 128 + wave * 32;
     const int qi = q_base + r;
     const int qrow = qi < a.Tq ? qi : a.Tq - 1;
 
@@ -278,8 +301,9 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_kernel_pp(const AttnArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave >> 2;
-    const int head = blockIdx.y;
-    const int b = blockIdx.z;
+    const AttnBlock blk = attn_block((a.Tq + PP_Q - 1) / PP_Q, a.H, a.B, a.plain_order);
+    const int head = blk.head;
+    const int b = blk.b;
     const int r = lane & 31, h = lane >> 5;
 
     const bf16_t* Qb = a.Q + (long)b * a.q_bstride + head * 128;
@@ -287,7 +311,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_kernel_pp(const AttnArgs a) {
     const bf16_t* Vb = a.Vt + (long)b * a.vt_bstride + (long)head * 128 * a.ldvt;
     const float* biasb = HAS_BIAS ? a.bias + (long)b * a.bias_bstride : nullptr;
 
-    const int qi = blockIdx.x * PP_Q + wave * 32 + r;
+    const int qi = blk.x * PP_Q + wave * 32 + r;
     const int qrow = qi < a.Tq ? qi : a.Tq - 1;
     s16x8 qf[8];
 #pragma unroll
@@ -457,7 +481,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_kernel_pp(const AttnArgs a) {
     if (group == 0) pp_barrier();  // pairs with group 1's last loop barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two stages issued past the end must not outlive the workgroup's LDS
 #ifdef PP_STAMPS
-    if (blockIdx.x == 1 && blockIdx.y == 3 && lane == 0) {
+    if (blk.x == 1 && head == 3 && lane == 0) {
         for (int i = 0; i < 6; ++i) g_pp_stamps[wave][i] = st_[i];
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -501,28 +525,6 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_kernel_pp(const AttnArgs a) {
 // to the compiler (which parks half the state in AGPRs and moves it back and forth): it exists to pin the layout with the
 // parity tests; the fast path is the assembly main loop generated from the same layout (attention_w48_asm.inc).
 // ---------------------------------------------------------------------------------------------------------------
-// Workgroup -> (query block, head, batch element) for the one-workgroup-per-CU kernels. Workgroups are dealt round-robin over the
-// 8 XCDs (blocks b and b + 8 share an L2: observed, for speed only), so with the plain (x, head, b) grid the query blocks of ONE head
-// land on eight different L2s and every XCD pulls every head's K / V^T through the fabric: 8 x the bytes. Here a 1-D grid is decoded
-// so that all query blocks of a head instance sit on one XCD (heads xcd, xcd + 8, ... per XCD), when the head count allows it.
-struct AttnBlock {
-    int x, head, b;
-};
-LTX_DEVFN AttnBlock attn_block(int nqb, int H, int B, int plain_order) {
-    const int id = blockIdx.x;
-    const int G = H * B;
-    int x, hb;
-    if ((G & 7) == 0 && !plain_order) {
-        const int xcd = id & 7, j = id >> 3;
-        hb = xcd + 8 * (j / nqb);
-        x = j % nqb;
-    } else {
-        hb = id / nqb;
-        x = id % nqb;
-    }
-    return AttnBlock{x, hb % H, hb / H};
-}
-
 constexpr int W48_Q = 192;
 constexpr int W48_SLOTS = 4;
 constexpr int W48_LDS = W48_SLOTS * STAGE_BYTES;
@@ -952,7 +954,7 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_pp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_pp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
             });
-            dim3 grid_pp((a.Tq + PP_Q - 1) / PP_Q, a.H, a.B);
+            dim3 grid_pp(((a.Tq + PP_Q - 1) / PP_Q) * a.H * a.B);
             if (a.bias)
                 hipLaunchKernelGGL((attn_fwd_kernel_pp<true>), grid_pp, dim3(512), PP_LDS, stream, a);
             else
@@ -961,7 +963,7 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
             return;
         }
     }
-    dim3 grid((a.Tq + 127) / 128, a.H, a.B);
+    dim3 grid(((a.Tq + 127) / 128) * a.H * a.B);
     const int lds = 2 * STAGE_BYTES;
     if (a.bias)
         hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, dim3(256), lds, stream, a);

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -51,3 +53,19 @@ def test_extra_legs_guard_fails_the_run_on_hang_and_error():
                        env=_clean_env(), timeout=120)
     assert r.returncode == 0
     assert json.loads(r.stdout.strip().splitlines()[-1])["extra_legs_status"] == "ok"
+
+
+@pytest.mark.gpu
+def test_two_rank_replica_line_rehearsed_on_one_gpu():
+    """The N > 1 code of bench.py (launcher, rank count by all-reduce, context broadcast, barrier-bracketed timing, MAX over ranks,
+    per-rank times) executed with two ranks that share the box's one GPU over gloo (--rehearse-one-gpu). Not a scaling number - the
+    line says so - but every statement a real 2-GPU run executes outside RCCL has run before the driver's scaling run does."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1", "--no-vae", "--no-aux",
+                        "--no-prof"], capture_output=True, text=True, env=_clean_env(), timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["scaling"] == "weak" and "rehearsal" in out
+    assert len(out["per_rank_ms_per_step"]) == 2 and out["value"] > 0
+    assert abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) < 0.05 * out["value"]   # whole-job steps/s = ranks x steps / max time
