@@ -65,6 +65,11 @@ struct Conv3dGeom {
                        // padding=1, SpatialUpscaler.swift:78-92,139-145): out-of-range taps read the all-zero row that
                        // the caller keeps at position index F*H*W of the input tensor; 2: replicate H/W/T
     int kt = 3;        // temporal taps: 3 (3x3x3) or 1 (per-frame 3x3 conv2d)
+    // Tile order of launches with ONE column tile (N <= 128): row-groups (192-position tiles) per frame when H * W % 192 == 0, else 0.
+    // The workgroups that run together on an XCD then cover a compact block of 8 row-groups x 4 frames instead of 32 consecutive
+    // row-groups of one frame: their 27-tap halo working set is (8 + 2) x (4 + 2) rows (2.9 MB at 128 channels x 192 voxels) instead
+    // of (32 + 2) x 3 (5 MB), i.e. inside the XCD's 4 MB L2. Speed only: every tile is computed exactly once either way.
+    int blk_rg = 0;
 };
 
 struct GemmArgs {

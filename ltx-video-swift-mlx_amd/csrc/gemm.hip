@@ -52,6 +52,20 @@ LTX_DEVFN void static_for(F&& f) {
 // instead of every row-tile x few columns. Every XCD's L2 fetches each operand tile it touches once from the fabric, so
 // this trades re-reads of A (rows) against re-reads of B (columns): measured on MI355X with group_m = 4 vs column-major:
 // 6144x4096x4096 833 -> 1039 TFLOP/s, 4096^3 897 -> 1017, 1536x4096x16384 1099 -> 1146 (PMC: A was fetched 8x).
+// conv launches with one column tile: position L of the launch order -> row tile, blocked 8 row-groups x 4 frames (Conv3dGeom::blk_rg)
+LTX_DEVFN int conv_block_order(int L, int F, int RG) {
+    constexpr int FB = 4;
+    const int RB = RG < 8 ? RG : 8;
+    const int fgi = L / (FB * RG);
+    const int f0 = fgi * FB;
+    const int nf = (F - f0) < FB ? (F - f0) : FB;
+    const int w = L - fgi * FB * RG;
+    const int per = nf * RB;
+    const int rbi = w / per, v = w - rbi * per;
+    const int fo = v / RB, ro = v - fo * RB;
+    return (f0 + fo) * RG + rbi * RB + ro;
+}
+
 LTX_DEVFN void tile_coords(const GemmArgs& g, int bid, int tiles_m, int BN_, int& tm, int& tn) {
     if (g.group_m > 0 && g.group_m < tiles_m) {
         const int tiles_n = (g.N + BN_ - 1) / BN_;
@@ -670,6 +684,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     const int bid = xcd_remap(blockIdx.x, gridDim.x) + g.tile0;
     int tm, tn;
     tile_coords(g, bid, tiles_m, BN, tm, tn);
+    if constexpr (CONV && BM == 192) {
+        if (g.geom.blk_rg > 0 && g.tile_count == 0 && g.split_k <= 1 && g.N <= BN) tm = conv_block_order(tm, g.geom.F, g.geom.blk_rg);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 #ifdef GEMM_V2_STAMPS  // tools/ubench/gemm_stamps.hip: 100 MHz wall-clock stamps of one wave (prologue / main loop / epilogue)
     const unsigned long long st0 = wall_clock64();

@@ -6,6 +6,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "elementwise.h"
@@ -237,6 +238,8 @@ void conv3d(const bf16_t* x, const Dims& d, const ConvW& cw, GemmEpilogue ep, hi
     g.geom.C = cw.cin;
     g.geom.causal = 0;    // the pipeline builds the decoder with causal:false (LTXPipeline.swift:338)
     g.geom.pad_mode = 0;  // reflect
+    static const bool blk_on = getenv("LTX_CONV_BLOCK") == nullptr || getenv("LTX_CONV_BLOCK")[0] != '0';  // A/B hook
+    if (blk_on && (d.H * d.W) % 192 == 0 && ((d.H * d.W) / 192 < 8 || (d.H * d.W) / 192 % 8 == 0)) g.geom.blk_rg = d.H * d.W / 192;
     ep.bias_n = cw.b;
     g.ep = ep;
     if (skws && !ep.d2s && cw.cout % 4 == 0) {
