@@ -517,14 +517,27 @@ class Gen:
                 e(f"s_add_u32 s47, %[wlds], {i * 4096}")
                 e("buffer_load_dwordx4 %[bvo], s[56:59], s47 offen lds")
             e(f"v_mov_b32 v{BADDR}, %[ba]")
-        e("; ---- tiles 0, 1, 2 ----")
+        # Every CU starts at once and the memory system serves the burst roughly first come, first served: with Q and three tiles
+        # requested up front (144 KB per CU, 37 MB in all) the first K.Q^T waited for most of it. Only Q, K0 and V0 are requested
+        # before the first wait; tiles 1 and 2 are staged in the gaps of the first K.Q^T product (W48_PROLOGUE=early restores the
+        # old order for A/B stamps).
+        late = os.environ.get("W48_PROLOGUE") != "early"
+        e("; ---- tile 0" + ("" if late else ", 1, 2") + " ----")
         n_stage_ops = 0
+        later = []
         for t in range(3):
-            for grp in self.stage(t):
-                for ins in grp:
+            grps = self.stage(t)
+            n_stage_ops += sum(ins.startswith("buffer_load") for grp in grps for ins in grp)
+            adv = ["s_add_u32 s44, s44, %[ktb]", "s_add_u32 s45, s45, 128"]
+            if late and t > 0:
+                later += grps
+                later[-1] = later[-1] + adv   # the offsets advance behind the tile's last piece
+            else:
+                for grp in grps:
+                    for ins in grp:
+                        e(ins)
+                for ins in adv:
                     e(ins)
-                    n_stage_ops += ins.startswith("buffer_load")
-            self.advance_stage_offsets()
         assert n_stage_ops == 3 * STAGE_OPS, n_stage_ops
         for i in range(LACC + 12):
             e(f"v_accvgpr_write_b32 a{i}, 0")
@@ -540,10 +553,13 @@ class Gen:
         # the end of step 0 retires them before step 1 reads them. check_wait_coverage() proves both (a prologue that left K1 in
         # flight shipped once and raced: DESIGN.md).
         half = STAGE_OPS // 2
-        e(f"s_waitcnt vmcnt({3 * STAGE_OPS - half})")     # everything up to K0 has landed
+        e(f"s_waitcnt vmcnt({(STAGE_OPS if late else 3 * STAGE_OPS) - half})")     # everything up to K0 has landed
         e("s_barrier")
-        for kind, text in self.qk_stream(SA, 0):
-            e(text)
+        if late:
+            self.spread_gaps(self.qk_stream(SA, 0), later, 40)
+        else:
+            for kind, text in self.qk_stream(SA, 0):
+                e(text)
         e("s_nop 7")
         e("s_nop 7")
         self.tail_mask("8", SA, 1)       # a single, ragged tile
