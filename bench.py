@@ -56,8 +56,8 @@ PEAK_BF16_TFLOPS = 2500.0
 # Reported beside `frac` for context only; `frac` stays priced against the 2.5 PFLOP/s headline.
 SUSTAINED_BF16_TFLOPS = 2000.0
 HBM_PEAK_GBPS = 8000.0
-TRAFFIC_FILES = ("r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
-VAE_TRAFFIC_FILES = ("r02_pmc_traffic_vae.json",)
+TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+VAE_TRAFFIC_FILES = ("r03_pmc_traffic_vae.json", "r02_pmc_traffic_vae.json")
 
 
 def pmc_traffic(files=None):

@@ -16,7 +16,29 @@ def family(name):
     return re.sub(r"\(.*\)$", "", name)
 
 
+def load_db(path, counter):
+    """rocpd sqlite database (the default output of this ROCm's rocprofv3)"""
+    import sqlite3
+
+    acc = defaultdict(list)
+    cur = sqlite3.connect(path).cursor()
+    q = ("select s.kernel_name, e.value from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
+         "join rocpd_kernel_dispatch d on d.event_id = e.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id where p.name = ?")
+    for name, val in cur.execute(q, (counter,)):
+        acc[family(demangle(name))].append(float(val))
+    return acc
+
+
+def demangle(name):
+    """_ZN12_GLOBAL__N_119gemm_bf16_kernel_v2ILi192E...  ->  gemm_bf16_kernel_v2<...> (enough for family())"""
+    name = name.replace("_ZN12_GLOBAL__N_1", "").replace("_Z", "")
+    m = re.match(r"(\d+)(.*)", name)
+    return m.group(2)[:int(m.group(1))] + ("<" + m.group(2)[int(m.group(1)):].split("EEv")[0] + ">" if "I" in m.group(2)[int(m.group(1)):][:1] else "") if m else name
+
+
 def load(path, counter):
+    if path.endswith(".db"):
+        return load_db(path, counter)
     acc = defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
