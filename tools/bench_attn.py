@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--once", action="store_true")
+    ap.add_argument("--impls", default="1,2,4,5,0")
     args = ap.parse_args()
     ctx = ltx.Context(0)
     H = 32
@@ -37,7 +38,7 @@ def main():
         fl = 4.0 * B * H * T * S * 128
         n = 3 if args.once else 20
         line = f"{name:24s}"
-        impls = ["1", "2", "4", "5", "0"]  # 1 = 4-wave, 2 = ping-pong, 4 = 48-query 16x16 assembly, 5 = 32x32 assembly, 0 = the launcher's choice
+        impls = args.impls.split(",")  # 1 = 4-wave, 2 = ping-pong, 4 = 48-query 16x16 assembly, 5 = 32x32 assembly, 0 = the launcher's choice
         best = {i: [] for i in impls}
         bad = set()
         for r in range(1 if args.once else args.rounds + 1):

@@ -46,8 +46,14 @@ RA = RN - 1  # fragment reads in flight ahead of their MFMAs. Stamps of the 4-re
              # costing ~73 cycles against 48 of MFMA issue: with four waves reading and the LDS-DMA writing, an LDS read takes ~220
              # cycles to return, so the loop ran at RA reads per latency. Seven in flight cover it; the arch VGPRs have no room for
              # a deeper ring (v0..v219 + ~36 operands), the accumulator file has 148 registers to spare.
+# Read pipeline across the step boundary (round 3, the 32x32 experiment's finding carried over): the first RA fragment reads of a step
+# used to be issued behind the step's opening barrier and waited for at once - one exposed LDS latency (~200 cycles of ~2300) per tile
+# step. Now a step's LDS-DMA is issued EARLY in the step (part A) and the step ends with vmcnt(0) + barrier, so at every barrier the
+# three tiles ahead are visible and the first RA K reads of step t+1 can be issued under the last MFMAs of step t. W48_PIPE=step
+# regenerates the old stream for A/B stamps.
+CROSS = os.environ.get("W48_PIPE") != "step"
 STAGE_OPS = 8  # LDS-DMA instructions per staged K / Vt tile (4 x 4 KB of K + 4 x 4 KB of Vt); Gen.stage() asserts it
-TILES_AHEAD = 1  # fills that may still be in flight when a step ends: the tile staged in this step (t+3) is first read two steps
+TILES_AHEAD = 0 if CROSS else 1  # fills that may still be in flight when a step ends (W48_PIPE=step): the tile staged in this step (t+3) is first read two steps
                  # later, the one staged a step earlier (t+2) is read by the next step's K.Q^T and must have landed
 
 
@@ -108,7 +114,7 @@ class Gen:
         addr = f"%[va{i}]" if slot < 2 else f"v{HI + 4 + i}"
         return f"ds_read_b128 {self.ring(ring)}, {addr} offset:{(slot & 1) * STAGE + vblock_off(db)}"
 
-    def step_stream(self, sbuf, kslot, vslot):
+    def step_stream(self, sbuf, kslot, vslot, young=0):
         """One step's MFMA work as ONE read-ahead pipeline: S(next) = K Q^T from ring slot `kslot` (16 fragments), then O += Vt P from
         `vslot` (16 fragments). Fragment F lands in ring entry F % RN, its read is issued RA fragments ahead, so the Vt reads start
         under the last K.Q^T products and the LDS latency is exposed once per step (the first RA reads), not once per stream."""
@@ -120,13 +126,19 @@ class Gen:
         frags = kf + vf
 
         def read(F):
+            if F >= len(frags):   # CROSS: the next step's first K fragments (K slot kslot + 1), same ring positions (32 % RN == 0)
+                kind, x, y = frags[F - len(frags)]
+                return ("ds", self.k_read(F, (kslot + 1) & 3, x, y))
             kind, x, y = frags[F]
             return ("ds", self.k_read(F, kslot, x, y) if kind == "k" else self.v_read(F, vslot, x, y))
 
-        out = [read(F) for F in range(RA)]
+        out = [] if CROSS else [read(F) for F in range(RA)]
         issued = RA
         for F, (kind, x, y) in enumerate(frags):
-            out.append(("wait", f"s_waitcnt lgkmcnt({issued - F - 1})"))
+            # `young`: LDS reads issued behind the RA fragment reads that are already in flight at the step's start (the masked variant's
+            # four bias reads): they are younger than fragments 0..RA-1 and older than everything issued in this step
+            keep = issued - F - 1 + (young if F < RA else 0)
+            out.append(("wait", f"s_waitcnt lgkmcnt({keep})"))
             for qb in range(3):
                 if kind == "k":
                     d = vr(s_reg(sbuf, x, qb))
@@ -135,7 +147,7 @@ class Gen:
                 else:
                     a = f"a[{o_reg(x, qb)}:{o_reg(x, qb) + 3}]"
                     out.append(("mfma", f"v_mfma_f32_16x16x32_bf16 {a}, {self.ring(F)}, {vr(PF + (qb * 2 + y) * 4)}, {a}"))
-            if F + RA < len(frags):
+            if F + RA < len(frags) or CROSS:
                 out.append(read(F + RA))
                 issued += 1
             if kind == "v" and x == 7:  # end of a k-step: the same P against a block of ones = this k-step's row sums
@@ -143,6 +155,11 @@ class Gen:
                     a = f"a[{LACC + 4 * qb}:{LACC + 4 * qb + 3}]"
                     out.append(("mfma", f"v_mfma_f32_16x16x32_bf16 {a}, {vr(ONES)}, {vr(PF + (qb * 2 + y) * 4)}, {a}"))
         return out
+
+    def first_reads(self, kslot):
+        """CROSS: the RA K reads a step expects in flight at its start (issued by the prologue for the first step)."""
+        kf = [(kb, ks) for ks in range(4) for kb in range(4)]
+        return [self.k_read(F, kslot, *kf[F]) for F in range(RA)]
 
     # ---- MFMA streams: list of groups, each group = [pre-instructions..., 3 MFMAs] per fragment ----
     def qk_stream(self, sbuf, slot):
@@ -428,27 +445,36 @@ class Gen:
         mul_b = [x for x in vb if x.startswith("v_mul_f32")]
         vb = [x for x in vb if not x.startswith("v_mul_f32")]
         va = va + mul_b
-        allst = self.step_stream(nxt, (slot + 1) & 3, slot)
+        allst = self.step_stream(nxt, (slot + 1) & 3, slot, young=4 if (BIAS and CROSS) else 0)
         part_a, rest = self.split_stream(allst, 48)
         head, tail = self.split_stream(rest, 24)
-        if BIAS:  # bias of tile t+1: its reads come first in the step (older than every fragment read, so the fragment waits cover
-            self.e(f"v_add_u32 v{BADDR}, 256, v{BADDR}")   # them; v184..199 are free here: maxima / rare-path temporaries are dead)
+        if BIAS:  # bias of tile t+1: its reads come first in the step (older than every fragment read issued in it, so the fragment
+            self.e(f"v_add_u32 v{BADDR}, 256, v{BADDR}")   # waits cover them; v184..199 are free here: maxima / rare-path temporaries are dead)
             for ins in self.bias_reads():
                 self.e(ins)
             vb = vb + self.bias_add(nxt)
-        for kind, text in part_a[:RA]:
-            self.e(text)
-        npre = min(6, len(va))
-        for ins in va[:npre]:  # independent of the reads just issued: covers part of their latency
-            self.e(ins)
-        self.spread(part_a[RA:], [[x] for x in va[npre:]], 44)
+        dma = [] if "nodma" in ABL else self.stage((slot + 3) & 3)
+        if CROSS:
+            # LDS-DMA of tile t+3 early in the step, spread through part A between the exponentials
+            fill = [[x] for x in va]
+            stride = max(1, len(fill) // (len(dma) + 1)) if dma else 1
+            for k, grp in enumerate(dma):
+                fill.insert(min(len(fill), (k + 1) * stride + k), grp)
+            dma = []
+            self.spread(part_a, fill, 46)
+        else:
+            for kind, text in part_a[:RA]:
+                self.e(text)
+            npre = min(6, len(va))
+            for ins in va[:npre]:  # independent of the reads just issued: covers part of their latency
+                self.e(ins)
+            self.spread(part_a[RA:], [[x] for x in va[npre:]], 44)
         self.tail_mask(f"{uid + 10}", nxt, 2)   # S(t+1) is the last, ragged tile
         st(1)
         self.spread(head, [[x] for x in vb], 22)
         st(2)
-        dma = [] if "nodma" in ABL else self.stage((slot + 3) & 3)
         mx = self.sm_max(nxt)
-        work = []  # B2 filler: alternate maxima instructions and DMA groups
+        work = []  # B2 filler: maxima instructions (and, W48_PIPE=step, the DMA groups)
         while mx or dma:
             for _ in range(4):
                 if mx:
@@ -572,8 +598,14 @@ class Gen:
         for ins in self.sm_max(SA):
             e(ins)
         self.sm_check_and_rare_path("9", SA, force=True)
-        e(f"s_waitcnt vmcnt({STAGE_OPS + half})")          # V0 and K1 have landed; V1, K2, V2 may fly
-        e("s_barrier")
+        if CROSS:   # the first step issues the K reads of tile 2 before its closing barrier: K2 must be visible here; only V2 may fly
+            e(f"s_waitcnt vmcnt({half})")
+            e("s_barrier")
+            for r in self.first_reads(1):
+                e(r)
+        else:
+            e(f"s_waitcnt vmcnt({STAGE_OPS + half})")          # V0 and K1 have landed; V1, K2, V2 may fly
+            e("s_barrier")
         self.kstamp(1)
         e("10:")
         self.step(0, SA, SB, 11)
@@ -588,7 +620,7 @@ class Gen:
         # every buffer_store touches 16 rows x 32 B and the kernel's tail is store-issue bound (~9 k cycles). Instead each wave writes
         # its [48 rows][256 B] block to LDS (ring slots 0 / 1 are free behind the barrier; 16-byte chunks XOR-swizzled by the row so that
         # both the 8-byte writes and the 16-byte row reads are conflict-free) and stores 4 full rows per instruction (dwordx4).
-        e("s_waitcnt vmcnt(0)")
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")   # LDS-DMA issued past the last tile, fragment reads issued ahead
         e("s_barrier")              # every wave has left the ring
         e("s_nop 7")
         e("s_nop 7")
@@ -802,8 +834,8 @@ def main():
     out = os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", name)
     if "--inject-prologue-race" in sys.argv:
         # the race that shipped once (commit 7c76101): the prologue left tiles 1 and 2 in flight while step 0 reads slot 1
-        k = lines.index(f"s_waitcnt vmcnt({STAGE_OPS + STAGE_OPS // 2})")
-        assert k < lines.index("10:")
+        want = f"s_waitcnt vmcnt({STAGE_OPS // 2})" if CROSS else f"s_waitcnt vmcnt({STAGE_OPS + STAGE_OPS // 2})"
+        k = max(i for i, ln in enumerate(lines[:lines.index("10:")]) if ln == want)
         lines[k] = f"s_waitcnt vmcnt({2 * STAGE_OPS})"
     stats = None
     if not (ABL - {""}):
