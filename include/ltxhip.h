@@ -476,6 +476,11 @@ int ltx_op_gemv_f32(ltx_ctx* ctx, const float* a, long lda, const uint16_t* W, l
  * O = softmax_2(Q K^T + bias * log2(e)) V. */
 int ltx_op_attention(ltx_ctx* ctx, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, long ldvt,
                      const float* bias, int B, int H, int Tq, int Tk, float scale, uint16_t* O);
+/* Number of key ranges the attention launcher divides a launch of this shape into when it has a workspace (1 = it does not): few
+ * queries against many keys - the cross-attention of a 128-token clip is 32 workgroups walking 16 key tiles each - run one workgroup
+ * per (query block, head, key range) and a combine pass (attention.h, AttnArgs::split_ws). ltx_op_attention and the DiT forward
+ * both lend that workspace. No reference counterpart: MLXFast.scaledDotProductAttention (LTXAttention.swift:209) is one call. */
+int ltx_attention_key_splits(int B, int H, int Tq, int Tk);
 /* adaLN: out = norm(x) * (1+scale) + shift -> bf16 ; norm_kind 0 RMS, 1 LayerNorm; scale/shift [D] or NULL */
 int ltx_op_norm_mod(ltx_ctx* ctx, const float* x, const float* scale, const float* shift, int rows, int D,
                     int norm_kind, float eps, int round_norm_bf16, uint16_t* out);

@@ -628,6 +628,11 @@ class Context:
             scale = 1.0 / (128.0 ** 0.5)
         self._ck(lib.ltx_op_attention(self._h, _ptr(Q), _ptr(K), _ptr(Vt), ldvt, _ptr(bias), B, H, Tq, Tk, scale, _ptr(O)))
 
+    @staticmethod
+    def attention_key_splits(B, H, Tq, Tk):
+        """Key ranges the attention launcher divides a launch of this shape into (1 = no split)."""
+        return lib.ltx_attention_key_splits(B, H, Tq, Tk)
+
     def op_norm_mod(self, x, scale, shift, out, norm_kind=0, eps=1e-6, round_norm_bf16=False):
         rows, D = x.shape
         self._ck(lib.ltx_op_norm_mod(self._h, _ptr(x), _ptr(scale), _ptr(shift), rows, D, norm_kind, eps, int(round_norm_bf16), _ptr(out)))

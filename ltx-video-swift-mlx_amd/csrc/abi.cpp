@@ -1089,8 +1089,19 @@ int ltx_op_attention(ltx_ctx* ctx, const uint16_t* Q, const uint16_t* K, const u
         a.bias = bias; a.bias_bstride = Tk;
         a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale;
         a.q_prescaled = scale <= 0.f ? 1 : 0;  // Q already carries scale * log2(e): scores are base-2 exponents
+        // few queries against many keys: lend the launcher room to divide the keys over workgroups, as the DiT forward does
+        if (const long need = attn_split_ws_bytes(B, H, Tq, Tk)) {
+            if (ctx->op_ws.ensure((size_t)need)) HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            a.split_ws = ctx->op_ws.p;
+            a.split_ws_bytes = (long)ctx->op_ws.bytes;
+        }
         launch_attention(a, ctx->stream);
     });
+}
+
+int ltx_attention_key_splits(int B, int H, int Tq, int Tk) {
+    if (B < 1 || H < 1 || Tq < 1 || Tk < 1) return 1;
+    return attn_key_splits(B, H, Tq, Tk);
 }
 
 int ltx_op_norm_mod(ltx_ctx* ctx, const float* x, const float* scale, const float* shift, int rows, int D,

@@ -20,7 +20,20 @@ struct AttnArgs {
     // kernels run with scale = ln 2. The bias stays in the reference's units (added to score * scale).
     int q_prescaled = 0;
     int plain_order = 0;  // 1: workgroups in (query block, head, batch) order instead of the XCD-aware order (A/B measurements only)
+    // Key split (few queries against many keys: the cross-attention of a 128-token launch is 32 workgroups walking 16 key tiles each).
+    // With a workspace the launcher may divide the keys over up to 8 workgroups per (query block, head): each writes its normalised
+    // O to a slice of the workspace plus log2 of its softmax denominators, attn_combine_kernel weights the slices together.
+    // attn_split_ws_bytes() says how much a launch can use; null = never split.
+    void* split_ws = nullptr;
+    long split_ws_bytes = 0;
+    // set by the launcher for the kernels (callers leave them alone)
+    int key_splits = 1, split_keys = 0;   // number of key ranges, keys per range (a multiple of 64)
+    bf16_t* o_part = nullptr;             // [splits][B][Tq][H*128]
+    float* lse = nullptr;                 // [splits][B][H][roundup(Tq, 192)]
 };
+// workspace a key-split launch of this shape would use (0: the launcher would not split it)
+long attn_split_ws_bytes(int B, int H, int Tq, int Tk);
+int attn_key_splits(int B, int H, int Tq, int Tk);  // the number of key ranges (1 = no split)
 // what a producer multiplies q by for q_prescaled: (1 / sqrt(128)) * log2(e)
 constexpr float kAttnQueryPrescale = 0.08838834764831845f * 1.4426950408889634f;
 

@@ -657,11 +657,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     const int c16 = lane & 15, g = lane >> 4;
     const AttnBlock blk = attn_block((a.Tq + W48_Q - 1) / W48_Q, a.H, a.B, a.plain_order);
     const int head = blk.head, b = blk.b;
+    // key split: blockIdx.y = the key range of this workgroup; everything below sees that range as the whole problem
+    const int zs = a.key_splits > 1 ? (int)blockIdx.y : 0;
+    const int s0 = zs * a.split_keys;
+    const int Tk = a.key_splits > 1 ? (a.Tk - s0 < a.split_keys ? a.Tk - s0 : a.split_keys) : a.Tk;
+    const long ldo = a.key_splits > 1 ? (long)a.H * 128 : a.ldo;
     const bf16_t* Qb = a.Q + (long)b * a.q_bstride + head * 128;
-    const bf16_t* Kb = a.K + (long)b * a.k_bstride + head * 128;
-    const bf16_t* Vb = a.Vt + (long)b * a.vt_bstride + (long)head * 128 * a.ldvt;
-    bf16_t* Ob = a.O + (long)b * a.o_bstride + head * 128;
+    const bf16_t* Kb = a.K + (long)b * a.k_bstride + head * 128 + (long)s0 * a.ldk;
+    const bf16_t* Vb = a.Vt + (long)b * a.vt_bstride + (long)head * 128 * a.ldvt + s0;
+    bf16_t* Ob = a.key_splits > 1 ? a.o_part + ((long)zs * a.B + b) * a.Tq * ldo + head * 128 : a.O + (long)b * a.o_bstride + head * 128;
     const int q0 = blk.x * W48_Q + wave * 48;
+    const float* lse_w = a.key_splits > 1 ? a.lse + (((long)zs * a.B + b) * a.H + head) * ((a.Tq + W48_Q - 1) / W48_Q * W48_Q) + q0 : nullptr;
     const W48Lane L = w48_lane(lane, wave, a.ldk, a.ldvt);
     // any Tq / Tk: query rows past Tq read row Tq-1 and their stores fall outside the O descriptor; key rows past Tk read zeros
     // through the K descriptor and are masked to -inf in the last tile (tmask: bit kb*4+j = this lane's key (kb, j) is invalid)
@@ -673,20 +679,20 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     }
     // epilogue: the wave's [48 rows][256 B] output block goes through LDS so that the stores are whole rows (the assembly derives the
     // lane geometry itself); eso = byte offset of the wave's first output row, o1 = one row, o4 = four rows
-    const uint32_t eso = (uint32_t)((long)q0 * a.ldo * 2), o1 = (uint32_t)(a.ldo * 2), o4 = (uint32_t)(4 * a.ldo * 2);
-    const uint32_t nt = (uint32_t)((a.Tk + KV_TILE - 1) / KV_TILE);
-    const uint32_t rag = (uint32_t)__builtin_amdgcn_readfirstlane((a.Tk % KV_TILE) != 0 ? 1 : 0);
+    const uint32_t eso = (uint32_t)((long)q0 * ldo * 2), o1 = (uint32_t)(ldo * 2), o4 = (uint32_t)(4 * ldo * 2);
+    const uint32_t nt = (uint32_t)((Tk + KV_TILE - 1) / KV_TILE);
+    const uint32_t rag = (uint32_t)__builtin_amdgcn_readfirstlane((Tk % KV_TILE) != 0 ? 1 : 0);
     uint32_t tmask = 0;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if ((int)(nt - 1) * KV_TILE + 32 * (kb >> 1) + 4 * (kb & 1) + 8 * g + j >= a.Tk) tmask |= 1u << (kb * 4 + j);
+            if ((int)(nt - 1) * KV_TILE + 32 * (kb >> 1) + 4 * (kb & 1) + 8 * g + j >= Tk) tmask |= 1u << (kb * 4 + j);
     const uint32_t oblo = (uint32_t)(uintptr_t)Ob, obhi = (uint32_t)((uintptr_t)Ob >> 32);
-    const uint32_t orec = (uint32_t)(((long)(a.Tq - 1) * a.ldo + 128) * 2);
+    const uint32_t orec = (uint32_t)(((long)(a.Tq - 1) * ldo + 128) * 2);
     const uint32_t kblo = (uint32_t)(uintptr_t)Kb, kbhi = (uint32_t)((uintptr_t)Kb >> 32);
     const uint32_t vblo = (uint32_t)(uintptr_t)Vb, vbhi = (uint32_t)((uintptr_t)Vb >> 32);
-    const uint32_t krec = (uint32_t)(((long)(a.Tk - 1) * a.ldk + 128) * 2), vrec = (uint32_t)((long)128 * a.ldvt * 2);
+    const uint32_t krec = (uint32_t)(((long)(Tk - 1) * a.ldk + 128) * 2), vrec = (uint32_t)(((long)128 * a.ldvt - s0) * 2);
     const uint32_t ktb = (uint32_t)(KV_TILE * a.ldk * 2);
     // PRESCALED: Q carries scale * log2(e) already, the scores are base-2 exponents (c = 1, the stream has no multiplies)
     const float c = PRESCALED ? 1.0f : a.scale * 1.4426950408889634f;
@@ -694,8 +700,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     const float tau = 8.0f / c;  // raw-score threshold: the reference maximum of a query is raised only when exp2((s - ref)*c) > 2^8
     // masked variant: the bias vector of this batch element goes to LDS once (16 KB after the ring, Tk <= 4096); a lane's 16 values
     // of a tile sit at ba + 256 * tile
-    const float* biasb = HAS_BIAS ? a.bias + (long)b * a.bias_bstride : nullptr;
-    const uint32_t bilo = (uint32_t)(uintptr_t)biasb, bihi = (uint32_t)((uintptr_t)biasb >> 32), birec = (uint32_t)(a.Tk * 4);
+    const float* biasb = HAS_BIAS ? a.bias + (long)b * a.bias_bstride + s0 : nullptr;
+    const uint32_t bilo = (uint32_t)(uintptr_t)biasb, bihi = (uint32_t)((uintptr_t)biasb >> 32), birec = (uint32_t)(Tk * 4);
     const float isc = PRESCALED ? 1.4426950408889634f : 1.0f / a.scale;  // bias (post-scale, natural log) -> score units
     const int bvo = lane * 16;
     const int ba = W48_LDS + g * 32;
@@ -708,7 +714,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
         [c] "s"(c), [tau] "s"(tau), [wlds] "s"(wlds), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]), [qo2] "v"(qo[2]), [eso] "s"(eso),               \
         [o1] "s"(o1), [o4] "s"(o4), [ko0] "v"(L.koff[0]), [ko1] "v"(L.koff[1]), [ko2] "v"(L.koff[2]), [ko3] "v"(L.koff[3]),       \
         [vo0] "v"(L.voff[0]), [vo1] "v"(L.voff[1]), [vo2] "v"(L.voff[2]), [vo3] "v"(L.voff[3]), [ka0] "v"(L.kaddr[0]),                  \
-        [ka1] "v"(L.kaddr[1]), [ka2] "v"(L.kaddr[2]), [ka3] "v"(L.kaddr[3]), [va0] "v"(L.vaddr[0]), [va1] "v"(L.vaddr[1])
+        [ka1] "v"(L.kaddr[1]), [ka2] "v"(L.kaddr[2]), [ka3] "v"(L.kaddr[3]), [va0] "v"(L.vaddr[0]), [va1] "v"(L.vaddr[1]),              \
+        [lse] "s"(lse_w)
     if constexpr (HAS_BIAS) {
         if constexpr (PRESCALED) {
             asm volatile(
@@ -760,6 +767,46 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w48_asm(const AttnArgs
     }
 #undef W48_OPERANDS
     (void)smem;
+}
+
+// Key-split launches: O[b][t][h][:] = sum_z w_z O_z / sum_z w_z, w_z = exp2(lse_z - max_z lse_z) - the softmax over all keys from
+// the per-range softmaxes (each O_z is normalised over its own keys, lse_z = log2 of that range's denominator in absolute units).
+// One thread per 8 output channels (16 bytes of bf16); the slices are summed in ascending z.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const bf16_t* __restrict__ o_part, const float* __restrict__ lse, int Z, int B, int H,
+                                                           int Tq, int Tq_pad, bf16_t* __restrict__ O, long ldo, long o_bstride) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // ((b * Tq + t) * H + h) * 16 + c
+    const long total = (long)B * Tq * H * 16;
+    if (i >= total) return;
+    const int c = (int)(i & 15);
+    const int h = (int)((i >> 4) % H);
+    const long bt = (i >> 4) / H;
+    const int t = (int)(bt % Tq), b = (int)(bt / Tq);
+    float ls[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {   // Z <= 8 (attn_split_plan); unrolled so that ls[] stays in registers
+        ls[z] = z < Z ? lse[(((long)z * B + b) * H + h) * Tq_pad + t] : -INFINITY;
+        mx = fmaxf(mx, ls[z]);
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {
+        if (z < Z) {
+            const float w = exp2f(ls[z] - mx);
+            den += w;
+            const s16x8 v = *(const s16x8*)(o_part + (((long)z * B + b) * Tq + t) * ((long)H * 128) + h * 128 + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += w * bf16_to_f32((bf16_t)v[e]);
+        }
+    }
+    const float inv = 1.0f / den;
+    uint4 pk;
+    pk.x = pack_bf16x2(acc[0] * inv, acc[1] * inv);
+    pk.y = pack_bf16x2(acc[2] * inv, acc[3] * inv);
+    pk.z = pack_bf16x2(acc[4] * inv, acc[5] * inv);
+    pk.w = pack_bf16x2(acc[6] * inv, acc[7] * inv);
+    *(uint4*)(O + (long)b * o_bstride + (long)t * ldo + h * 128 + c * 8) = pk;
 }
 
 #ifdef LTX_EXPERIMENTS
@@ -860,6 +907,32 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_x32_asm(const AttnArgs
 
 }  // namespace
 
+// Key split of a launch of the 48-query kernel: only when its (query block, head, batch) workgroups leave most of the chip idle and
+// every range still has two key tiles; at most 8 ranges (attn_combine_kernel's register array), as many as fill 256 CUs.
+struct AttnSplitPlan {
+    int splits = 1, keys = 0;
+    long o_bytes = 0, bytes = 0;
+};
+static AttnSplitPlan attn_split_plan(int B, int H, int Tq, int Tk) {
+    AttnSplitPlan p;
+    const long wgs = (long)((Tq + W48_Q - 1) / W48_Q) * H * B;
+    if (wgs > 128 || Tk < 4 * KV_TILE) return p;
+    int z = (int)(256 / wgs);
+    if (z > 8) z = 8;
+    if (z > Tk / (2 * KV_TILE)) z = Tk / (2 * KV_TILE);
+    if (z < 2) return p;
+    const int keys = ((Tk + z - 1) / z + KV_TILE - 1) / KV_TILE * KV_TILE;
+    z = (Tk + keys - 1) / keys;  // no empty range
+    if (z < 2) return p;
+    p.splits = z;
+    p.keys = keys;
+    p.o_bytes = ((long)z * B * Tq * H * 128 * 2 + 255) / 256 * 256;
+    p.bytes = p.o_bytes + (long)z * B * H * ((Tq + W48_Q - 1) / W48_Q * W48_Q) * 4;
+    return p;
+}
+long attn_split_ws_bytes(int B, int H, int Tq, int Tk) { return attn_split_plan(B, H, Tq, Tk).splits > 1 ? attn_split_plan(B, H, Tq, Tk).bytes : 0; }
+int attn_key_splits(int B, int H, int Tq, int Tk) { return attn_split_plan(B, H, Tq, Tk).splits; }
+
 void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
     AttnArgs a = a_in;
     // q_prescaled: every kernel but the prescaled assembly stream computes exp2(score * scale * log2(e)); with Q carrying
@@ -936,16 +1009,34 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS + 16384));
             });
-            const dim3 grid4(((a.Tq + W48_Q - 1) / W48_Q) * a.H * a.B);
+            // few queries against many keys: divide the keys over workgroups (attn_split_plan) when the caller lent a workspace
+            AttnArgs k = a;
+            k.key_splits = 1;
+            const AttnSplitPlan plan = attn_split_plan(a.B, a.H, a.Tq, a.Tk);
+            static const bool no_split = getenv("LTX_ATTN_NO_SPLIT") != nullptr;  // A/B hook
+            if (plan.splits > 1 && a.split_ws && a.split_ws_bytes >= plan.bytes && !no_split && ((uintptr_t)a.split_ws & 15) == 0 &&
+                ((uintptr_t)a.O & 15) == 0 && a.ldo % 8 == 0 && a.o_bstride % 8 == 0) {
+                k.key_splits = plan.splits;
+                k.split_keys = plan.keys;
+                k.o_part = (bf16_t*)a.split_ws;
+                k.lse = (float*)((char*)a.split_ws + plan.o_bytes);
+            }
+            const dim3 grid4(((a.Tq + W48_Q - 1) / W48_Q) * a.H * a.B, k.key_splits);
             if (a.bias && a.q_prescaled)
-                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<true, true>), grid4, dim3(256), W48_LDS + 16384, stream, a);
+                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<true, true>), grid4, dim3(256), W48_LDS + 16384, stream, k);
             else if (a.bias)
-                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<true, false>), grid4, dim3(256), W48_LDS + 16384, stream, a);
+                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<true, false>), grid4, dim3(256), W48_LDS + 16384, stream, k);
             else if (a.q_prescaled)
-                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<false, true>), grid4, dim3(256), W48_LDS, stream, a);
+                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<false, true>), grid4, dim3(256), W48_LDS, stream, k);
             else
-                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<false, false>), grid4, dim3(256), W48_LDS, stream, a);
+                hipLaunchKernelGGL((attn_fwd_kernel_w48_asm<false, false>), grid4, dim3(256), W48_LDS, stream, k);
             HIP_CHECK(hipGetLastError());
+            if (k.key_splits > 1) {
+                const long total = (long)a.B * a.Tq * a.H * 16;
+                hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, k.o_part, k.lse, k.key_splits, a.B, a.H,
+                                   a.Tq, (a.Tq + W48_Q - 1) / W48_Q * W48_Q, a.O, a.ldo, a.o_bstride);
+                HIP_CHECK(hipGetLastError());
+            }
             return;
         }
         if (use_pp) {

@@ -367,6 +367,12 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     const int S = a.S, Spad = cc->Spad;
 
     const SplitWs sk{m->ws_splitk.as<float>(), (long)(m->ws_splitk.bytes / 4)};
+    // few tokens: the attention launcher may divide the keys of a launch over workgroups (attention.h, key split) - lend it the room
+    {
+        const long need_x = attn_split_ws_bytes(B, m->cfg.num_heads, T, S), need_s = attn_split_ws_bytes(B, m->cfg.num_heads, T, T);
+        const long need = need_x > need_s ? need_x : need_s;
+        if (need > 0) m->ws_attn_split.ensure((size_t)need);
+    }
     float* x = m->ws_x.as<float>();
     bf16_t* xn = m->ws_xn.as<bf16_t>();
     bf16_t* xb = m->ws_xb.as<bf16_t>();
@@ -466,6 +472,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             at.O = ao; at.ldo = D; at.o_bstride = (long)T * D;
             at.B = B; at.H = m->cfg.num_heads; at.Tq = T;
             at.q_prescaled = 1;
+            at.split_ws = m->ws_attn_split.p; at.split_ws_bytes = (long)m->ws_attn_split.bytes;
             launch_attention(at, st);
             GemmEpilogue eo;
             eo.out_f32 = x;
@@ -497,6 +504,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             at.bias_bstride = S;
             at.B = B; at.H = m->cfg.num_heads; at.Tq = T; at.Tk = S;
             at.q_prescaled = 1;
+            at.split_ws = m->ws_attn_split.p; at.split_ws_bytes = (long)m->ws_attn_split.bytes;
             launch_attention(at, st);
             GemmEpilogue eo;
             eo.out_f32 = x;

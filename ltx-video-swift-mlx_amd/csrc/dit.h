@@ -96,7 +96,7 @@ struct DiTModel {
     // ---- activation workspace (grown on demand, never freed inside a step) ----
     DevBuf ws_x, ws_xn, ws_xb, ws_qk, ws_q, ws_k, ws_vt, ws_ao, ws_ffh, ws_qc;
     DevBuf ws_sp_k, ws_sp_vt, ws_sp_vtg;  // sequence-parallel: gathered K [T][D], V^T [D][Tpad], V^T gather staging
-    DevBuf ws_ts, ws_emb256, ws_h1, ws_embts, ws_ada, ws_mod, ws_modout, ws_splitk;
+    DevBuf ws_ts, ws_emb256, ws_h1, ws_embts, ws_ada, ws_mod, ws_modout, ws_splitk, ws_attn_split;
     int ws_rows = 0, ws_B = 0, ws_Tpad = 0;
 };
 

@@ -100,6 +100,9 @@ struct GemmArgs {
     const uint8_t* Bq = nullptr;
     const bf16_t* Bqs = nullptr;
     const bf16_t* Bqb = nullptr;
+    // B's LDS-DMA loads with the non-temporal policy (once-read weights of a few-row launch: they should not displace the activations
+    // every column tile re-reads from the L2). Set by launch_gemm_bf16 for its few-row path; 128x64 ring instance only.
+    int b_nt = 0;
 };
 
 // tile_cfg 90 (experiments build only): a weight-streaming kernel for M <= 128 that loads MFMA fragments straight from global memory

@@ -906,11 +906,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         if constexpr (QB) {
             stage_q(kt + 1);  // the codes run one tile ahead of the activations: they are converted during K-tile kt
         } else {
+            if (BM == 128 && BN == 64 && !CONV && g.b_nt) {  // uniform branch; the policy is an immediate of the instruction
 #pragma unroll
-            for (int i = 0; i < B_PER_WAVE; ++i) {
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(b_src[i] + (long)kt * BK),
-                    (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
+                for (int i = 0; i < B_PER_WAVE; ++i) {
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(b_src[i] + (long)kt * BK),
+                        (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * i) * 1024), 16, 0, 2);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_PER_WAVE; ++i) {
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(b_src[i] + (long)kt * BK),
+                        (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
+                }
             }
         }
     };
@@ -1976,10 +1985,24 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 22: { GemmArgs b = a; b.group_m = 0; launch_v2<192, 128, 4, false, 4, 2>(b, stream); break; }  // A/B: column-major order
             case 23: launch_v2<256, 128, 3, false, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, false, 2, 4>(a, stream); break;
-            case 29:  // few rows: narrow column tiles, 4 waves, one workgroup per CU; 8-bit codes de-quantised in the B stage
-                if (a.Bq) launch_v2<128, 64, 4, false, 2, 2, true>(a, stream); else launch_v2<128, 64, 4, false, 2, 2>(a, stream);
+            case 29:  // few rows: narrow column tiles, 4 waves, one workgroup per CU; 8-bit codes de-quantised in the B stage.
+                      // bf16 weights: SIX ring slots (144 KB) - five K-tiles of weights in flight per CU instead of three: the
+                      // weight stream of a 128-token launch goes from 3.45 to 3.65 TB/s (same-box A/B, tools/fewrow_stride.py)
+                if (a.Bq) {
+                    launch_v2<128, 64, 4, false, 2, 2, true>(a, stream);
+                } else {
+                    static const int nt_env = getenv("LTX_B_NT") ? atoi(getenv("LTX_B_NT")) : -1;  // A/B hook: 0 / 1 overrides the launcher
+                    if (nt_env >= 0 && a.b_nt != nt_env) {
+                        GemmArgs b = a;
+                        b.b_nt = nt_env;
+                        launch_v2<128, 64, 6, false, 2, 2>(b, stream);
+                    } else {
+                        launch_v2<128, 64, 6, false, 2, 2>(a, stream);
+                    }
+                }
                 break;
 #ifdef LTX_EXPERIMENTS
+            case 28: launch_v2<128, 64, 4, false, 2, 2>(a, stream); break;  // cfg 29 with the 4-slot ring it had until round 3 (A/B)
             case 30:  // few rows (M <= 128), operand rings of their own, weights in macro-tiles: measured, not selected
                 if (a.Bq) launch_fewrow<true>(a, stream); else launch_fewrow<false>(a, stream);
                 break;
@@ -2113,6 +2136,7 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
             b.split_k = sk < 1 ? 1 : (int)sk;
             while (b.split_k > 1 && (long)b.split_k * a.M * a.N > a.split_ws_elems) --b.split_k;
             if (cfg == 30 && !gemm_fewrow_takes(a.M, a.N, a.K, b.split_k)) cfg = 29;
+            b.b_nt = 1;  // once-read weights, non-temporal: 11.64-11.70 -> 11.55-11.59 ms per 128-token forward (same box, interleaved)
         }
         if (cfg == 25) {
             const long tiles = (long)((a.N + 191) / 192);

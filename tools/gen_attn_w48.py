@@ -650,6 +650,26 @@ class Gen:
         e(f"v_mul_lo_u32 v{ESO}, v{G}, %[o1]")
         e(f"v_lshl_add_u32 v{ESO}, v{C16}, 4, v{ESO}")
         e(f"v_add_u32 v{ESO}, %[eso], v{ESO}")
+        # key-split launches (%[lse] != 0: few queries, the keys divided over several workgroups): besides its normalised O, which then
+        # goes to the split's slice of a partial buffer, the wave stores log2 of each query's denominator in absolute units,
+        # log2(l) + m_ref (* c when the scores are not base-2 exponents yet): the weights of attn_combine_kernel. The four lanes that
+        # share a query store the same value to the same address.
+        e("s_cmp_eq_u64 %[lse], 0")
+        e("s_cbranch_scc1 31f")
+        e(f"v_lshlrev_b32 v{RT + 1}, 2, v{C16}")
+        for qb in range(3):
+            d = RT + 2 + qb          # a data register per store: nothing rewrites it while the store is in flight
+            e(f"v_accvgpr_read_b32 v{d}, a{LACC + 4 * qb}")
+            e("s_nop 1")
+            e(f"v_log_f32 v{d}, v{d}")
+            if PS:
+                e("s_nop 1")
+                e(f"v_sub_f32 v{d}, v{d}, v{NMCT[qb]}")
+            else:
+                e(f"v_mul_f32 v{RT + 6}, %[c], v{NMCT[qb]}")
+                e(f"v_sub_f32 v{d}, v{d}, v{RT + 6}")
+            e(f"global_store_dword v{RT + 1}, v{d}, %[lse] offset:{qb * 64}")
+        e("31:")
         WA = SA                      # v[48:55]: write address per db
         for db in range(8):
             e(f"v_xor_b32 v{WA + db}, {db << 5}, v{ESX}")
