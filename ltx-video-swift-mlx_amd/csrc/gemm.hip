@@ -1103,9 +1103,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
 // MEASURED, NOT SELECTED (tile_cfg 30, experiments build): bit-exact (tests/test_experiments_gpu.py), and 9 % SLOWER than the 128x64
 // ring kernel at 128 tokens - 22.9 / 25.9 / 45.0 us against 20.95 / 23.3 / 41.1 us for the N = 4096 / 8192 / 16384 launches of a block
 // (rocprofv3, profiles/r03_config1_fewrow.txt); forward 12.7 against 11.9 ms. Both kernels stream the weights at ~3 TB/s whatever the
-// bytes in flight (72 KB or 136 KB per CU) and whatever the run length per DRAM row (128 B or 512 B): what a CU takes in per K-tile
-// is 16 KB of ACTIVATIONS (from L2) beside 8 KB of weights, 37 GB/s per CU through LDS-DMA in all - the operand that is re-fetched
-// by every column tile, not HBM, bounds a 128-row GEMM with 64-column tiles.
+// run length per DRAM row (128 B or 512 B). The activation tile's re-fetch (16 KB per K-tile from L2 beside 8 KB of weights) was this
+// kernel's premise and is NOT the bound: 16-row launches of the ring kernel are only 7 % faster than 128-row ones
+// (profiles/r03_fewrow_bounds.txt); a six-slot ring there gained 5 % and is what the product now runs.
 // ---------------------------------------------------------------------------------------------------------------
 template <int N>
 LTX_DEVFN void wait_vmcnt_only() {
