@@ -2136,7 +2136,9 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
             b.split_k = sk < 1 ? 1 : (int)sk;
             while (b.split_k > 1 && (long)b.split_k * a.M * a.N > a.split_ws_elems) --b.split_k;
             if (cfg == 30 && !gemm_fewrow_takes(a.M, a.N, a.K, b.split_k)) cfg = 29;
-            b.b_nt = 1;  // once-read weights, non-temporal: 11.64-11.70 -> 11.55-11.59 ms per 128-token forward (same box, interleaved)
+            // once-read weights, non-temporal - from 64 MB up: the q|k, FFN-up and FFN-down launches gain 3-6 %, the 33.5 MB ones
+            // (N = K = 4096, four splits) LOSE 12 % with it (profiles/r03_fewrow_bounds.txt)
+            b.b_nt = (long)a.N * a.K >= (32L << 20) ? 1 : 0;
         }
         if (cfg == 25) {
             const long tiles = (long)((a.N + 191) / 192);
