@@ -107,10 +107,3 @@ def test_key_ranges_with_maxima_far_apart(ctx):
         assert np.isfinite(got).all()
         assert np.abs(got - ref).max() <= 3e-2, np.abs(got - ref).max()
         assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-2
-
-
-def test_split_plan_leaves_filled_launches_alone():
-    assert ltx.Context.attention_key_splits(1, 32, 1536, 1024) == 1   # config 2: 256 workgroups already
-    assert ltx.Context.attention_key_splits(1, 32, 128, 128) == 1     # config 1 self-attention: two key tiles
-    assert ltx.Context.attention_key_splits(1, 32, 128, 1024) == 8    # config 1 cross-attention
-    assert ltx.Context.attention_key_splits(2, 32, 128, 1024) == 4

@@ -407,3 +407,25 @@ def test_mlx_random_normal_matches_the_restatement(ltx, oracle):
     assert abs(float(x.mean())) < 0.01 and abs(float(x.std()) - 1.0) < 0.01 and np.isfinite(x).all()
     assert not np.array_equal(x, ltx.mlx_random_normal(43, (1, 128, 4, 16, 24)))
     assert not np.array_equal(x, ltx.mlx_random_normal(42, (1, 128, 4, 16, 24), 1))  # second draw after the same seed
+
+
+def test_attention_key_split_plan(ltx):
+    """Host logic of the attention launcher's key split (attention.h): only launches that leave most CUs idle AND have at least four
+    key tiles are divided, into at most 8 non-empty ranges of whole 64-key tiles. No reference counterpart (one SDPA call,
+    LTXAttention.swift:209); the plan decides which kernel arrangement computes it."""
+    ks = ltx.Context.attention_key_splits
+    assert ks(1, 32, 1536, 1024) == 1   # config 2: 256 workgroups already
+    assert ks(1, 32, 128, 128) == 1     # config 1 self-attention: two key tiles
+    assert ks(1, 32, 128, 1024) == 8    # config 1 cross-attention: 32 workgroups x 16 tiles -> 256 x 2
+    assert ks(2, 32, 128, 1024) == 4    # CFG pair: 64 workgroups
+    assert ks(1, 32, 384, 1024) == 4    # 64 workgroups
+    assert ks(1, 32, 768, 1024) == 2    # 128 workgroups
+    assert ks(1, 32, 960, 1024) == 1    # 160 workgroups: left alone
+    assert ks(1, 1, 35, 257) == 2       # ragged: 192 + 65 keys
+    assert ks(0, 1, 1, 1) == 1 and ks(1, 1, 1, 1 << 20) == 8
+    for B, H, Tq, Tk in [(1, 2, 100, 1000), (1, 3, 1, 4097), (2, 5, 191, 333), (1, 32, 128, 1000)]:
+        z = ks(B, H, Tq, Tk)
+        assert 1 <= z <= 8
+        if z > 1:
+            keys = -(-(-(-Tk // z)) // 64) * 64   # what the launcher gives a range
+            assert (z - 1) * keys < Tk <= z * keys, (B, H, Tq, Tk, z, keys)
