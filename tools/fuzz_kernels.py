@@ -55,6 +55,9 @@ def run(ctx, cases, seed, verbose=True):
         Tq, Tk = int(rng.integers(1, 900)), int(rng.integers(1, 1300))
         D = H * 128
         q, k, v = (bf16(rng.standard_normal((Bn, t, D))) for t in (Tq, Tk, Tk))
+        prescaled = bool(rng.integers(0, 2))  # Q carrying (1 / sqrt(128)) * log2(e), as the DiT's q-norm pass writes it
+        if prescaled:
+            q = (q.float() * (1.4426950408889634 / math.sqrt(128.0))).to(torch.bfloat16)
         biasv = None
         if rng.integers(0, 2):
             m = (rng.random((Bn, Tk)) > 0.3).astype(np.float32)
@@ -65,10 +68,10 @@ def run(ctx, cases, seed, verbose=True):
         vt[:, :, :Tk] = v.transpose(1, 2)
         o = torch.empty((Bn, Tq, D), device="cuda", dtype=torch.bfloat16)
         scale = 1.0 / math.sqrt(128.0)
-        ctx.op_attention(q, k, vt, biasv, H, o, scale)
+        ctx.op_attention(q, k, vt, biasv, H, o, -1.0 if prescaled else scale)
         torch.cuda.synchronize()
         qh, kh, vh = (t.float().cpu().reshape(Bn, -1, H, 128).permute(0, 2, 1, 3) for t in (q, k, v))
-        s = qh @ kh.transpose(-1, -2) * scale
+        s = qh @ kh.transpose(-1, -2) * (math.log(2.0) if prescaled else scale)
         if biasv is not None:
             s = s + biasv.cpu()[:, None, None, :]
         ref = (torch.softmax(s, dim=-1) @ vh).permute(0, 2, 1, 3).reshape(Bn, Tq, D).numpy()
@@ -79,7 +82,7 @@ def run(ctx, cases, seed, verbose=True):
         if not ok:
             bad += 1
         if verbose:
-            print(f"attention B={Bn} H={H} Tq={Tq:4d} Tk={Tk:4d} mask={biasv is not None}: max err {err:.2e} rel {rel:.2e} {'ok' if ok else 'FAIL'}", flush=True)
+            print(f"attention B={Bn} H={H} Tq={Tq:4d} Tk={Tk:4d} mask={biasv is not None} prescaled={prescaled} key ranges={ctx.attention_key_splits(Bn, H, Tq, Tk)}: max err {err:.2e} rel {rel:.2e} {'ok' if ok else 'FAIL'}", flush=True)
     return bad
 
 
