@@ -3,6 +3,8 @@
 // wave shuffles + one LDS hop. Roofline for each is HBM bytes / 8 TB/s; none of them is reshaped into a GEMM.
 #include "elementwise.h"
 
+#include <stdlib.h>
+
 #include "runtime.h"
 
 namespace {
@@ -599,10 +601,17 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
     LTX_REQUIRE((scale == nullptr) == (shift == nullptr), "norm_mod: scale/shift must both be set or both null");
     const int rpb = rows_per_batch < 1 ? 1 : rows_per_batch;
     ProfScope prof(PROF_ELEM, (double)rows * D * (4 + 2), stream);  // algorithmic bytes: f32 row in, bf16 row out
-    constexpr int R = 4;
-    if (norm_kind == LTX_NORM_RMS && scale && !row_map && D == 4096 && rows >= 512 && rpb % R == 0) {
-        hipLaunchKernelGGL((norm_mod_rows_kernel<4, R>), dim3((rows + R - 1) / R), dim3(256), 0, stream, x, ldx, scale, shift, mod_bstride, rpb, out, ldo,
-                           rows, eps, round_norm_bf16);
+    // rows per workgroup: 4 share one fetch of the modulation vectors; at 1536 rows that is 384 workgroups = 1.5 per CU, and two rows per
+    // workgroup (768 = 3 per CU) are 10 % faster (9.15 vs 10.2 us alone, 36.39 vs 36.53 ms per forward); no difference from 6144 rows up
+    static const int r_env = getenv("LTX_NORM_ROWS") ? atoi(getenv("LTX_NORM_ROWS")) : 0;  // A/B hook: 2 or 4
+    const int R_rows = r_env ? r_env : (rows <= 3072 ? 2 : 4);
+    if (norm_kind == LTX_NORM_RMS && scale && !row_map && D == 4096 && rows >= 512 && rpb % R_rows == 0) {
+#define LTX_ROWS_LAUNCH(R)                                                                                                                      \
+    hipLaunchKernelGGL((norm_mod_rows_kernel<4, R>), dim3((rows + R - 1) / R), dim3(256), 0, stream, x, ldx, scale, shift, mod_bstride, rpb, out, ldo, \
+                       rows, eps, round_norm_bf16)
+        if (R_rows == 2) LTX_ROWS_LAUNCH(2);
+        else LTX_ROWS_LAUNCH(4);
+#undef LTX_ROWS_LAUNCH
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -817,7 +826,7 @@ void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const f
     const int t = T < 1 ? 1 : T;
     static const bool no_pair = getenv("LTX_QKNORM_NO_PAIR") != nullptr;  // A/B hook
     if (D == 4096 && rows >= 512 && x1 && cosT && !no_pair) {  // q and k of the same tokens: one fetch of the tables (2.64 -> 2.54 ms of row passes per step)
-        constexpr int R = 2;
+        constexpr int R = 2;  // 1 and 3 rows per workgroup: within the run-to-run noise of the forward (round 3)
         hipLaunchKernelGGL(qknorm_rope_pair_kernel<R>, dim3((rows + R - 1) / R), dim3(256), 0, stream, j0, j1, cosT, sinT, t, rows, eps);
         HIP_CHECK(hipGetLastError());
         return;
