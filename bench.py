@@ -57,7 +57,7 @@ PEAK_BF16_TFLOPS = 2500.0
 SUSTAINED_BF16_TFLOPS = 2000.0
 HBM_PEAK_GBPS = 8000.0
 TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
-VAE_TRAFFIC_FILES = ("r03_pmc_traffic_vae.json", "r02_pmc_traffic_vae.json")
+VAE_TRAFFIC_FILES = ("r03_pmc_traffic_vae_v2.json", "r03_pmc_traffic_vae.json", "r02_pmc_traffic_vae.json")
 
 
 def pmc_traffic(files=None):
@@ -709,7 +709,7 @@ def bench_vae(ctx, ltx, torch, dev, F, H, W, iters=3):
         vtraffic, vsrc = pmc_traffic(VAE_TRAFFIC_FILES)  # fabric-side bytes per conv launch, two --pmc passes of tools/bench_vae.py
         res["conv_kernel_tflops"] = round(ach, 1)
         res["conv_ms"] = round(c["ms"] / iters, 3)
-        res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel_v2<conv>", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+        res["roofline"] = {"bound": "mfma", "kernel": "conv3d_halo_kernel + gemm_bf16_kernel_v2<conv>", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": vtraffic, "traffic_source": vsrc,
                            "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / max(1, c["launches"]), 2),
                            "whole_decode_frac": round(12.96 / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4),

@@ -1085,6 +1085,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
 }
 
 
+#include "conv_halo.inc"
+
 #ifdef LTX_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------
 // Few-row launches (M <= 128: the DiT at 256x256x9 = 128 tokens), round 3. Such a GEMM streams its weights once and is bound by
@@ -1949,6 +1951,26 @@ static void launch_stream(const GemmArgs& a_in, hipStream_t stream) {
 
 #endif
 
+// conv_halo.inc: which conv launches the halo-staged kernel takes (everything else stays on the ring kernel)
+static bool conv_halo_takes(const GemmArgs& a) {
+    static const bool off = getenv("LTX_CONV_HALO") && atoi(getenv("LTX_CONV_HALO")) == 0;  // A/B hook
+    const Conv3dGeom& q = a.geom;
+    if (off || !a.conv || q.kt != 3 || !(q.pad_mode == 0 || q.pad_mode == 2) || q.C % 64 != 0 || a.split_k > 1 || a.tile0 != 0 || a.win_rows != 0) return false;
+    if (a.K != 27 * q.C || a.M != q.F * q.H * q.W || a.M < 192 || a.ldb % 8 != 0) return false;
+    const bool w_ok = (q.W <= 192 && q.W >= 48 && 192 % q.W == 0) || (q.W % 192 == 0);
+    return w_ok && !a.ep.out_bf16_t;
+}
+static void launch_conv_halo(const GemmArgs& a, hipStream_t stream) {
+    constexpr int smem = 2 * 32 * 1024 + 6 * 128 * ROW_BYTES;
+    static PerDeviceOnce attr_set;
+    attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)conv3d_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
+    const int all_tiles = ((a.M + 191) / 192) * ((a.N + 127) / 128);
+    const int tiles = a.tile_count ? a.tile_count : all_tiles;
+    LTX_REQUIRE(tiles <= all_tiles, "conv halo: tile window of %d tiles outside %d", tiles, all_tiles);
+    hipLaunchKernelGGL(conv3d_halo_kernel<0>, dim3(tiles), dim3(512), smem, stream, a);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     if (a.ep.out_bf16_t) {
         const GemmEpilogue& e = a.ep;
@@ -1963,7 +1985,9 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     // cfg 0..2: v1 (2-stage, one barrier + full drain per K-tile); cfg 10..: v2 (ring + counted vmcnt)
     if (a.conv) {
         switch (cfg) {
-            case 21: launch_v2<192, 128, 4, true, 4, 2>(a, stream); break;   // 8 waves (4x2), per-wave 48x64, 4-slot ring
+            case 21:  // 8 waves (4x2), per-wave 48x64: the halo-staged kernel where it applies, else the 4-slot ring
+                if (conv_halo_takes(a)) launch_conv_halo(a, stream); else launch_v2<192, 128, 4, true, 4, 2>(a, stream);
+                break;
 #ifdef LTX_EXPERIMENTS  // measured, not selected for convs (VAE decode 19.4 ms with the 256x128 ring, 22.8 with the two-stage kernel, against 17.0)
             case 0: launch_one<128, 128, true>(a, stream); break;
             case 1: launch_one<192, 128, true>(a, stream); break;

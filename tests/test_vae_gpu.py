@@ -80,6 +80,32 @@ def test_conv3d_random_shapes_integer_exact(gpu_ctx):
         assert torch.equal(out, ref), (F, H, W, Cin, Cout, float((out - ref).abs().max()))
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("F,H,W,Cin,Cout", [(3, 7, 48, 64, 128), (2, 5, 64, 128, 96), (3, 6, 96, 192, 128), (2, 3, 192, 64, 256),
+                                            (1, 4, 384, 128, 128), (5, 4, 48, 64, 128), (1, 1, 192, 64, 128), (2, 2, 576, 64, 80)])
+def test_conv3d_halo_staged_geometries_integer_exact(gpu_ctx, F, H, W, Cin, Cout, causal):
+    """The geometries the halo-staged conv kernel takes (csrc/conv_halo.inc: an image row is a whole number of 192-position tiles or a
+    tile a whole number of image rows, W >= 48): segments of 48 / 64 / 96 positions, whole and half rows of 192 / 384 / 576, a last tile
+    that ends before its 192 rows (7 x 48, 5 x 64 positions per frame), fewer than 128 output channels, one- and two-half channel
+    counts, causal and replicated time padding - against torch's conv3d on integer data (exact whatever the order of the sums).
+    VideoConvolution.swift:202-348 is the reference's conv (three conv2d summed)."""
+    import torch.nn.functional as F_
+
+    rng = np.random.default_rng(F * 1000 + H * 100 + W + Cin + Cout + causal)
+    x = torch.from_numpy(rng.integers(-2, 3, (1, Cin, F, H, W)).astype(np.float32)).cuda()
+    w = torch.from_numpy(rng.integers(-2, 3, (Cout, Cin, 3, 3, 3)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rng.integers(-4, 5, (Cout,)).astype(np.float32)).cuda()
+    xp = F_.pad(x, (1, 1, 1, 1, 0, 0), mode="reflect")
+    xp = torch.cat([xp[:, :, :1], xp[:, :, :1], xp], 2) if causal else torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], 2)
+    ref = F_.conv3d(xp.double(), w.double(), b.double())[0].permute(1, 2, 3, 0).float()
+    xd = x[0].permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)
+    wd = torch.from_numpy(relayout(w.cpu().numpy())).to(torch.bfloat16).cuda()
+    out = torch.full((F, H, W, Cout), float("nan"), device="cuda")
+    gpu_ctx.op_conv3d(xd, wd, b, out, causal=causal)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+
+
 @pytest.fixture(scope="module")
 def vae_model(ltx, oracle, gpu_ctx, tmp_path_factory):
     from safetensors.torch import save_file

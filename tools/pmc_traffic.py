@@ -59,7 +59,7 @@ def main():
         fb = 2.0 * 1024.0 * (sum(f) / len(f)) if f else 0.0
         wb = 1024.0 * (sum(w) / len(w)) if w else 0.0
         out["kernels"][k] = {"launches": max(len(f), len(w)), "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
-        if k.startswith("gemm_bf16_kernel"):
+        if k.startswith("gemm_bf16_kernel") or k.startswith("conv3d_halo_kernel"):
             tot_f += 2.0 * 1024.0 * sum(f)
             tot_w += 1024.0 * sum(w)
             n_gemm += max(len(f), len(w))
