@@ -1961,14 +1961,15 @@ static bool conv_halo_takes(const GemmArgs& a) {
     const bool w_ok = (q.W <= 192 && q.W >= 48 && 192 % q.W == 0) || (q.W % 192 == 0);
     return w_ok && !a.ep.out_bf16_t;
 }
+template <int BN>
 static void launch_conv_halo(const GemmArgs& a, hipStream_t stream) {
-    constexpr int smem = 2 * 32 * 1024 + 6 * 128 * ROW_BYTES;
+    constexpr int smem = 2 * 32 * 1024 + 6 * BN * ROW_BYTES;
     static PerDeviceOnce attr_set;
-    attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)conv3d_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
-    const int all_tiles = ((a.M + 191) / 192) * ((a.N + 127) / 128);
+    attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)conv3d_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
+    const int all_tiles = ((a.M + 191) / 192) * ((a.N + BN - 1) / BN);
     const int tiles = a.tile_count ? a.tile_count : all_tiles;
     LTX_REQUIRE(tiles <= all_tiles, "conv halo: tile window of %d tiles outside %d", tiles, all_tiles);
-    hipLaunchKernelGGL(conv3d_halo_kernel, dim3(tiles), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL(conv3d_halo_kernel<BN>, dim3(tiles), dim3(512), smem, stream, a);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1987,7 +1988,7 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     if (a.conv) {
         switch (cfg) {
             case 21:  // 8 waves (4x2), per-wave 48x64: the halo-staged kernel where it applies, else the 4-slot ring
-                if (conv_halo_takes(a)) launch_conv_halo(a, stream); else launch_v2<192, 128, 4, true, 4, 2>(a, stream);
+                if (conv_halo_takes(a)) launch_conv_halo<128>(a, stream); else launch_v2<192, 128, 4, true, 4, 2>(a, stream);
                 break;
 #ifdef LTX_EXPERIMENTS  // measured, not selected for convs (VAE decode 19.4 ms with the 256x128 ring, 22.8 with the two-stage kernel, against 17.0)
             case 0: launch_one<128, 128, true>(a, stream); break;
@@ -1997,7 +1998,9 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
             case 23: launch_v2<256, 128, 3, true, 4, 2>(a, stream); break;  // 8 waves, per-wave 64x64
             case 25: launch_v2<128, 192, 4, true, 2, 4>(a, stream); break;
 #endif
-            case 27: launch_v2<256, 64, 4, true, 4, 2>(a, stream); break;   // narrow outputs (the VAE's 128 -> 48 conv_out): per-wave 64x32
+            case 27:  // narrow outputs (the VAE's 128 -> 48 conv_out): the halo-staged kernel's 192x64 instance, else the 256x64 ring (per-wave 64x32)
+                if (a.N <= 64 && conv_halo_takes(a)) launch_conv_halo<64>(a, stream); else launch_v2<256, 64, 4, true, 4, 2>(a, stream);
+                break;
             default: LTX_THROW(LTXS_INVALID_CONFIGURATION, "gemm: unknown tile cfg %d", cfg);
         }
     } else {

@@ -1,0 +1,121 @@
+"""The halo-staged conv kernel (csrc/conv_halo.inc) orders its LDS-DMA loads against its fragment reads with counted `s_waitcnt vmcnt(N)`
+immediates derived by hand in the file's header. This test replays the kernel's issue order - prologue, first triple, steady triples,
+tail - for both instances (2 or 1 weight pieces per wave and K-tile) and several channel counts, and checks on the model what the
+assembly generators' checkers prove on their streams: at every mid-tile wait the loads the NEXT K-tile reads (its weight tile; its slab if
+it opens a triple) are older than the N youngest loads in flight, no slab / weight slot is overwritten while a K-tile that reads it is
+still ahead of the barrier that precedes the overwrite, and every load issued is waited for before the epilogue. The immediates and ring
+sizes are read from the source, so an edit there that breaks the schedule fails here without a GPU.
+(VideoConvolution.swift:202-348 is the conv being computed; the schedule itself has no reference counterpart.)"""
+import os
+import re
+
+import pytest
+
+SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ltx-video-swift-mlx_amd", "csrc", "conv_halo.inc")
+
+
+def _constants():
+    text = open(SRC).read()
+    m = re.search(r"NS = (\d+), NB = (\d+)", text)
+    ns, nb = int(m.group(1)), int(m.group(2))
+    m = re.search(r"wait_vmcnt_barrier<\(DX == 2 \|\| FIRST\) \? (\d+) \* BPW : (\d+) \* BPW \+ (\d+)>", text)
+    assert m, "steady wait expression changed: update this model"
+    tight_b, loose_b, loose_c = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    assert re.search(r"wait_vmcnt_barrier<BPW \* \(PDB - 1\)>", text), "prologue wait changed: update this model"
+    assert "if constexpr (DX == 2) stage_slab(sbuf);" in text and "stage_slab(0);\n    stage_slab(1);" in text
+    return ns, nb, tight_b, loose_b, loose_c
+
+
+@pytest.mark.parametrize("bpw", [2, 1])
+@pytest.mark.parametrize("cpt", [1, 2, 4, 8])
+def test_counted_waits_cover_every_fragment_read(bpw, cpt):
+    ns, nb, tight_b, loose_b, loose_c = _constants()
+    assert ns == 2
+    pdb = nb - 1
+    nq, nk = 9 * cpt, 27 * cpt
+    issued = []            # loads in issue order: ("slab", triple) x 4 or ("w", tile) x bpw
+    slab_of_buf = {}       # buffer -> triple whose slab was staged there last
+    tile_of_slot = {}      # weight ring slot -> K-tile staged there last
+
+    def stage_slab(q, buf):
+        issued.extend([("slab", q)] * 4)
+        slab_of_buf[buf] = q
+
+    def stage_w(t):
+        issued.extend([("w", t)] * bpw)
+        tile_of_slot[t % nb] = t
+
+    def landed_after_wait(n):
+        return set(issued[:len(issued) - n]) if n else set(issued)
+
+    # prologue
+    stage_slab(0, 0)
+    stage_slab(1, 1)
+    for t in range(pdb):
+        stage_w(t)
+    ok = landed_after_wait(bpw * (pdb - 1))
+    assert ("slab", 0) in ok and ("w", 0) in ok
+    next_slab = 2
+    drained = False
+    for t in range(nk):
+        q, dx = divmod(t, 3)
+        steady = t < nk - pdb
+        first = q == 0
+        # first half reads K-tile t's second fragments: its slab and weights must be the ones in LDS
+        assert slab_of_buf[q % ns] == q, (t, slab_of_buf)
+        assert tile_of_slot[t % nb] == t, (t, tile_of_slot)
+        # mid-tile wait + barrier
+        if steady:
+            n = tight_b * bpw if (dx == 2 or first) else loose_b * bpw + loose_c
+            ok = landed_after_wait(n)
+        elif not drained:
+            ok = landed_after_wait(0)
+            drained = True
+        if t + 1 < nk:
+            assert ("w", t + 1) in ok, (t, "weights of the next K-tile may still be in flight")
+            if dx == 2:
+                assert ("slab", q + 1) in ok, (t, "the next triple's slab may still be in flight")
+        # second half: staging behind the barrier, then the first fragments of K-tile t + 1
+        if steady:
+            if dx == 2:
+                # the buffer being overwritten belongs to triple q, whose last fragment read was in this iteration's first half
+                assert slab_of_buf[q % ns] == q
+                stage_slab(next_slab, q % ns)
+                next_slab += 1
+            # the slot being overwritten held K-tile t - 1 (read in the previous iteration, a barrier ago)
+            slot = (t + pdb) % nb
+            assert tile_of_slot.get(slot, -1) in (-1, t - 1) or t == 0, (t, slot, tile_of_slot)
+            stage_w(t + pdb)
+        if t + 1 < nk:
+            q1 = (t + 1) // 3
+            assert slab_of_buf[q1 % ns] == q1 and tile_of_slot[(t + 1) % nb] == t + 1
+    assert next_slab == nq, "every triple's slab is staged exactly once"
+    assert sorted(set(x[1] for x in issued if x[0] == "w")) == list(range(nk)), "every K-tile's weights are staged exactly once"
+    assert drained, "the tail drains the loads in flight before the epilogue reuses LDS"
+
+
+def test_the_model_rejects_a_wait_that_is_too_loose():
+    """The same replay with the steady immediate raised by one piece must fail - the check is not vacuous."""
+    ns, nb, tight_b, loose_b, loose_c = _constants()
+    bpw, cpt = 2, 2
+    pdb = nb - 1
+    nk = 27 * cpt
+    issued = []
+    for _ in range(2):
+        issued.extend([("slab", _)] * 4)
+    for t in range(pdb):
+        issued.extend([("w", t)] * bpw)
+    bad = False
+    next_slab = 2
+    for t in range(nk - pdb):
+        q, dx = divmod(t, 3)
+        n = (tight_b * bpw if (dx == 2 or q == 0) else loose_b * bpw + loose_c) + bpw  # one weight tile too many allowed in flight
+        ok = set(issued[:len(issued) - n])
+        if ("w", t + 1) not in ok:
+            bad = True
+            break
+        if dx == 2:
+            issued.extend([("slab", next_slab)] * 4)
+            next_slab += 1
+        issued.extend([("w", t + pdb)] * bpw)
+    assert bad
