@@ -348,7 +348,8 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     };
     // Self-test hook: LTX_SP_SELFTEST=1 sends a ONE-rank group of the native transport through the sequence-parallel branch (gathers of
     // one part, side stream, events): the only way to execute that code where a single GPU is all there is. Output bits == NW = 1 path.
-    const bool sp = NW > 1 || (B == 1 && !a.sp_gather && dist_can_overlap(ctx) && dist_world(ctx) == 1 && getenv("LTX_SP_SELFTEST") != nullptr);
+    static const bool sp_selftest = getenv("LTX_SP_SELFTEST") != nullptr;  // read once, like the other A/B hooks
+    const bool sp = NW > 1 || (sp_selftest && B == 1 && !a.sp_gather && dist_can_overlap(ctx) && dist_world(ctx) == 1);
     const int T = Tfull / NW;            // rows this rank evaluates
     const int tok0 = a.sp_rank * T;      // first global token of this rank (NW == 1: 0)
     LTX_REQUIRE(B >= 1 && B <= 8 && T >= 1 && a.S >= 1, "dit_forward: bad shapes B=%d T=%d S=%d", B, T, a.S);
@@ -369,7 +370,8 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     const SplitWs sk{m->ws_splitk.as<float>(), (long)(m->ws_splitk.bytes / 4)};
     // few tokens: the attention launcher may divide the keys of a launch over workgroups (attention.h, key split) - lend it the room
     {
-        const long need_x = attn_split_ws_bytes(B, m->cfg.num_heads, T, S), need_s = attn_split_ws_bytes(B, m->cfg.num_heads, T, T);
+        // (a sequence-parallel rank's self-attention sees all Tfull keys)
+        const long need_x = attn_split_ws_bytes(B, m->cfg.num_heads, T, S), need_s = attn_split_ws_bytes(B, m->cfg.num_heads, T, Tfull);
         const long need = need_x > need_s ? need_x : need_s;
         if (need > 0) m->ws_attn_split.ensure((size_t)need);
     }

@@ -603,7 +603,8 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
     ProfScope prof(PROF_ELEM, (double)rows * D * (4 + 2), stream);  // algorithmic bytes: f32 row in, bf16 row out
     // rows per workgroup: 4 share one fetch of the modulation vectors; at 1536 rows that is 384 workgroups = 1.5 per CU, and two rows per
     // workgroup (768 = 3 per CU) are 10 % faster (9.15 vs 10.2 us alone, 36.39 vs 36.53 ms per forward); no difference from 6144 rows up
-    static const int r_env = getenv("LTX_NORM_ROWS") ? atoi(getenv("LTX_NORM_ROWS")) : 0;  // A/B hook: 2 or 4
+    static const int r_raw = getenv("LTX_NORM_ROWS") ? atoi(getenv("LTX_NORM_ROWS")) : 0;  // A/B hook: 2 or 4, anything else is ignored
+    static const int r_env = (r_raw == 2 || r_raw == 4) ? r_raw : 0;
     const int R_rows = r_env ? r_env : (rows <= 3072 ? 2 : 4);
     if (norm_kind == LTX_NORM_RMS && scale && !row_map && D == 4096 && rows >= 512 && rpb % R_rows == 0) {
 #define LTX_ROWS_LAUNCH(R)                                                                                                                      \

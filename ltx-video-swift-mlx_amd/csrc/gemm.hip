@@ -2157,7 +2157,10 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         // the partial slices are a quarter of the weights (128x192 tiles needed 16 splits: as many partial bytes as weight bytes),
         // and the FFN's first GEMM (256 column tiles) needs no split at all. Config 1: 12.04 ms per forward against 12.25 (cfg 25).
         static const int smallm_cfg = getenv("LTX_SMALLM_CFG") ? atoi(getenv("LTX_SMALLM_CFG")) : 29;  // 30 (experiments build): the few-row kernel, 9 % slower
-        int cfg = a.Bq ? (a.M <= 128 ? smallm_cfg : 29) : ((a.M <= 128 && b.split_k > 1) ? smallm_cfg : 21);
+        // codes in the B stage exist only in the 128x64 ring (29) and the experiments build's few-row kernel (30): the hook cannot move a
+        // quantised launch anywhere else
+        const int smallm_q = (smallm_cfg == 29 || smallm_cfg == 30) ? smallm_cfg : 29;
+        int cfg = a.Bq ? (a.M <= 128 ? smallm_q : 29) : ((a.M <= 128 && b.split_k > 1) ? smallm_cfg : 21);
         if (cfg == 29 || cfg == 30) {
             const long tiles = (long)((a.N + 63) / 64);
             long sk = 256 / tiles;

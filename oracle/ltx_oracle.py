@@ -18,10 +18,45 @@ observable here) is f32 activations x bf16-rounded weights, with bf16 storage on
 the caption projection and the cross-attention K/V. `bf16_round` marks those rounding points.
 """
 import math
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
 F32 = np.float32
+
+# Host threads for the position-wise passes of the full-size runs (numpy ufuncs release the GIL; BLAS has its own pool). Values do
+# not depend on it: `_pmap` only ever splits an axis along which `fn` is position-wise.
+_HOST_THREADS = max(1, min(32, int(os.environ.get("LTX_ORACLE_THREADS", os.cpu_count() or 1))))
+_pool = None
+_in_worker = threading.local()  # a slab function that itself calls `_pmap` runs that inner call inline (no nested submission)
+
+
+def _pmap(fn, x, axis, out_dtype=F32):
+    """out = fn(x), computed slab by slab along `axis` on a thread pool. `fn` must map a slab to the same slab of the result
+    (same shape), i.e. be position-wise along `axis`. Small inputs run inline."""
+    global _pool
+    n = x.shape[axis]
+    k = min(_HOST_THREADS, n)
+    if k <= 1 or x.size < (1 << 22) or getattr(_in_worker, "on", False):
+        return np.asarray(fn(x), dtype=out_dtype)
+    if _pool is None:
+        _pool = ThreadPoolExecutor(_HOST_THREADS)
+    out = np.empty(x.shape, out_dtype)
+    cuts = [n * i // k for i in range(k + 1)]
+
+    def run(i):
+        sl = [slice(None)] * x.ndim
+        sl[axis] = slice(cuts[i], cuts[i + 1])
+        _in_worker.on = True
+        try:
+            out[tuple(sl)] = fn(x[tuple(sl)])
+        finally:
+            _in_worker.on = False
+
+    list(_pool.map(run, range(k)))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -195,10 +230,10 @@ def apply_split_rope(x, cos, sin, num_heads):
 # ---------------------------------------------------------------------------------------------------------------
 def linear(x, w, b=None):
     """Linear with weights [out,in] (MLXNN.Linear): f32 accumulate."""
-    y = x.astype(F32) @ w.astype(F32).T
+    y = x.astype(F32, copy=False) @ w.astype(F32, copy=False).T
     if b is not None:
-        y = y + b.astype(F32)
-    return y.astype(F32)
+        y += b.astype(F32, copy=False)
+    return y
 
 
 def rms_norm(x, weight=None, eps=1e-6):
@@ -226,8 +261,8 @@ def gelu_tanh(x):
 
 
 def silu(x):
-    x = x.astype(F32)
-    return (x / (F32(1.0) + np.exp(-x))).astype(F32)
+    x = x.astype(F32, copy=False)
+    return (x / (F32(1.0) + np.exp(-x))).astype(F32, copy=False)
 
 
 def sdpa(q, k, v, num_heads, scale, bias=None):
@@ -491,16 +526,23 @@ def denoise(w, cfg, latent, sigmas_, context, mask, F, H, W, cfg_scale=1.0, resc
 # ---------------------------------------------------------------------------------------------------------------
 # R18-R19: VAE decoder (VideoDecoder.swift, VideoConvolution.swift:202-348). Tensors are [B,C,F,H,W] f32.
 # ---------------------------------------------------------------------------------------------------------------
-def conv3d_full(x, weight, bias, causal=False):
-    """Conv3dFull: reflect pad H/W by 1, replicate pad T (1+1, or 2+0 causal), 27 taps, bias."""
-    b, c, t, h, wd = x.shape
-    o = weight.shape[0]
+def _pad_reflect_hw_replicate_t(x, causal):
+    """Conv3dFull's padding (VideoConvolution.swift:268-305) on a [B,C,T,H,W] tensor: reflect 1 in H and W, then replicate in T
+    (1 + 1, or 2 + 0 when causal)."""
+    h, wd = x.shape[3], x.shape[4]
     xp = np.concatenate([x[:, :, :, 1:2], x, x[:, :, :, h - 2:h - 1]], axis=3)
     xp = np.concatenate([xp[:, :, :, :, 1:2], xp, xp[:, :, :, :, wd - 2:wd - 1]], axis=4)
     if causal:
-        xp = np.concatenate([xp[:, :, :1]] * 2 + [xp], axis=2)
-    else:
-        xp = np.concatenate([xp[:, :, :1], xp, xp[:, :, -1:]], axis=2)
+        return np.concatenate([xp[:, :, :1]] * 2 + [xp], axis=2)
+    return np.concatenate([xp[:, :, :1], xp, xp[:, :, -1:]], axis=2)
+
+
+def conv3d_full_einsum(x, weight, bias, causal=False):
+    """Conv3dFull, first restatement (27 strided patch copies + einsum; ~10 GFLOP/s): kept as the cross-check of `conv3d_full`
+    (tests/test_oracle_vs_torch.py asserts the two agree on the golden fixture)."""
+    b, c, t, h, wd = x.shape
+    o = weight.shape[0]
+    xp = _pad_reflect_hw_replicate_t(x, causal)
     out = np.zeros((b, o, t, h, wd), F32)
     wf = weight.astype(F32)
     for kt in range(3):
@@ -513,10 +555,59 @@ def conv3d_full(x, weight, bias, causal=False):
     return out
 
 
+def conv3d_full(x, weight, bias, causal=False):
+    """Conv3dFull (VideoConvolution.swift:202-348): reflect pad H/W by 1, replicate pad T (1+1, or 2+0 causal), 27 taps, bias,
+    f32 accumulation. BLAS-speed form: on the channels-last PADDED grid flattened to rows [(T+2)(H+2)(W+2)][C] a tap is a constant
+    row offset, so each tap is one zero-copy `rows[off:off+n] @ W_tap` sgemm accumulated in place (beta = 1); rows that fall on
+    padding positions are computed and dropped. Same tap order (kt, kh, kw) as `conv3d_full_einsum`."""
+    from scipy.linalg.blas import sgemm
+    global _pool
+    b, c, t, h, wd = x.shape
+    o = weight.shape[0]
+    hp, wp = h + 2, wd + 2
+    n = (t - 1) * hp * wp + (h - 1) * wp + wd                                    # last output row + 1 on the padded grid
+    wt = np.ascontiguousarray(weight.astype(F32).transpose(2, 3, 4, 1, 0))       # [3,3,3,C,O]
+    out = np.empty((b, o, t, h, wd), F32)
+    if _pool is None:
+        _pool = ThreadPoolExecutor(_HOST_THREADS)
+    for bi in range(b):
+        xp = np.empty((t + 2, hp, wp, c), F32)
+
+        def fill(pf):  # padded frame pf <- source frame (replicate in T), channels last, reflect in H then W
+            src = min(max(pf - (2 if causal else 1), 0), t - 1)
+            xp[pf, 1:h + 1, 1:wd + 1] = x[bi, :, src].transpose(1, 2, 0)
+            xp[pf, 0, 1:wd + 1] = xp[pf, 2, 1:wd + 1]
+            xp[pf, h + 1, 1:wd + 1] = xp[pf, h - 1, 1:wd + 1]
+            xp[pf, :, 0] = xp[pf, :, 2]
+            xp[pf, :, wd + 1] = xp[pf, :, wd - 1]
+
+        list(_pool.map(fill, range(t + 2)))
+        rows = xp.reshape(-1, c)
+        acc = np.empty((t * hp * wp, o), F32)
+        acc[:] = 0.0 if bias is None else bias.astype(F32)[None, :]
+        for kt in range(3):
+            for kh in range(3):
+                for kw in range(3):
+                    off = (kt * hp + kh) * wp + kw
+                    # acc[:n] += rows[off:off+n] @ wt[kt,kh,kw], as the column-major product acc^T += W^T @ rows^T (all three
+                    # operands are Fortran-contiguous views, so the BLAS call works in place)
+                    r = sgemm(1.0, wt[kt, kh, kw].T, rows[off:off + n].T, beta=1.0, c=acc[:n].T, overwrite_c=1)
+                    assert np.shares_memory(r, acc)
+        a4 = acc.reshape(t, hp, wp, o)
+
+        def take(f):
+            out[bi, :, f] = a4[f, :h, :wd].transpose(2, 0, 1)
+
+        list(_pool.map(take, range(t)))
+    return out
+
+
 def pixel_norm(x, eps=1e-8):
     """vaePixelNorm (VideoDecoder.swift:29-32)."""
-    ms = np.mean(x.astype(np.float64) ** 2, axis=1, keepdims=True)
-    return (x / np.sqrt(ms + eps)).astype(F32)
+    def f(v):
+        ms = np.mean(v.astype(np.float64) ** 2, axis=1, keepdims=True)
+        return (v / np.sqrt(ms + eps)).astype(F32)
+    return _pmap(f, x, x.ndim - 2) if x.ndim >= 4 else f(x)
 
 
 def vae_res_block(w, p, x, time_emb=None):
@@ -528,9 +619,9 @@ def vae_res_block(w, p, x, time_emb=None):
         sst = sst[None]
     r = lambda v: v.reshape(v.shape[0], -1, 1, 1, 1)
     shift1, scale1, shift2, scale2 = r(sst[:, 0]), r(sst[:, 1] + 1), r(sst[:, 2]), r(sst[:, 3] + 1)
-    h = silu(pixel_norm(x) * scale1 + shift1)
+    h = _pmap(lambda v: silu(pixel_norm(v) * scale1 + shift1), x, 3)   # position-wise: slabs along H
     h = conv3d_full(h, w[p + "conv1.conv.weight"], w[p + "conv1.conv.bias"])
-    h = silu(pixel_norm(h) * scale2 + shift2)
+    h = _pmap(lambda v: silu(pixel_norm(v) * scale2 + shift2), h, 3)
     h = conv3d_full(h, w[p + "conv2.conv.weight"], w[p + "conv2.conv.bias"])
     return (h + x).astype(F32)
 
@@ -615,11 +706,11 @@ def vae_decode_raw(w, latent, channels=VAE_CHANNELS, timestep=None, noise=None):
             x = vae_res_block(w, f"up_blocks_{2 * gi}.res_blocks.{r}.", x, te)
         if gi < 3:
             x = vae_upsample(w, f"up_blocks_{2 * gi + 1}.", x)
-    x = pixel_norm(x)
     lsst = w["last_scale_shift_table"].astype(F32)[None]
     if scaled is not None:
         lsst = lsst + vae_time_embed(w, "last_time_embedder.", scaled).reshape(x.shape[0], 2, -1)
-    x = silu(x * (lsst[:, 1] + 1).reshape(lsst.shape[0], -1, 1, 1, 1) + lsst[:, 0].reshape(lsst.shape[0], -1, 1, 1, 1))
+    sc, sh = (lsst[:, 1] + 1).reshape(lsst.shape[0], -1, 1, 1, 1), lsst[:, 0].reshape(lsst.shape[0], -1, 1, 1, 1)
+    x = _pmap(lambda v: silu(pixel_norm(v) * sc + sh), x, 3)
     x = conv3d_full(x, w["conv_out.conv.weight"], w["conv_out.conv.bias"])
     return vae_unpatchify(x, 4)
 

@@ -132,6 +132,28 @@ def test_vae_res_block_at_headline_resolution_vs_oracle(ltx, oracle, vae_from_or
     assert float(np.linalg.norm(ref - x_cl) / np.linalg.norm(x_cl)) > 1e-2, "the block adds too little to prove anything"
 
 
+def test_vae_whole_decode_768x512x25_vs_oracle(ltx, oracle, vae_from_oracle_weights):
+    """The WHOLE headline decode in one comparison (round-3 verdict 1c): [1,128,4,16,24] -> (25,512,768,3), all 42 convs chained -
+    the halo-staged kernel, the split-K tile windows, the three fused depth-to-space stores, the fused PixelNorm + SiLU epilogues and
+    the permuted conv_out rows - against oracle.decode_video (VideoDecoder.swift:358-449) on every one of the 29.5 M values.
+    Bounds: the ones test_vae_gpu.py states (<= 2e-2 abs on [0,1] frames, rel-L2 <= 3e-2 about the mean)."""
+    import time
+
+    ctx, w = vae_from_oracle_weights
+    rng = np.random.default_rng(45)
+    lat = rng.standard_normal((1, 128, 4, 16, 24)).astype(np.float32)
+    got = ctx.vae_decode(lat)
+    assert got.shape == (25, 512, 768, 3) and np.isfinite(got).all()
+    t0 = time.time()
+    ref = np.clip((oracle.decode_video(w, lat, return_raw=True) + 1) / 2, 0, 1)
+    err = float(np.abs(got - ref).max())
+    rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref - ref.mean()))
+    sat = float(np.mean((ref <= 0) | (ref >= 1)))
+    print(f"whole decode 768x512x25: max abs {err:.3e}, rel-L2 {rel:.3e}, clipped share {sat:.3f} (oracle {time.time() - t0:.0f} s)")
+    assert sat < 0.5, "the synthetic decoder saturates: the comparison proves too little"
+    assert err <= 2e-2 and rel <= 3e-2, (err, rel)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # (c) rank-384 LoRA on a D = 4096 model
 # ---------------------------------------------------------------------------------------------------------------

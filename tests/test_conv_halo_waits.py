@@ -3,13 +3,16 @@ immediates derived by hand in the file's header. This test replays the kernel's 
 tail - for both instances (2 or 1 weight pieces per wave and K-tile) and several channel counts, and checks on the model what the
 assembly generators' checkers prove on their streams: at every mid-tile wait the loads the NEXT K-tile reads (its weight tile; its slab if
 it opens a triple) are older than the N youngest loads in flight, no slab / weight slot is overwritten while a K-tile that reads it is
-still ahead of the barrier that precedes the overwrite, and every load issued is waited for before the epilogue. The immediates and ring
+still ahead of the barrier that precedes the overwrite (and its fragment reads have RETIRED before that barrier: an lgkmcnt(0) in the
+wait - round-3 advice), and every load issued is waited for before the epilogue. The immediates and ring
 sizes are read from the source, so an edit there that breaks the schedule fails here without a GPU.
 (VideoConvolution.swift:202-348 is the conv being computed; the schedule itself has no reference counterpart.)"""
 import os
 import re
 
 import pytest
+
+DX2_WAIT_RETIRES_LDS_READS = None
 
 SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ltx-video-swift-mlx_amd", "csrc", "conv_halo.inc")
 
@@ -18,9 +21,13 @@ def _constants():
     text = open(SRC).read()
     m = re.search(r"NS = (\d+), NB = (\d+)", text)
     ns, nb = int(m.group(1)), int(m.group(2))
-    m = re.search(r"wait_vmcnt_barrier<\(DX == 2 \|\| FIRST\) \? (\d+) \* BPW : (\d+) \* BPW \+ (\d+)>", text)
-    assert m, "steady wait expression changed: update this model"
+    m2 = re.search(r"if constexpr \(DX == 2\) (wait_\w+)<(\d+) \* BPW>\(\);", text)
+    m = re.search(r"else wait_vmcnt_barrier<FIRST \? (\d+) \* BPW : (\d+) \* BPW \+ (\d+)>", text)
+    assert m and m2, "steady wait expressions changed: update this model"
     tight_b, loose_b, loose_c = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    assert int(m2.group(2)) == tight_b
+    global DX2_WAIT_RETIRES_LDS_READS
+    DX2_WAIT_RETIRES_LDS_READS = m2.group(1) == "wait_lgkm_vmcnt_barrier"  # lgkmcnt(0) in the wait that precedes the slab re-stage
     assert re.search(r"wait_vmcnt_barrier<BPW \* \(PDB - 1\)>", text), "prologue wait changed: update this model"
     assert "if constexpr (DX == 2) stage_slab(sbuf);" in text and "stage_slab(0);\n    stage_slab(1);" in text
     return ns, nb, tight_b, loose_b, loose_c
@@ -29,7 +36,20 @@ def _constants():
 @pytest.mark.parametrize("bpw", [2, 1])
 @pytest.mark.parametrize("cpt", [1, 2, 4, 8])
 def test_counted_waits_cover_every_fragment_read(bpw, cpt):
+    _replay(bpw, cpt, None)
+
+
+def test_the_model_rejects_a_slab_restage_without_the_lgkm_wait():
+    """Round-3 advice: with a vmcnt-only wait before the DX == 2 barrier, another wave's LDS-DMA may overwrite the slab while this
+    wave's fa1 reads are outstanding. The replay must see that."""
+    with pytest.raises(AssertionError, match="WAR"):
+        _replay(2, 2, False)
+
+
+def _replay(bpw, cpt, dx2_lgkm):
     ns, nb, tight_b, loose_b, loose_c = _constants()
+    if dx2_lgkm is None:
+        dx2_lgkm = DX2_WAIT_RETIRES_LDS_READS
     assert ns == 2
     pdb = nb - 1
     nq, nk = 9 * cpt, 27 * cpt
@@ -64,10 +84,16 @@ def test_counted_waits_cover_every_fragment_read(bpw, cpt):
         # first half reads K-tile t's second fragments: its slab and weights must be the ones in LDS
         assert slab_of_buf[q % ns] == q, (t, slab_of_buf)
         assert tile_of_slot[t % nb] == t, (t, tile_of_slot)
+        # the first half has ISSUED the second fragments' reads (fa1 / fb1); the MFMAs that consume them sit behind the barrier, so only an
+        # lgkmcnt(0) in the wait retires them before it (the first fragments, read in the previous second half, were consumed by this
+        # first half's MFMAs and are retired)
+        reads_in_flight = {("slab", q % ns), ("w", t % nb)}
         # mid-tile wait + barrier
         if steady:
             n = tight_b * bpw if (dx == 2 or first) else loose_b * bpw + loose_c
             ok = landed_after_wait(n)
+            if dx == 2 and dx2_lgkm:
+                reads_in_flight = set()
         elif not drained:
             ok = landed_after_wait(0)
             drained = True
@@ -80,11 +106,13 @@ def test_counted_waits_cover_every_fragment_read(bpw, cpt):
             if dx == 2:
                 # the buffer being overwritten belongs to triple q, whose last fragment read was in this iteration's first half
                 assert slab_of_buf[q % ns] == q
+                assert ("slab", q % ns) not in reads_in_flight, (t, "slab re-staged while fragment reads of it may be outstanding (WAR)")
                 stage_slab(next_slab, q % ns)
                 next_slab += 1
             # the slot being overwritten held K-tile t - 1 (read in the previous iteration, a barrier ago)
             slot = (t + pdb) % nb
             assert tile_of_slot.get(slot, -1) in (-1, t - 1) or t == 0, (t, slot, tile_of_slot)
+            assert ("w", slot) not in reads_in_flight, (t, "weight slot re-staged while fragment reads of it may be outstanding (WAR)")
             stage_w(t + pdb)
         if t + 1 < nk:
             q1 = (t + 1) // 3

@@ -1,0 +1,90 @@
+"""Parity at the reference's DEPTH and at the headline SIZE (round-3 verdict, item 1): the stated tolerances, until now shown on
+two-layer cuts, on small latents or block by block, are checked here on the whole thing.
+
+  (a) ltx_denoise_dev, ALL 48 layers, D = 4096, distilled 8-step schedule, config 1's 2x8x8 latent (128 tokens, 256 text keys)
+      vs oracle.denoise: final latent rel-L2 <= 1e-2, cos >= 0.999 - the end-to-end bound of DESIGN.md section 2
+      (LTXPipeline.swift:800-956).
+  (b) one 48-layer forward at the HEADLINE shape (T = 1536 = 4x16x24, S = 1024, masked) vs oracle.dit_forward: rel-L2 <= 2e-2,
+      cos >= 0.9995 (the bound the 2- and 8-layer cuts are held to; LTXTransformer.swift:235-486).
+  (c) in tests/test_config4_and_full_res_parity_gpu.py (it owns the full-size VAE fixture): the whole 768x512x25 decode.
+
+The oracle gets the very weights the library holds (ltx_dit_export_param); they are fetched once and kept on the host as f32 (52 GB:
+the GPU box allows 270 GiB) so that the eight steps of (a) and the forward of (b) do not re-export them. Host time on the GPU box:
+about a minute of export, then BLAS.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from test_dit_gpu import rel_l2
+from test_full_width_parity_gpu import _cos, _dev_bf16, _forward
+
+pytestmark = pytest.mark.gpu
+
+
+class HostWeights(dict):
+    """Module key -> f32 array; exported from the library on first access and kept."""
+
+    def __init__(self, ctx, shapes):
+        super().__init__()
+        self.ctx, self.shapes = ctx, shapes
+
+    def __missing__(self, key):
+        self[key] = v = self.ctx.dit_export_param(key).reshape(self.shapes[key])
+        return v
+
+    def __contains__(self, key):
+        return key in self.shapes
+
+
+@pytest.fixture(scope="module")
+def full48_host(ltx, oracle):
+    """The reference architecture (48 layers, 32 heads x 128, caption 3840) with on-device synthetic weights (seed 1234: what
+    bench.py runs) and their host mirror for the oracle."""
+    ctx = ltx.Context(0)
+    cfg = ltx.default_transformer_config()
+    ctx.dit_init_synthetic(cfg, seed=1234)
+    ocfg = oracle.DiTConfig()
+    yield ctx, cfg, ocfg, HostWeights(ctx, oracle.dit_param_shapes(ocfg))
+    ctx.close()
+
+
+def test_48_layer_forward_at_the_headline_shape_vs_oracle(ltx, oracle, full48_host):
+    """(b) BASELINE configs[1]'s forward: 768x512x25 -> 1536 tokens, 1024 text keys, a tenth of them masked, all 48 blocks."""
+    ctx, cfg, ocfg, w = full48_host
+    F, H, W, S = 4, 16, 24, 1024
+    T = F * H * W
+    rng = np.random.default_rng(2)
+    lat = oracle.bf16_round(rng.standard_normal((1, T, 128)).astype(np.float32))
+    cx = oracle.bf16_round(rng.standard_normal((1, S, 3840)).astype(np.float32))
+    mask = (rng.random((1, S)) > 0.1).astype(np.int32)
+    mask[:, 0] = 1
+    got = _forward(ctx, lat, cx, 0.9086057, mask, F, H, W, version=11)
+    t0 = time.time()
+    ref = oracle.dit_forward(w, ocfg, lat, cx, np.array([0.9086057], np.float32), mask, F, H, W)
+    r, c = rel_l2(got, ref), _cos(got, ref)
+    print(f"full width, 48 blocks, T={T}, S={S}, masked: rel-L2 {r:.3e}, cos {c:.6f} (oracle {time.time() - t0:.0f} s)")
+    assert np.isfinite(got).all() and r <= 2e-2 and c >= 0.9995, (r, c)
+
+
+def test_48_layer_eight_step_denoise_vs_oracle(ltx, oracle, full48_host):
+    """(a) The stated end-to-end tolerance at the reference's depth: 8 Euler steps x 48 blocks compound the per-block bf16 deviation."""
+    ctx, cfg, ocfg, w = full48_host
+    assert ltx.latent_shape(256, 256, 9) == (2, 8, 8)
+    F, H, W, S = 2, 8, 8, 256
+    rng = np.random.default_rng(8)
+    noise = rng.standard_normal((1, 128, F, H, W)).astype(np.float32)
+    cx = oracle.bf16_round(rng.standard_normal((1, S, 3840)).astype(np.float32))
+    sig = ltx.sigmas(True, 8, F * H * W)
+    assert len(sig) == 9
+    lat0 = noise * sig[0]
+    latd = torch.from_numpy(lat0).cuda()
+    ctx.denoise_dev(latd, sig, _dev_bf16(cx), None, F, H, W, ctx_version=78)
+    got = latd.cpu().numpy()
+    t0 = time.time()
+    ref = oracle.denoise(w, ocfg, lat0, sig, cx, None, F, H, W)
+    r, c = rel_l2(got, ref), _cos(got, ref)
+    print(f"full width, 48 blocks, 8-step denoise: rel-L2 {r:.3e}, cos {c:.6f} (oracle {time.time() - t0:.0f} s)")
+    assert np.isfinite(got).all() and r <= 1e-2 and c >= 0.999, (r, c)

@@ -65,6 +65,21 @@ def test_conv3d_full(oracle, causal):
     xp = torch.cat([xp[:, :, :1]] * 2 + [xp], 2) if causal else torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], 2)
     ref = Fn.conv3d(xp, torch.from_numpy(w), torch.from_numpy(b)).numpy()
     assert np.allclose(oracle.conv3d_full(x, w, b, causal), ref, atol=1e-4)
+    assert np.allclose(oracle.conv3d_full_einsum(x, w, b, causal), ref, atol=1e-4)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("shape,cout", [((2, 8, 1, 2, 2), 4), ((1, 16, 3, 5, 6), 8), ((1, 64, 4, 16, 24), 96), ((1, 32, 2, 40, 36), 5)])
+def test_conv3d_blas_form_equals_the_einsum_form(oracle, shape, cout, causal):
+    """conv3d_full (one in-place sgemm per tap on the flattened padded grid, threaded padding) against the first restatement
+    (27 patch copies + einsum): same taps in the same order, so only the BLAS-internal summation order differs."""
+    rng = np.random.default_rng(sum(shape) + cout)
+    x = rng.standard_normal(shape).astype(np.float32)
+    w = rng.standard_normal((cout, shape[1], 3, 3, 3)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    a, c = oracle.conv3d_full_einsum(x, w, b, causal), oracle.conv3d_full(x, w, b, causal)
+    assert a.shape == c.shape and float(np.abs(a - c).max()) <= 2e-6 * float(np.abs(a).max())
+    assert np.array_equal(oracle.conv3d_full(x, w, None, causal), oracle.conv3d_full(x, w, np.zeros(cout, np.float32), causal))
 
 
 def test_depth_to_space_and_unpatchify_index_maps(oracle):
@@ -112,6 +127,7 @@ def test_oracle_matches_golden_fixtures(oracle):
     assert np.allclose(vel, g["velocity"], rtol=1e-4, atol=1e-4)
     c = np.load(os.path.join(GOLD, "conv3d_small.npz"))
     assert np.allclose(oracle.conv3d_full(c["x"], c["w"], c["b"]), c["y"], atol=1e-4)
+    assert np.allclose(oracle.conv3d_full_einsum(c["x"], c["w"], c["b"]), c["y"], atol=1e-4)
     k = np.load(os.path.join(GOLD, "connector_tiny.npz"))
     wk = oracle.synth_connector_weights(dim=int(k["dim"]), heads=int(k["heads"]), layers=int(k["layers"]), registers=int(k["registers"]),
                                         states=int(k["states"]), seed=int(k["seed"]))
