@@ -162,6 +162,20 @@ struct LtxError {
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only, and one process may hold contexts on several
 // GPUs (ltx_ctx_create(device)): a process-wide "done" flag would leave the second device's first launch of a > 64 KB LDS kernel
 // without its attribute. One bit per device, set under a lock so that a second thread cannot launch between check and set.
+// CUs of the current device (cached per device index; 256 on MI355X)
+inline int device_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int v = cached[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+        hipDeviceProp_t p;
+        v = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+        cached[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 struct PerDeviceOnce {
     std::atomic<uint64_t> done{0};
     std::mutex mu;

@@ -600,6 +600,10 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
     LTX_REQUIRE(D % 4 == 0 && D <= MAXV * 1024 && ldx % 4 == 0 && ldo % 4 == 0, "norm_mod: D=%d ldx=%ld ldo=%ld", D, ldx, ldo);
     LTX_REQUIRE((scale == nullptr) == (shift == nullptr), "norm_mod: scale/shift must both be set or both null");
     const int rpb = rows_per_batch < 1 ? 1 : rows_per_batch;
+#ifdef LTX_EXPERIMENTS  // timing ablation (experiments library only): LTX_ABL_ROWS bit 0 drops this pass after the first 400 calls - the
+    // buffers keep realistic stale values, so what the step then gains is the upper bound of any fusion of the pass (profiles/r04_row_ablation.txt)
+    { static const int abl = getenv("LTX_ABL_ROWS") ? atoi(getenv("LTX_ABL_ROWS")) : 0; static long calls = 0; if ((abl & 1) && ++calls > 400) return; }
+#endif
     ProfScope prof(PROF_ELEM, (double)rows * D * (4 + 2), stream);  // algorithmic bytes: f32 row in, bf16 row out
     // rows per workgroup: 4 share one fetch of the modulation vectors; at 1536 rows that is 384 workgroups = 1.5 per CU, and two rows per
     // workgroup (768 = 3 per CU) are 10 % faster (9.15 vs 10.2 us alone, 36.39 vs 36.53 ms per forward); no difference from 6144 rows up
@@ -821,6 +825,10 @@ void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const f
                          hipStream_t stream, float out_scale0) {
     LTX_REQUIRE(D % 128 == 0 && D <= MAXV * 1024 && ldx % 4 == 0 && ldo % 4 == 0, "qknorm_rope: D=%d", D);
     const QkJob j0{x0, w0, out0, ldx, ldo, out_scale0}, j1{x1, w1, out1, ldx, ldo, 1.0f};
+#ifdef LTX_EXPERIMENTS  // timing ablation: LTX_ABL_ROWS bit 1 drops the q|k pass, bit 2 the cross-attention q pass, after two forwards' worth of calls
+    { static const int abl = getenv("LTX_ABL_ROWS") ? atoi(getenv("LTX_ABL_ROWS")) : 0; static long c2 = 0, c1 = 0;
+      if (x1 && (abl & 2) && ++c2 > 200) return; if (!x1 && (abl & 4) && ++c1 > 300) return; }
+#endif
     // algorithmic bytes: the f32 rows in, the bf16 rows out, cos/sin rows once per job
     ProfScope prof(PROF_ELEM, (double)rows * D * (x1 ? 2 : 1) * (4 + 2 + (cosT ? 4 : 0)), stream);
     const dim3 grid(rows, x1 ? 2 : 1);

@@ -86,9 +86,12 @@ LTX_DEVFN void tile_coords(const GemmArgs& g, int bid, int tiles_m, int BN_, int
 // VGPRs all at once next to this function's prefetch buffers).
 // Residual-stream values of this wave's whole tile, loaded by the kernel under its last K-tiles (`gemm_residual_prefetch`) so that
 // the epilogue of a gated-residual GEMM - one workgroup per CU, nothing else resident - does not start with an exposed HBM read.
-template <int BM, int BN, int WGM, int WGN>
+// NSL: how many of the wave's 16-row slabs are held (all of them by default). A kernel whose registers are too few to hold the whole tile
+// next to its accumulators keeps slab 0 only (the persistent conv kernel: 16 instead of 48 registers) and the epilogue fetches the
+// others itself, one slab ahead.
+template <int BM, int BN, int WGM, int WGN, int NSL = BM / WGM / 16>
 struct ResidualTile {
-    static constexpr int MI = BM / WGM / 16, NIT = (16 * (BN / WGN / 4)) / 64;
+    static constexpr int MI = NSL, NSLABS = NSL, NIT = (16 * (BN / WGN / 4)) / 64;
     f32x4 v[MI][NIT];
     f32x4 bias[NIT];          // the column bias: what the epilogue's first slab waits on in launches without a residual
     bool valid = false;       // v holds data
@@ -96,8 +99,8 @@ struct ResidualTile {
 };
 
 // Column bias of this wave's tile (every launch with interior columns), fetched under the last K-tiles as well.
-template <int BM, int BN, int WGM, int WGN>
-LTX_DEVFN void gemm_bias_prefetch(const GemmArgs& g, int n0, int wc, int lane, ResidualTile<BM, BN, WGM, WGN>& rt) {
+template <int BM, int BN, int WGM, int WGN, int NSL>
+LTX_DEVFN void gemm_bias_prefetch(const GemmArgs& g, int n0, int wc, int lane, ResidualTile<BM, BN, WGM, WGN, NSL>& rt) {
     constexpr int WN = BN / WGN, LPR = WN / 4, NIT = (16 * LPR) / 64;
     const int gn_w = n0 + wc * WN;
 #pragma unroll
@@ -108,9 +111,9 @@ LTX_DEVFN void gemm_bias_prefetch(const GemmArgs& g, int n0, int wc, int lane, R
     rt.bias_valid = true;
 }
 
-template <int BM, int BN, int WGM, int WGN>
-LTX_DEVFN void gemm_residual_prefetch(const GemmArgs& g, int m0, int n0, int wr, int wc, int lane, ResidualTile<BM, BN, WGM, WGN>& rt) {
-    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, LPR = WN / 4, NIT = (16 * LPR) / 64;
+template <int BM, int BN, int WGM, int WGN, int NSL>
+LTX_DEVFN void gemm_residual_prefetch(const GemmArgs& g, int m0, int n0, int wr, int wc, int lane, ResidualTile<BM, BN, WGM, WGN, NSL>& rt) {
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = NSL, LPR = WN / 4, NIT = (16 * LPR) / 64;
     const GemmEpilogue& ep = g.ep;
     const float* rbase = ep.resid_src ? ep.resid_src : ep.out_f32;
     const long rld = ep.resid_src ? ep.ld_resid : ep.ld_f32;
@@ -131,15 +134,23 @@ LTX_DEVFN void gemm_residual_prefetch(const GemmArgs& g, int m0, int n0, int wr,
 // workgroup barrier per 16-row slab and registers the dense kernels' epilogues do not have to spare).
 // SCR: `get(mi_c, scr)` writes the 16 x WN slab row-major into this wave's LDS scratch itself (accumulators that are not in the
 // 16x16 MFMA layout: the 32x32x16 kernel); the transposed store, which works from the 16x16 register layout, is then not available.
-template <int BM, int BN, int WGM = 2, int WGN = 2, bool PN = false, bool SCR = false, class Get>
+// SGATE: the launch never carries a gate VECTOR (conv launches: residual gate = gate_scalar) - the interior path then keeps no gate
+// registers (32 per lane in the general form, which the persistent conv kernel does not have to spare).
+// `hook()`: called once, at the point of the epilogue behind which it issues no further global LOAD (the interior path: right after the
+// residual fetch of the last slab has been requested). A persistent kernel requests its next tile's first operands there: vmcnt retires
+// loads in order, so anything requested earlier would be waited for by every later residual fetch of this epilogue.
+struct NoHook { LTX_DEVFN void operator()() const {} };
+template <int BM, int BN, int WGM = 2, int WGN = 2, bool PN = false, bool SCR = false, bool SGATE = false, class Get, class Pre = ResidualTile<BM, BN, WGM, WGN>,
+          class Hook = NoHook>
 LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, int wr, int wc, int lane, int wave, char* smem,
-                                  const ResidualTile<BM, BN, WGM, WGN>* pre = nullptr) {
+                                  const Pre* pre = nullptr, Hook&& hook = Hook{}) {
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
     float* scr = (float*)(smem + wave * (16 * WN * 4));
     constexpr int LPR = WN / 4;    // lanes per output row
     const GemmEpilogue& ep = g.ep;
     if constexpr (!SCR)
     if (ep.out_bf16_t) {
+        hook();
         // transposed bf16 store from the accumulator layout: acc[mi][ni][r] = C[16 mi + 4 (lane >> 4) + r][16 ni + (lane & 15)]
         static_for<0, MI>([&](auto mi_c) {
             constexpr int mi = decltype(mi_c)::value;
@@ -191,7 +202,7 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
         const int row_lo = (m0 + wr * WM) < g.M ? (m0 + wr * WM) : g.M - 1;
         const int row_hi = (m0 + wr * WM + WM - 1) < g.M ? (m0 + wr * WM + WM - 1) : g.M - 1;
         const int gb_lo = row_lo / ep.rows_per_batch;
-        const bool gate_uniform = has_res && ep.gate && !ep.gate_rowmap && gb_lo == row_hi / ep.rows_per_batch;
+        const bool gate_uniform = !SGATE && has_res && ep.gate && !ep.gate_rowmap && gb_lo == row_hi / ep.rows_per_batch;
         f32x4 gtu[NIT];
         if (gate_uniform) {
 #pragma unroll
@@ -206,11 +217,17 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
                 const int c4 = (chunk % LPR) * 4;
                 int gm = m0 + wr * WM + mi * 16 + chunk / LPR;
                 gm = gm < g.M ? gm : g.M - 1;
-                if (pre_res)
-                    rs[buf][it] = pre->v[mi][it];
-                else
-                    rs[buf][it] = *(const f32x4*)(rbase + (long)gm * rld + gn_w + c4);
-                if (gate_uniform)
+                bool held = false;
+                if constexpr (mi < Pre::NSLABS) {
+                    if (pre_res) {
+                        rs[buf][it] = pre->v[mi][it];
+                        held = true;
+                    }
+                }
+                if (!held) rs[buf][it] = *(const f32x4*)(rbase + (long)gm * rld + gn_w + c4);
+                if constexpr (SGATE) {
+                    // (nothing: the scalar gate is applied from ep.gate_scalar below)
+                } else if (gate_uniform)
                     gt[buf][it] = gtu[it];
                 else if (ep.gate)
                     gt[buf][it] = *(const f32x4*)(ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[gm] : gm / ep.rows_per_batch) * ep.gate_bstride + gn_w + c4);
@@ -235,6 +252,7 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
             constexpr int mi = decltype(mi_c)::value;
             constexpr int buf = mi & 1;
             if constexpr (mi + 1 < MI) prefetch(std::integral_constant<int, mi + 1>{}, std::integral_constant<int, (mi + 1) & 1>{});
+            if constexpr (mi == (MI >= 2 ? MI - 2 : 0)) hook();  // the last residual fetch has just been requested
             if constexpr (SCR) {
                 get(mi_c, scr);
             } else {
@@ -274,7 +292,7 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
                 }
                 if (has_res) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = rs[buf][it][e] + gt[buf][it][e] * v[e];
+                    for (int e = 0; e < 4; ++e) v[e] = rs[buf][it][e] + (SGATE ? ep.gate_scalar : gt[buf][it][e]) * v[e];
                 }
 #ifdef EPI_NO_STORE  // tools/ubench/gemm_stamps.hip timing experiment
                 if (gm < 0) {
@@ -326,6 +344,7 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
         });
         return;
     }
+    hook();
     static_for<0, MI>([&](auto mi_c) {
         constexpr int mi = decltype(mi_c)::value;
         if constexpr (SCR) {
@@ -461,17 +480,17 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
     });
 }
 
-template <int BM, int BN, int WGM = 2, int WGN = 2, bool PN = false>
+template <int BM, int BN, int WGM = 2, int WGN = 2, bool PN = false, bool SGATE = false, class Pre = ResidualTile<BM, BN, WGM, WGN>, class Hook = NoHook>
 LTX_DEVFN void gemm_epilogue(f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], const GemmArgs& g, int m0, int n0, int wr, int wc,
-                             int lane, int wave, char* smem, const ResidualTile<BM, BN, WGM, WGN>* pre = nullptr) {
+                             int lane, int wave, char* smem, const Pre* pre = nullptr, Hook&& hook = Hook{}) {
     constexpr int NI = BN / WGN / 16;
-    gemm_epilogue_with<BM, BN, WGM, WGN, PN>(
+    gemm_epilogue_with<BM, BN, WGM, WGN, PN, false, SGATE>(
         [&](auto mi_c, f32x4(&slab)[NI]) {
             constexpr int mi = decltype(mi_c)::value;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) slab[ni] = acc[mi][ni];
         },
-        g, m0, n0, wr, wc, lane, wave, smem, pre);
+        g, m0, n0, wr, wc, lane, wave, smem, pre, hook);
 }
 
 template <int BM, int BN, bool CONV>
@@ -1051,8 +1070,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         // gated-residual launches (the DiT's attention-out and FFN-out projections): fetch the residual-stream tile now, under the
         // MFMAs of the last PD-1 K-tiles, instead of at the top of the epilogue
         if (!g.ep.d2s && g.split_k <= 1 && n0 + BN <= g.N && kt < nk) {
-            gemm_bias_prefetch<BM, BN, WGM, WGN>(g, n0, wc, lane, rt);
-            if (g.ep.resid) gemm_residual_prefetch<BM, BN, WGM, WGN>(g, m0, n0, wr, wc, lane, rt);
+            gemm_bias_prefetch(g, n0, wc, lane, rt);
+            if (g.ep.resid) gemm_residual_prefetch(g, m0, n0, wr, wc, lane, rt);
         }
     }
     for (; kt < nk; ++kt) ktile(kt, std::false_type{});
@@ -1286,8 +1305,8 @@ __global__ __launch_bounds__(256, 1) void gemm_fewrow_kernel(const GemmArgs g) {
             if (m + PBM < nm) { stage_b(m + PBM); b_issued = m + PBM; }
         }
         if (t == nk - 1 && !g.ep.d2s && g.split_k <= 1 && n0 + BN <= g.N) {  // residual / bias under the last tile's MFMAs
-            gemm_bias_prefetch<BM, BN, WGM, WGN>(g, n0, wc, lane, rt);
-            if (g.ep.resid) gemm_residual_prefetch<BM, BN, WGM, WGN>(g, m0, n0, wr, wc, lane, rt);
+            gemm_bias_prefetch(g, n0, wc, lane, rt);
+            if (g.ep.resid) gemm_residual_prefetch(g, m0, n0, wr, wc, lane, rt);
         }
         const char* abase = smem + A_OFF + (t % NA) * A_BYTES + a_wave_off;
         s16x8 fa[2][MI], fb[2][NI];
@@ -1503,8 +1522,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_m32(const GemmArgs g) {
         ++kt;
         drained = true;
         if (!g.ep.d2s && g.split_k <= 1 && n0 + BN <= g.N && kt < nk) {
-            gemm_bias_prefetch<BM, BN, WGM, WGN>(g, n0, wc, lane, rt);
-            if (g.ep.resid) gemm_residual_prefetch<BM, BN, WGM, WGN>(g, m0, n0, wr, wc, lane, rt);
+            gemm_bias_prefetch(g, n0, wc, lane, rt);
+            if (g.ep.resid) gemm_residual_prefetch(g, m0, n0, wr, wc, lane, rt);
         }
     }
     for (; kt < nk; ++kt) ktile(kt, std::false_type{});
@@ -1958,8 +1977,10 @@ static bool conv_halo_takes(const GemmArgs& a) {
     // (win_rows on a launch without split-K is work accounting only: the head launch of a window pair)
     if (off || !a.conv || q.kt != 3 || !(q.pad_mode == 0 || q.pad_mode == 2) || q.C % 64 != 0 || a.split_k > 1 || a.tile0 != 0) return false;
     if (a.K != 27 * q.C || a.M != q.F * q.H * q.W || a.M < 192 || a.ldb % 8 != 0) return false;
+    if ((long)a.M * q.C >= (1L << 31) || (long)a.N * a.ldb >= (1L << 31)) return false;  // the kernel addresses both operands with 32-bit element offsets
+    if ((long)a.M * q.W >= (1L << 32) || (long)q.F * q.H * q.H >= (1L << 32) || q.H < 2 || q.W < 2) return false;  // ... and divides by W and H with multiply-high forms
     const bool w_ok = (q.W <= 192 && q.W >= 48 && 192 % q.W == 0) || (q.W % 192 == 0);
-    return w_ok && !a.ep.out_bf16_t;
+    return w_ok && !a.ep.out_bf16_t && !a.ep.gate;  // (its epilogue is the scalar-gate form)
 }
 template <int BN>
 static void launch_conv_halo(const GemmArgs& a, hipStream_t stream) {
@@ -1969,7 +1990,12 @@ static void launch_conv_halo(const GemmArgs& a, hipStream_t stream) {
     const int all_tiles = ((a.M + 191) / 192) * ((a.N + BN - 1) / BN);
     const int tiles = a.tile_count ? a.tile_count : all_tiles;
     LTX_REQUIRE(tiles <= all_tiles, "conv halo: tile window of %d tiles outside %d", tiles, all_tiles);
-    hipLaunchKernelGGL(conv3d_halo_kernel<BN>, dim3(tiles), dim3(512), smem, stream, a);
+    // persistent above one round: one workgroup per CU walks the tiles of its XCD's chunk and requests the next tile's first operands
+    // before the epilogue of the current one (conv_halo.inc); LTX_CONV_PERSIST=0 restores one workgroup per tile (A/B hook)
+    static const bool persist = !(getenv("LTX_CONV_PERSIST") && atoi(getenv("LTX_CONV_PERSIST")) == 0);
+    const int ncu = device_cu_count() & ~7;
+    const int grid = (persist && tiles > ncu && ncu >= 8) ? ncu : tiles;
+    hipLaunchKernelGGL(conv3d_halo_kernel<BN>, dim3(grid), dim3(512), smem, stream, a);
     HIP_CHECK(hipGetLastError());
 }
 

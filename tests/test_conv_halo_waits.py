@@ -39,6 +39,15 @@ def test_counted_waits_cover_every_fragment_read(bpw, cpt):
     _replay(bpw, cpt, None)
 
 
+@pytest.mark.parametrize("bpw", [2, 1])
+@pytest.mark.parametrize("cpt", [1, 2, 4])
+def test_persistent_handover_keeps_the_wait_accounting(bpw, cpt):
+    """Round 4: a workgroup walks several tiles; the next tile's first operands are requested from inside the epilogue. The K loop's
+    counted waits must hold when it is entered through that handover (fewer loads in flight than after the plain prologue, in the same
+    order), and the early request must stay out of the epilogue's scratch slots."""
+    _replay(bpw, cpt, None, handover=True)
+
+
 def test_the_model_rejects_a_slab_restage_without_the_lgkm_wait():
     """Round-3 advice: with a vmcnt-only wait before the DX == 2 barrier, another wave's LDS-DMA may overwrite the slab while this
     wave's fa1 reads are outstanding. The replay must see that."""
@@ -46,7 +55,22 @@ def test_the_model_rejects_a_slab_restage_without_the_lgkm_wait():
         _replay(2, 2, False)
 
 
-def _replay(bpw, cpt, dx2_lgkm):
+def _handover_constants():
+    """The persistent kernel's tile handover (round 4), read from the source: how many weight tiles of the NEXT tile are requested before the
+    epilogue (PRE_B), where the epilogue's scratch lives, and that the K loop restarts from a clean vmcnt behind a barrier."""
+    text = open(SRC).read()
+    pre_b = int(re.search(r"constexpr int PRE_B = (\d+);", text).group(1))
+    assert "char* smem_epi = smem + B_OFF + PRE_B * B_BYTES;" in text, "epilogue scratch moved: update this model"
+    i_epi = text.index("gemm_epilogue<BM, BN, WGM, WGN, (BN == 128), true>(acc, g, em0, en0")
+    tail = text[i_epi:]
+    i_wait = tail.index('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();')
+    i_rest = tail.index("for (int q = PRE_B; q < PDB; ++q) stage_b();")
+    assert 0 < i_wait < i_rest, "the remaining weight tiles must be staged behind vmcnt(0) + barrier"
+    assert "for (int q = 0; q < PRE_B; ++q) stage_b();" in text
+    return pre_b
+
+
+def _replay(bpw, cpt, dx2_lgkm, handover=False):
     ns, nb, tight_b, loose_b, loose_c = _constants()
     if dx2_lgkm is None:
         dx2_lgkm = DX2_WAIT_RETIRES_LDS_READS
@@ -65,14 +89,35 @@ def _replay(bpw, cpt, dx2_lgkm):
         issued.extend([("w", t)] * bpw)
         tile_of_slot[t % nb] = t
 
-    def landed_after_wait(n):
-        return set(issued[:len(issued) - n]) if n else set(issued)
+    landed_early = set()
+    retired = []           # loads a vmcnt(0) has already retired (handover), kept for the exactly-once bookkeeping
 
-    # prologue
-    stage_slab(0, 0)
-    stage_slab(1, 1)
-    for t in range(pdb):
-        stage_w(t)
+    def landed_after_wait(n):
+        return (set(issued[:len(issued) - n]) if n else set(issued)) | landed_early
+
+    if not handover:
+        # prologue of a workgroup's first tile
+        stage_slab(0, 0)
+        stage_slab(1, 1)
+        for t in range(pdb):
+            stage_w(t)
+    else:
+        # a later tile of a persistent workgroup: slabs 0 / 1 and the weights of K-tiles 0 .. PRE_B - 1 were requested from inside the
+        # previous tile's epilogue - into slabs 0 / 1 and ring slots 0 .. PRE_B - 1, while the epilogue's scratch occupies slots PRE_B .. -
+        # then vmcnt(0) + barrier, then the remaining weight tiles
+        pre_b = _handover_constants()
+        assert 1 <= pre_b <= pdb and nb - pre_b >= 2, "scratch needs the slots the early request leaves free"
+        stage_slab(0, 0)
+        stage_slab(1, 1)
+        for t in range(pre_b):
+            stage_w(t)
+        assert all(slot < pre_b for slot in tile_of_slot), "an early weight request lands in the epilogue's scratch"
+        issued_before = list(issued)
+        retired.extend(issued_before)
+        del issued[:]            # vmcnt(0): nothing of it is in flight any more ...
+        landed_early |= set(issued_before)
+        for t in range(pre_b, pdb):
+            stage_w(t)
     ok = landed_after_wait(bpw * (pdb - 1))
     assert ("slab", 0) in ok and ("w", 0) in ok
     next_slab = 2
@@ -118,7 +163,7 @@ def _replay(bpw, cpt, dx2_lgkm):
             q1 = (t + 1) // 3
             assert slab_of_buf[q1 % ns] == q1 and tile_of_slot[(t + 1) % nb] == t + 1
     assert next_slab == nq, "every triple's slab is staged exactly once"
-    assert sorted(set(x[1] for x in issued if x[0] == "w")) == list(range(nk)), "every K-tile's weights are staged exactly once"
+    assert sorted(set(x[1] for x in retired + issued if x[0] == "w")) == list(range(nk)), "every K-tile's weights are staged exactly once"
     assert drained, "the tail drains the loads in flight before the epilogue reuses LDS"
 
 
