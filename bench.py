@@ -325,12 +325,24 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="accepted for compatibility: the legs are off unless --extra-legs")
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher self-test: ranks rendezvous over gloo, count themselves and print the line without touching a GPU")
+    ap.add_argument("--sp-overlap", action="store_true",
+                    help="--mode sp / the sp extra leg: run each block's V^T gather on the library's side stream under the q|k projection "
+                         "(LTX_SP_OVERLAP=1; off by default until a multi-GPU run has confirmed it)")
+    ap.add_argument("--quant", type=int, choices=(0, 4, 8), default=0,
+                    help="--mode sp: quantise the transformer to this many bits (MLX affine, group 64) after the bf16 run and report both - "
+                         "BASELINE configs[4] names a qint8 transformer")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N ranks on ONE GPU over gloo (every rank on cuda:0, host-staged collectives): executes the multi-rank code of "
                          "this script where a single GPU is all there is; the line is labelled and is not a scaling measurement")
     ap.add_argument("--selftest-legs", choices=("hang", "error", "ok"), default=None,
                     help="with --launch-check: drive the extra-legs guard with a fake leg that hangs / raises / returns (no GPU)")
     args = ap.parse_args()
+    if args.sp_overlap:
+        os.environ["LTX_SP_OVERLAP"] = "1"  # read once by the library at its first sequence-parallel forward; inherited by spawned ranks
+    if args.rehearse_one_gpu and (args.mode != "replica" or args.extra_legs):
+        # every rank on cuda:0 over gloo: only the replica path (no RCCL communicator inside the library) can run like that - two ranks of
+        # one RCCL group on one device end in a duplicate-GPU error or in the watchdog
+        raise SystemExit("bench.py: --rehearse-one-gpu rehearses the replica path only (no --mode cfg-pair / sp / vae-tiles, no --extra-legs)")
 
     # ---- who launches the ranks? (before torch or the library are imported: no GPU call may precede a spawn) ----
     has_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -375,6 +387,8 @@ def main():
         return
 
     if args.rehearse_one_gpu:
+        # every rank on cuda:0 over gloo: only the replica path (no RCCL communicator inside the library) can run like that - two
+        # ranks of one RCCL group on one device end in a duplicate-GPU error or in the watchdog
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -659,6 +673,18 @@ def run_sp(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side):
     r = leg_sp(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side, args.steps, args.warmup)
     if "skipped" in r:
         raise SystemExit("bench.py --mode sp: " + r["skipped"])
+    if args.quant and world == 1:
+        # config 5's named setting: the same steps on the quantised model (codes + bf16 group scale / bias resident, bf16 weights released;
+        # at this token count every quantised GEMM is preceded by a de-quantise pass into one scratch matrix: the GEMMs are MFMA-bound
+        # here, so the price of the smaller model is that pass - LTXQuantizationConfig.swift:19-62)
+        mem0 = ctx.dit_memory_info()
+        ctx.dit_quantize(args.quant)
+        mem1 = ctx.dit_memory_info()
+        q = leg_sp(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side, args.steps, args.warmup)
+        r["quant"] = {"bits": args.quant, "group": 64, "steps_per_s": q["steps_per_s"], "ms_per_step": q["ms_per_step"],
+                      "vs_bf16": round(q["ms_per_step"] / r["ms_per_step"], 4),
+                      "weights_before": mem0, "weights_after": mem1,
+                      "note": "capacity feature at this size: the quantised step pays the de-quantise pre-pass of every Linear"}
     el = r["ms_per_step"] * 1e-3 * args.steps
     out = base_line(args, world, el, r["steps_per_s"], "strong",
                     "distilled schedule, 768x512x201 -> latent 26x16x24 (9984 tokens), 1024 text keys, CFG off, ONE sample over all "

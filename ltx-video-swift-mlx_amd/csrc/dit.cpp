@@ -348,8 +348,10 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     };
     // Self-test hook: LTX_SP_SELFTEST=1 sends a ONE-rank group of the native transport through the sequence-parallel branch (gathers of
     // one part, side stream, events): the only way to execute that code where a single GPU is all there is. Output bits == NW = 1 path.
-    static const bool sp_selftest = getenv("LTX_SP_SELFTEST") != nullptr;  // read once, like the other A/B hooks
-    const bool sp = NW > 1 || (sp_selftest && B == 1 && !a.sp_gather && dist_can_overlap(ctx) && dist_world(ctx) == 1);
+    // (the environment is consulted LAST, i.e. only on a context that holds a one-rank native group - a test artefact; no production
+    // forward reaches the getenv. The test sets the variable in mid-process, so it cannot be cached in a static.)
+    const bool sp_selftest = NW == 1 && B == 1 && !a.sp_gather && dist_can_overlap(ctx) && dist_world(ctx) == 1 && getenv("LTX_SP_SELFTEST") != nullptr;
+    const bool sp = NW > 1 || sp_selftest;
     const int T = Tfull / NW;            // rows this rank evaluates
     const int tok0 = a.sp_rank * T;      // first global token of this rank (NW == 1: 0)
     LTX_REQUIRE(B >= 1 && B <= 8 && T >= 1 && a.S >= 1, "dit_forward: bad shapes B=%d T=%d S=%d", B, T, a.S);
@@ -434,7 +436,11 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             // Sequence parallelism on the native transport: the V^T gather (and its interleave) runs on the side stream under
             // the q|k projection and its norm + RoPE pass; only the K gather stays on the critical path. Same kernels, same
             // operands, same order of every reduction: the bits do not depend on which stream carried a collective.
-            const bool overlap = sp && !a.sp_gather && dist_can_overlap(ctx);
+            // Opt-in (LTX_SP_OVERLAP=1, read once) until a run on two or more GPUs has confirmed it: the side-stream gather shares ONE RCCL
+            // communicator with the K gather on the context's stream, and no box reachable so far could execute that with two ranks
+            // (round-3 advice). The self-test hook always takes the branch - that is what it is for.
+            static const bool sp_overlap_on = getenv("LTX_SP_OVERLAP") && atoi(getenv("LTX_SP_OVERLAP")) != 0;
+            const bool overlap = sp && !a.sp_gather && dist_can_overlap(ctx) && (sp_overlap_on || sp_selftest);
             if (sp) {
                 gemm_vt(xn, D, T, blk.v1, vt, T, st, sk);  // V^T of the local tokens, dense [D][T]
                 if (overlap) {

@@ -555,50 +555,73 @@ def conv3d_full_einsum(x, weight, bias, causal=False):
     return out
 
 
-def conv3d_full(x, weight, bias, causal=False):
-    """Conv3dFull (VideoConvolution.swift:202-348): reflect pad H/W by 1, replicate pad T (1+1, or 2+0 causal), 27 taps, bias,
-    f32 accumulation. BLAS-speed form: on the channels-last PADDED grid flattened to rows [(T+2)(H+2)(W+2)][C] a tap is a constant
-    row offset, so each tap is one zero-copy `rows[off:off+n] @ W_tap` sgemm accumulated in place (beta = 1); rows that fall on
-    padding positions are computed and dropped. Same tap order (kt, kh, kw) as `conv3d_full_einsum`."""
+def _conv_taps_blas(xp, wt, bias):
+    """The tap loop shared by the BLAS-speed conv forms. xp: the PADDED input, channels last, [T + kT - 1][H + 2][W + 2][C] f32 contiguous;
+    wt: [kT][3][3][C][O] f32 contiguous. On the padded grid flattened to rows [(T+kT-1)(H+2)(W+2)][C] a tap is a constant row offset, so
+    each tap is one zero-copy `rows[off:off+n] @ W_tap` sgemm accumulated in place (beta = 1, taps in (kt, kh, kw) order); rows that fall
+    on padding positions are computed and dropped. Returns [O][T][H][W]."""
     from scipy.linalg.blas import sgemm
     global _pool
-    b, c, t, h, wd = x.shape
-    o = weight.shape[0]
-    hp, wp = h + 2, wd + 2
+    kt_n = wt.shape[0]
+    tp, hp, wp, c = xp.shape
+    t, h, wd, o = tp - kt_n + 1, hp - 2, wp - 2, wt.shape[4]
     n = (t - 1) * hp * wp + (h - 1) * wp + wd                                    # last output row + 1 on the padded grid
-    wt = np.ascontiguousarray(weight.astype(F32).transpose(2, 3, 4, 1, 0))       # [3,3,3,C,O]
-    out = np.empty((b, o, t, h, wd), F32)
+    rows = xp.reshape(-1, c)
+    acc = np.empty((t * hp * wp, o), F32)
+    acc[:] = 0.0 if bias is None else bias.astype(F32)[None, :]
+    for kt in range(kt_n):
+        for kh in range(3):
+            for kw in range(3):
+                off = (kt * hp + kh) * wp + kw
+                # acc[:n] += rows[off:off+n] @ wt[kt,kh,kw], as the column-major product acc^T += W^T @ rows^T (all three
+                # operands are Fortran-contiguous views, so the BLAS call works in place)
+                r = sgemm(1.0, wt[kt, kh, kw].T, rows[off:off + n].T, beta=1.0, c=acc[:n].T, overwrite_c=1)
+                assert np.shares_memory(r, acc)
+    a4 = acc.reshape(t, hp, wp, o)
+    out = np.empty((o, t, h, wd), F32)
     if _pool is None:
         _pool = ThreadPoolExecutor(_HOST_THREADS)
-    for bi in range(b):
-        xp = np.empty((t + 2, hp, wp, c), F32)
 
-        def fill(pf):  # padded frame pf <- source frame (replicate in T), channels last, reflect in H then W
-            src = min(max(pf - (2 if causal else 1), 0), t - 1)
-            xp[pf, 1:h + 1, 1:wd + 1] = x[bi, :, src].transpose(1, 2, 0)
+    def take(f):
+        out[:, f] = a4[f, :h, :wd].transpose(2, 0, 1)
+
+    list(_pool.map(take, range(t)))
+    return out
+
+
+def _pad_channels_last(x1, t_src, mode):
+    """[C][T][H][W] -> padded channels-last [len(t_src)][H+2][W+2][C] f32: frame i of the result is source frame t_src[i] (None = a zero
+    frame); `mode` pads H and W by one: "reflect" or "zero". Frames are filled on the thread pool."""
+    global _pool
+    c, t, h, wd = x1.shape
+    xp = np.zeros((len(t_src), h + 2, wd + 2, c), F32) if mode == "zero" else np.empty((len(t_src), h + 2, wd + 2, c), F32)
+    if _pool is None:
+        _pool = ThreadPoolExecutor(_HOST_THREADS)
+
+    def fill(pf):
+        src = t_src[pf]
+        if src is None:
+            return
+        xp[pf, 1:h + 1, 1:wd + 1] = x1[:, src].transpose(1, 2, 0)
+        if mode == "reflect":
             xp[pf, 0, 1:wd + 1] = xp[pf, 2, 1:wd + 1]
             xp[pf, h + 1, 1:wd + 1] = xp[pf, h - 1, 1:wd + 1]
             xp[pf, :, 0] = xp[pf, :, 2]
             xp[pf, :, wd + 1] = xp[pf, :, wd - 1]
 
-        list(_pool.map(fill, range(t + 2)))
-        rows = xp.reshape(-1, c)
-        acc = np.empty((t * hp * wp, o), F32)
-        acc[:] = 0.0 if bias is None else bias.astype(F32)[None, :]
-        for kt in range(3):
-            for kh in range(3):
-                for kw in range(3):
-                    off = (kt * hp + kh) * wp + kw
-                    # acc[:n] += rows[off:off+n] @ wt[kt,kh,kw], as the column-major product acc^T += W^T @ rows^T (all three
-                    # operands are Fortran-contiguous views, so the BLAS call works in place)
-                    r = sgemm(1.0, wt[kt, kh, kw].T, rows[off:off + n].T, beta=1.0, c=acc[:n].T, overwrite_c=1)
-                    assert np.shares_memory(r, acc)
-        a4 = acc.reshape(t, hp, wp, o)
+    list(_pool.map(fill, range(len(t_src))))
+    return xp
 
-        def take(f):
-            out[bi, :, f] = a4[f, :h, :wd].transpose(2, 0, 1)
 
-        list(_pool.map(take, range(t)))
+def conv3d_full(x, weight, bias, causal=False):
+    """Conv3dFull (VideoConvolution.swift:202-348): reflect pad H/W by 1, replicate pad T (1+1, or 2+0 causal), 27 taps, bias,
+    f32 accumulation. BLAS-speed form (`_conv_taps_blas`); same tap order (kt, kh, kw) as `conv3d_full_einsum`."""
+    b, c, t, h, wd = x.shape
+    wt = np.ascontiguousarray(weight.astype(F32).transpose(2, 3, 4, 1, 0))       # [3,3,3,C,O]
+    t_src = [min(max(pf - (2 if causal else 1), 0), t - 1) for pf in range(t + 2)]
+    out = np.empty((b, weight.shape[0], t, h, wd), F32)
+    for bi in range(b):
+        out[bi] = _conv_taps_blas(_pad_channels_last(x[bi], t_src, "reflect"), wt, bias)
     return out
 
 
@@ -980,23 +1003,20 @@ def quantize_dit_weights(w, bits, group=64):
 # R23: latent spatial upscaler + two-stage glue (SpatialUpscaler.swift:14-258,352-379; LTXPipeline.swift:2588-2647)
 # ---------------------------------------------------------------------------------------------------------------
 def conv_nd_zero(x, weight, bias):
-    """MLXNN.Conv3d/Conv2d with padding=1 (zeros), stride 1. x [B,C,F,H,W]; weight (O,I,3,3,3) or (O,I,3,3) (per frame)."""
+    """MLXNN.Conv3d/Conv2d with padding=1 (zeros), stride 1. x [B,C,F,H,W]; weight (O,I,3,3,3) or (O,I,3,3) (per frame).
+    BLAS-speed form (`_conv_taps_blas`, as conv3d_full; the einsum form it replaced is `conv3d_full_einsum`'s twin and was checked
+    against torch by tests/test_oracle_vs_torch.py, as this one is)."""
     b, c, t, h, w = x.shape
-    o = weight.shape[0]
     if weight.ndim == 4:
         weight = weight[:, :, None]  # kT = 1
-        pt = 0
+        t_src = list(range(t))
     else:
-        pt = 1
-    xp = np.pad(x.astype(F32), ((0, 0), (0, 0), (pt, pt), (1, 1), (1, 1)))
-    out = np.zeros((b, o, t, h, w), F32)
-    wf = weight.astype(F32)
-    for kt in range(weight.shape[2]):
-        for kh in range(3):
-            for kw in range(3):
-                patch = xp[:, :, kt:kt + t, kh:kh + h, kw:kw + w].reshape(b, c, -1)
-                out += np.einsum("oc,bcn->bon", wf[:, :, kt, kh, kw], patch, optimize=True).reshape(b, o, t, h, w)
-    return out + bias.astype(F32).reshape(1, -1, 1, 1, 1)
+        t_src = [None] + list(range(t)) + [None]
+    wt = np.ascontiguousarray(weight.astype(F32).transpose(2, 3, 4, 1, 0))
+    out = np.empty((b, weight.shape[0], t, h, w), F32)
+    for bi in range(b):
+        out[bi] = _conv_taps_blas(_pad_channels_last(x[bi].astype(F32, copy=False), t_src, "zero"), wt, bias)
+    return out
 
 
 def group_norm3d(x, weight, bias, groups=32, eps=1e-5):
@@ -1293,23 +1313,13 @@ ENC_FACTORS = ((1, 2, 2), (2, 1, 1), (2, 2, 2), (2, 2, 2))
 
 def conv3d_causal_zero(x, weight, bias, causal=True):
     """CausalConv3dFull with spatialPaddingMode .zeros (VideoConvolution.swift:238-347): zero pad H/W by 1; temporal pad
-    = first frame twice in front (causal) or replicate 1+1."""
+    = first frame twice in front (causal) or replicate 1+1. BLAS-speed form (`_conv_taps_blas`)."""
     b, c, t, h, wd = x.shape
-    o = weight.shape[0]
-    xp = np.pad(x.astype(F32), ((0, 0), (0, 0), (0, 0), (1, 1), (1, 1)))
-    if causal:
-        xp = np.concatenate([xp[:, :, :1]] * 2 + [xp], axis=2)
-    else:
-        xp = np.concatenate([xp[:, :, :1], xp, xp[:, :, -1:]], axis=2)
-    out = np.zeros((b, o, t, h, wd), F32)
-    wf = weight.astype(F32)
-    for kt in range(3):
-        for kh in range(3):
-            for kw in range(3):
-                patch = xp[:, :, kt:kt + t, kh:kh + h, kw:kw + wd].reshape(b, c, -1)
-                out += np.einsum("oc,bcn->bon", wf[:, :, kt, kh, kw], patch, optimize=True).reshape(b, o, t, h, wd)
-    if bias is not None:
-        out += bias.astype(F32).reshape(1, -1, 1, 1, 1)
+    t_src = [min(max(pf - (2 if causal else 1), 0), t - 1) for pf in range(t + 2)]
+    wt = np.ascontiguousarray(weight.astype(F32).transpose(2, 3, 4, 1, 0))
+    out = np.empty((b, weight.shape[0], t, h, wd), F32)
+    for bi in range(b):
+        out[bi] = _conv_taps_blas(_pad_channels_last(x[bi].astype(F32, copy=False), t_src, "zero"), wt, bias)
     return out
 
 

@@ -55,6 +55,16 @@ def test_extra_legs_guard_fails_the_run_on_hang_and_error():
     assert json.loads(r.stdout.strip().splitlines()[-1])["extra_legs_status"] == "ok"
 
 
+def test_one_gpu_rehearsal_is_refused_for_modes_that_open_rccl_groups():
+    """--rehearse-one-gpu puts every rank on cuda:0; the sharded modes and the extra legs would bootstrap RCCL groups with two
+    ranks on one device. They must be refused before any rank starts."""
+    for extra in (["--mode", "sp"], ["--mode", "cfg-pair"], ["--mode", "vae-tiles"], ["--extra-legs"]):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse-one-gpu"] + extra, capture_output=True, text=True,
+                           env=_clean_env(), timeout=120)
+        assert r.returncode != 0 and "replica path only" in r.stderr, (extra, r.returncode, r.stderr[-300:])
+        assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 @pytest.mark.gpu
 def test_two_rank_replica_line_rehearsed_on_one_gpu():
     """The N > 1 code of bench.py (launcher, rank count by all-reduce, context broadcast, barrier-bracketed timing, MAX over ranks,

@@ -7,7 +7,8 @@ reference architecture (LTXConfig.swift:83-177: 48 layers, 32 heads x 128, capti
 
   config 2 shape  D=4096, 2 layers, T=1536 (4x16x24), S=1024           forward vs oracle: rel-L2 <= 2e-2, cos >= 0.9995
   config 1        D=4096, ALL 48 layers, T=128 (2x8x8: 256x256x9)       forward vs oracle: rel-L2 <= 3e-2, cos >= 0.999
-                  (48 blocks amplify the per-block bf16 deviation; this launch shape exercises the split-K path)
+                  (48 blocks amplify the per-block bf16 deviation; this launch shape exercises the split-K path) - lives in
+                  tests/test_depth_parity_gpu.py since round 4, where it shares the host copy of the 48 layers' weights
   end to end      D=4096, 2 layers, distilled 8-step schedule, T=128    final latent: rel-L2 <= 1e-2, cos >= 0.999
   config 4        T=6144 (4x32x48) 48-layer forward bit-repeatable; latent upscaler at [1,128,4,16,24] (mid 1024) vs oracle
   config 5        T=9984 (26x16x24) 48-layer forward bit-repeatable; qint8 model vs bf16 model at full size (<= 3e-2, the
@@ -106,26 +107,6 @@ def test_full_width_two_blocks_config2_shape_vs_oracle(ltx, oracle, two_layer):
     r, c = rel_l2(got, ref), _cos(got, ref)
     print(f"full width, 2 blocks, T={T}, S={S}: rel-L2 {r:.3e}, cos {c:.6f}")
     assert np.isfinite(got).all() and r <= 2e-2 and c >= 0.9995, (r, c)
-
-
-def test_full_depth_48_layers_config1_vs_oracle(ltx, oracle, full48):
-    """BASELINE configs[0]: 256x256x9 -> latent 2x8x8 = 128 tokens through ALL 48 blocks of the reference architecture."""
-    ctx, cfg = full48
-    ocfg = oracle.DiTConfig()
-    w = DeviceWeights(ctx, oracle.dit_param_shapes(ocfg))
-    assert ltx.latent_shape(256, 256, 9) == (2, 8, 8)
-    F, H, W, S = 2, 8, 8, 256
-    T = F * H * W
-    rng = np.random.default_rng(1)
-    lat = oracle.bf16_round(rng.standard_normal((1, T, 128)).astype(np.float32))
-    cx = oracle.bf16_round(rng.standard_normal((1, S, 3840)).astype(np.float32))
-    got = _forward(ctx, lat, cx, 0.725, None, F, H, W)
-    again = _forward(ctx, lat, cx, 0.725, None, F, H, W)
-    assert np.array_equal(got, again)  # the split-K path of this launch shape is deterministic
-    ref = oracle.dit_forward(w, ocfg, lat, cx, np.array([0.725], np.float32), None, F, H, W)
-    r, c = rel_l2(got, ref), _cos(got, ref)
-    print(f"full width, 48 blocks, T={T}, S={S}: rel-L2 {r:.3e}, cos {c:.6f}")
-    assert np.isfinite(got).all() and r <= 3e-2 and c >= 0.999, (r, c)
 
 
 def test_full_width_eight_step_denoise_vs_oracle(ltx, oracle, two_layer):

@@ -82,6 +82,29 @@ def test_conv3d_blas_form_equals_the_einsum_form(oracle, shape, cout, causal):
     assert np.array_equal(oracle.conv3d_full(x, w, None, causal), oracle.conv3d_full(x, w, np.zeros(cout, np.float32), causal))
 
 
+@pytest.mark.parametrize("per_frame", [False, True])
+def test_conv_nd_zero_and_causal_zero_vs_torch(oracle, per_frame):
+    """The zero-padded convs of the latent upscaler (SpatialUpscaler.swift:78-92,139-145) and of the VAE encoder
+    (VideoConvolution.swift:238-347), BLAS-speed forms, against torch conv3d / conv2d."""
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 6, 3, 5, 7)).astype(np.float32)
+    b = rng.standard_normal(10).astype(np.float32)
+    if per_frame:
+        w = rng.standard_normal((10, 6, 3, 3)).astype(np.float32)
+        ref = torch.stack([Fn.conv2d(torch.from_numpy(x[:, :, f]), torch.from_numpy(w), torch.from_numpy(b), padding=1) for f in range(3)], 2).numpy()
+        assert np.allclose(oracle.conv_nd_zero(x, w, b), ref, atol=1e-4)
+        return
+    w = rng.standard_normal((10, 6, 3, 3, 3)).astype(np.float32)
+    ref = Fn.conv3d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), padding=1).numpy()
+    assert np.allclose(oracle.conv_nd_zero(x, w, b), ref, atol=1e-4)
+    for causal in (True, False):
+        xt = torch.from_numpy(x)
+        xp = Fn.pad(xt, (1, 1, 1, 1, 0, 0))
+        xp = torch.cat([xp[:, :, :1]] * 2 + [xp], 2) if causal else torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], 2)
+        ref = Fn.conv3d(xp, torch.from_numpy(w), torch.from_numpy(b)).numpy()
+        assert np.allclose(oracle.conv3d_causal_zero(x, w, b, causal), ref, atol=1e-4)
+
+
 def test_depth_to_space_and_unpatchify_index_maps(oracle):
     # D2S: out[c, 2t+dt, 2h+dh, 2w+dw] = in[((c*2+dt)*2+dh)*2+dw, t, h, w]  (VideoDecoder.swift:201-213)
     x = np.arange(16 * 2 * 3 * 4, dtype=np.float32).reshape(1, 16, 2, 3, 4)
