@@ -36,6 +36,9 @@ LTX_DEVFN int reflect_idx(int i, int n) {
     return (i >= n) ? (2 * n - 2 - i) : i;
 }
 LTX_DEVFN int clamp_idx(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+// x / d == __umulhi(x, magic_u32(d)) for every x with x * d < 2^32 (d >= 2): the runtime divisors of the conv index arithmetic (W, H,
+// slab rows) as multiply-high constants - an integer division by a runtime value is ~35 VALU instructions, and a tile needs dozens
+LTX_DEVFN unsigned magic_u32(int d) { return (unsigned)((0x100000000ull + (unsigned long long)(d - 1)) / (unsigned long long)d); }
 
 // compile-time loop: the body gets an integral_constant, so accumulator arrays are only ever indexed with constants
 // (a `#pragma unroll` that the optimiser declines leaves a runtime index and demotes the array to scratch memory)
@@ -340,6 +343,78 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
                         }
                     }
                 }
+            }
+        });
+        return;
+    }
+    // ---- depth-to-space store of the VAE upsampler (d2s == 1), interior columns, a wave's columns inside ONE sub-position: the
+    // general path below spends ~25 us per tile here (three runtime divisions per 4-wide chunk, four dependent gather loads of the tiled
+    // D2S residual, nothing prefetched - tools/ubench/conv_stamps.hip, CONV_D2S=1: epilogue 32.5 us against 7.2 us of a plain store).
+    // Here the column part (sub-position, channel, residual column) is per-lane constant, a row splits into (frame, y, x) with two
+    // multiply-high forms, and the residual gathers of slab mi + 1 are requested before slab mi is transposed.
+    if (ep.d2s == 1 && n0 + BN <= g.N && ep.out_f32 && !ep.out_bf16 && !ep.bias_m && ep.act == LTX_ACT_NONE && !ep.round_bf16 &&
+        ((g.N >> 3) % WN) == 0 && ((g.geom.C >> 3) & 3) == 0 && (long)g.M * g.geom.W < (1L << 32) &&
+        (long)g.geom.F * g.geom.H * g.geom.H < (1L << 32)) {
+        constexpr int NIT = (16 * LPR) / 64, RPI = 64 / LPR;
+        const int cout = g.N >> 3, cd2s = g.geom.C >> 3;
+        const int H = g.geom.H, W = g.geom.W;
+        const unsigned mg_w = magic_u32(W), mg_h = magic_u32(H);
+        const int gn = n0 + wc * WN + (lane % LPR) * 4;
+        const int sub = gn / cout, c = gn - sub * cout;  // the wave's 64 columns share `sub` (cout is a multiple of WN)
+        const int dt = sub >> 2, dh = (sub >> 1) & 1, dw = sub & 1;
+        const int cm = (cd2s & (cd2s - 1)) == 0 ? (c & (cd2s - 1)) : (c % cd2s);
+        // (if / else on VALUES: a ?: between `pre->bias[0]` and a global load becomes a select between two pointers, and the kernel's
+        // ResidualTile then cannot be promoted to registers - the whole struct went to scratch, in every kernel that shares this function)
+        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ep.bias_n) bias = *(const f32x4*)(ep.bias_n + gn);
+        const float* rcol = ep.resid_src ? ep.resid_src + cm * 8 + sub : nullptr;  // + gm * ld_resid + 8 e
+        float* ocol = ep.out_f32 + c;
+        f32x4 rs[2][NIT];
+        long orow[2][NIT];  // -1: nothing to store (row past M, or the dropped first frame)
+        auto fetch = [&](auto mi_c, auto buf_c) {
+            constexpr int mi = decltype(mi_c)::value, buf = decltype(buf_c)::value;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int gm = m0 + wr * WM + mi * 16 + it * RPI + lane / LPR;
+                const int gmc = gm < g.M ? gm : g.M - 1;
+                const int rowi = (int)__umulhi((unsigned)gmc, mg_w);  // image row over all frames
+                const int x = gmc - rowi * W;
+                const int f = (int)__umulhi((unsigned)rowi, mg_h);
+                const int y = rowi - f * H;
+                const int fo = 2 * f + dt - 1;  // first frame after D2S is dropped
+                orow[buf][it] = (gm < g.M && fo >= 0) ? ((long)fo * (2 * H) + (2 * y + dh)) * (2 * W) + (2 * x + dw) : -1;
+                if (rcol) {
+                    const float* rp = rcol + (long)gmc * ep.ld_resid;
+                    rs[buf][it] = f32x4{rp[0], rp[8], rp[16], rp[24]};
+                } else {
+                    rs[buf][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        };
+        fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        static_for<0, MI>([&](auto mi_c) {
+            constexpr int mi = decltype(mi_c)::value;
+            constexpr int buf = mi & 1;
+            if constexpr (mi + 1 < MI) fetch(std::integral_constant<int, mi + 1>{}, std::integral_constant<int, (mi + 1) & 1>{});
+            if constexpr (mi == (MI >= 2 ? MI - 2 : 0)) hook();  // the last residual gather has just been requested
+            if constexpr (SCR) {
+                get(mi_c, scr);
+            } else {
+                f32x4 slab[NI];
+                get(mi_c, slab);
+                static_for<0, NI>([&](auto ni_c) {
+                    constexpr int ni = decltype(ni_c)::value;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = slab[ni][r];
+                });
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = it * RPI + lane / LPR;
+                f32x4 v = *(const f32x4*)(scr + row * WN + (lane % LPR) * 4);
+                v += bias;
+                v += rs[buf][it];
+                if (orow[buf][it] >= 0) *(f32x4*)(ocol + orow[buf][it] * ep.ld_f32) = v;
             }
         });
         return;

@@ -17,7 +17,7 @@ ProfRec* Profiler::begin(int, double, hipStream_t) { return nullptr; }
 void Profiler::end(ProfRec*, hipStream_t) {}
 
 int main() {
-    const int F = getenv("CONV_F") ? atoi(getenv("CONV_F")) : 25, H = 128, W = 192, C = getenv("CONV_C") ? atoi(getenv("CONV_C")) : 128;
+    const int F = getenv("CONV_F") ? atoi(getenv("CONV_F")) : 25, H = getenv("CONV_H") ? atoi(getenv("CONV_H")) : 128, W = getenv("CONV_W") ? atoi(getenv("CONV_W")) : 192, C = getenv("CONV_C") ? atoi(getenv("CONV_C")) : 128;
     const int N = getenv("CONV_N") ? atoi(getenv("CONV_N")) : C;
     const long P = (long)F * H * W;
     std::vector<bf16_t> hx((size_t)P * C), hw((size_t)N * 27 * C);
@@ -26,11 +26,11 @@ int main() {
     bf16_t *x, *w, *pn;
     float *stream, *vec;
     (void)hipMalloc(&x, hx.size() * 2); (void)hipMalloc(&w, hw.size() * 2); (void)hipMalloc(&pn, (size_t)P * N * 2);
-    (void)hipMalloc(&stream, (size_t)P * N * 4); (void)hipMalloc(&vec, 4 * 1024 * 4);
+    (void)hipMalloc(&stream, (size_t)P * (N > C ? N : C) * 4); (void)hipMalloc(&vec, 4 * 4096 * 4);
     (void)hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
     (void)hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
-    (void)hipMemset(stream, 0, (size_t)P * N * 4);
-    std::vector<float> hv(4 * 1024, 1.0f);
+    (void)hipMemset(stream, 0, (size_t)P * (N > C ? N : C) * 4);
+    std::vector<float> hv(4 * 4096, 1.0f);
     (void)hipMemcpy(vec, hv.data(), hv.size() * 4, hipMemcpyHostToDevice);
     GemmArgs g;
     g.A = x; g.B = w; g.ldb = 27L * C; g.M = (int)P; g.N = N; g.K = 27 * C; g.conv = 1;
@@ -43,6 +43,14 @@ int main() {
     } else {
         g.ep.out_f32 = stream; g.ep.ld_f32 = N;
     }
+    float* d2s_out = nullptr;
+    if (getenv("CONV_D2S")) {  // the upsampler conv: N = 4 C channels, depth-to-space store with first-frame drop + tiled D2S residual of the input stream
+        (void)hipMalloc(&d2s_out, (size_t)(2 * F - 1) * 2 * H * 2 * W * (C / 2) * 4);
+        g.ep = GemmEpilogue{};
+        g.ep.bias_n = vec;
+        g.ep.out_f32 = d2s_out; g.ep.ld_f32 = C / 2; g.ep.d2s = 1; g.ep.resid_src = stream; g.ep.ld_resid = C;
+        g.geom.blk_rg = 0;
+    }
     const int cfg = N <= 64 ? 27 : 21;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -54,6 +62,7 @@ int main() {
     (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const int tiles = (int)((P + 191) / 192) * ((N + 127) / 128);
+    if (tiles > 16383) printf("(more tiles than stamp slots: statistics over the first 16383)\n");
     printf("conv %d -> %d at %dx%dx%d: %d tiles, %.1f us per launch, %.0f TFLOP/s\n", C, N, F, H, W, tiles, ms * 1e3 / reps, 2.0 * P * N * 27 * C / (ms / reps * 1e-3) / 1e12);
     static unsigned long long st[16384][10];
     (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_conv_stamps), sizeof(st));
