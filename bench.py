@@ -57,18 +57,21 @@ PEAK_BF16_TFLOPS = 2500.0
 # Reported beside `frac` for context only; `frac` stays priced against the 2.5 PFLOP/s headline.
 SUSTAINED_BF16_TFLOPS = 2000.0
 HBM_PEAK_GBPS = 8000.0
-TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
-VAE_TRAFFIC_FILES = ("r03_pmc_traffic_vae_v2.json", "r03_pmc_traffic_vae.json", "r02_pmc_traffic_vae.json")
+# (file, key): since round 4 one collection carries the dense GEMM launches ("gemm_all") and the VAE conv launches ("conv_all") side by side
+TRAFFIC_FILES = (("r04_pmc_traffic.json", "gemm_all"), ("r03_pmc_traffic.json", "gemm_all"), ("r02_pmc_traffic_v2.json", "gemm_all"),
+                 ("r02_pmc_traffic.json", "gemm_all"), ("r01_pmc_traffic.json", "gemm_all"))
+VAE_TRAFFIC_FILES = (("r04_pmc_traffic.json", "conv_all"), ("r03_pmc_traffic_vae_v2.json", "gemm_all"), ("r03_pmc_traffic_vae.json", "gemm_all"),
+                     ("r02_pmc_traffic_vae.json", "gemm_all"))
 
 
 def pmc_traffic(files=None):
     """HBM-side bytes per GEMM launch (mean over all GEMM launches of this workload) and the file they come from. PMC counters
     cannot be read from inside the process: they come from two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE) of this
     same command, corrected as MI355X_MICROARCH.md prescribes (KiB units, FETCH_SIZE x2 on gfx950) by tools/pmc_traffic.py."""
-    for name in (files or TRAFFIC_FILES):
+    for name, key in (files or TRAFFIC_FILES):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return round(json.load(f)["gemm_all"]["hbm_bytes_per_launch"]), "profiles/" + name
+                return round(json.load(f)[key]["hbm_bytes_per_launch"]), "profiles/" + name
         except (OSError, KeyError, ValueError):
             continue
     return None, None

@@ -419,6 +419,54 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
         });
         return;
     }
+    // ---- the decoder's final un-patchify store (d2s == 3; conv_out: 48 of the tile's 64 columns exist): the same treatment - the
+    // column part (pixel row b, offset inside its 12 floats) is per-lane constant, rows split with two multiply-high forms
+    if (ep.d2s == 3 && (g.N & 3) == 0 && ep.out_f32 && !ep.out_bf16 && !ep.bias_m && ep.act == LTX_ACT_NONE && !ep.round_bf16 && !ep.resid &&
+        (long)g.M * g.geom.W < (1L << 32) && (long)g.geom.F * g.geom.H * g.geom.H < (1L << 32)) {
+        constexpr int NIT = (16 * LPR) / 64, RPI = 64 / LPR;
+        hook();
+        const int H = g.geom.H, W = g.geom.W;
+        const unsigned mg_w = magic_u32(W), mg_h = magic_u32(H);
+        const int gn = n0 + wc * WN + (lane % LPR) * 4;
+        const bool col_ok = gn < g.N;  // N % 4 == 0: a 4-wide chunk exists entirely or not at all
+        const int b = gn / 12, oc = gn - 12 * b;
+        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ep.bias_n && col_ok) bias = *(const f32x4*)(ep.bias_n + gn);
+        static_for<0, MI>([&](auto mi_c) {
+            constexpr int mi = decltype(mi_c)::value;
+            if constexpr (SCR) {
+                get(mi_c, scr);
+            } else {
+                f32x4 slab[NI];
+                get(mi_c, slab);
+                static_for<0, NI>([&](auto ni_c) {
+                    constexpr int ni = decltype(ni_c)::value;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = slab[ni][r];
+                });
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = it * RPI + lane / LPR;
+                const int gm = m0 + wr * WM + mi * 16 + row;
+                f32x4 v = *(const f32x4*)(scr + row * WN + (lane % LPR) * 4);
+                v += bias;
+                if (ep.clip01) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf((v[e] + 1.0f) * 0.5f, 0.f), 1.f);
+                }
+                if (gm < g.M && col_ok) {
+                    const int rowi = (int)__umulhi((unsigned)gm, mg_w);
+                    const int x = gm - rowi * W;
+                    const int f = (int)__umulhi((unsigned)rowi, mg_h);
+                    const int y = rowi - f * H;
+                    const long orow = (((long)f * (4 * H) + (4 * y + b)) * (4 * W) + 4 * x) * 3;  // ld_f32 is 1
+                    *(f32x4*)(ep.out_f32 + orow * ep.ld_f32 + oc) = v;
+                }
+            }
+        });
+        return;
+    }
     hook();
     static_for<0, MI>([&](auto mi_c) {
         constexpr int mi = decltype(mi_c)::value;

@@ -51,21 +51,30 @@ def main():
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
     out = {"unit": "bytes per launch (mean over the launches of the run)", "corrections": "FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1", "kernels": {}}
-    tot_f = tot_w = 0.0
-    n_gemm = 0
+    tot_f = tot_w = conv_f = conv_w = 0.0
+    n_gemm = n_conv = 0
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, [])
         w = write.get(k, [])
         fb = 2.0 * 1024.0 * (sum(f) / len(f)) if f else 0.0
         wb = 1024.0 * (sum(w) / len(w)) if w else 0.0
         out["kernels"][k] = {"launches": max(len(f), len(w)), "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
-        if k.startswith("gemm_bf16_kernel") or k.startswith("conv3d_halo_kernel"):
+        m = re.search(r"ELb([01])E", k)  # first bool template argument of gemm_bf16_kernel_v2 = CONV
+        is_conv = k.startswith("conv3d_halo_kernel") or (k.startswith("gemm_bf16_kernel_v2") and m is not None and m.group(1) == "1")
+        if is_conv:
+            conv_f += 2.0 * 1024.0 * sum(f)
+            conv_w += 1024.0 * sum(w)
+            n_conv += max(len(f), len(w))
+        elif k.startswith("gemm_bf16_kernel"):
             tot_f += 2.0 * 1024.0 * sum(f)
             tot_w += 1024.0 * sum(w)
             n_gemm += max(len(f), len(w))
-    if n_gemm:
+    if n_gemm:  # the dense (DiT) GEMM launches: bench.py's roofline.traffic
         out["gemm_all"] = {"launches": n_gemm, "hbm_bytes_per_launch": (tot_f + tot_w) / n_gemm,
                            "fetch_bytes_per_launch": tot_f / n_gemm, "write_bytes_per_launch": tot_w / n_gemm}
+    if n_conv:  # the implicit-GEMM conv launches (VAE): bench.py's vae.roofline.traffic
+        out["conv_all"] = {"launches": n_conv, "hbm_bytes_per_launch": (conv_f + conv_w) / n_conv,
+                           "fetch_bytes_per_launch": conv_f / n_conv, "write_bytes_per_launch": conv_w / n_conv}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out.get("gemm_all", {})))
 
