@@ -410,6 +410,11 @@ int ltx_vae_decode_tile_dev(ltx_ctx* ctx, const float* latent, int F, int H, int
  * C = channels of up-block group `group` (0..3: 1024, 512, 256, 128), block 0..4. Runs the very kernels and fused epilogues of the
  * decode, so a host (or a parity test) can check one stage at full resolution without a full-size reference decode. DEVICE pointer. */
 int ltx_vae_res_block_dev(ltx_ctx* ctx, int group, int block, float* x, int F, int H, int W);
+/* One VAEDepthToSpaceUpsample3d of the loaded decoder (VideoDecoder.swift:201-251: conv C -> 4C, depth-to-space (2,2,2), drop the first
+ * frame, + the channel-tiled depth-to-space of the input) - the stage behind up-block group `group` (0..2: 1024, 512, 256 channels in,
+ * half of that out) - on a caller-supplied channels-last f32 stream x [F][H][W][C] -> out [2F-1][2H][2W][C/2]. Runs the decode's own
+ * conv kernel and fused depth-to-space epilogue, so one upsampler can be checked at full resolution. DEVICE pointers. */
+int ltx_vae_upsample_dev(ltx_ctx* ctx, int group, const float* x, int F, int H, int W, float* out);
 /* Blend raw tiles in tile order over 8*overlap frames (VideoDecoder.swift:561-592), then clip((x+1)/2, 0, 1) (:501-505).
  * tiles: HOST array of n_tiles DEVICE pointers, tile_frames their frame counts; tiles[0] may be frames_out. */
 int ltx_vae_blend_tiles_dev(ltx_ctx* ctx, const float* const* tiles, const int* tile_frames, int n_tiles, int overlap, int H,

@@ -436,6 +436,10 @@ class Context:
         """One res-block of the loaded decoder on the channels-last f32 stream x [F][H][W][C], in place."""
         self._ck(lib.ltx_vae_res_block_dev(self._h, group, block, _ptr(x), F, H, W))
 
+    def vae_upsample_dev(self, group, x, F, H, W, out):
+        """One depth-to-space upsampler of the loaded decoder: x [F][H][W][C] f32 -> out [2F-1][2H][2W][C/2] f32 (device tensors)."""
+        self._ck(lib.ltx_vae_upsample_dev(self._h, group, _ptr(x), F, H, W, _ptr(out)))
+
     def vae_blend_tiles_dev(self, tiles, tile_frames, overlap, H, W, frames):
         n = C.c_int()
         ptrs = (C.c_void_p * len(tiles))(*[t.data_ptr() for t in tiles])

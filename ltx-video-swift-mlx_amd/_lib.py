@@ -112,6 +112,7 @@ SIGNATURES = {
     "ltx_dit_memory_info": (_i, [_vp, C.POINTER(_l), C.POINTER(_l), C.POINTER(_l), C.POINTER(_l)]),
     "ltx_op_gemm_q8": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _l]),
     "ltx_vae_res_block_dev": (_i, [_vp, _i, _i, _vp, _i, _i, _i]),
+    "ltx_vae_upsample_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "ltx_vae_blend_tiles_dev": (_i, [_vp, C.POINTER(_vp), _ip, _i, _i, _i, _i, _vp, _l, _ip]),
     "ltx_vae_decode_sharded_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _vp, _l, _ip]),
     "ltx_vae_decode_gathered_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp, _l, _ip]),

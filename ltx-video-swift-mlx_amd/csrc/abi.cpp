@@ -683,6 +683,11 @@ int ltx_vae_res_block_dev(ltx_ctx* ctx, int group, int block, float* x, int F, i
     return guarded(ctx, [&] { vae_res_block(ctx, need_vae(ctx), group, block, x, F, H, W); });
 }
 
+int ltx_vae_upsample_dev(ltx_ctx* ctx, int group, const float* x, int F, int H, int W, float* out) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] { vae_upsample(ctx, need_vae(ctx), group, x, F, H, W, out); });
+}
+
 int ltx_vae_blend_tiles_dev(ltx_ctx* ctx, const float* const* tiles, const int* tile_frames, int n_tiles, int overlap, int H,
                             int W, float* frames_out, long frames_cap, int* n_frames_out) {
     if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;

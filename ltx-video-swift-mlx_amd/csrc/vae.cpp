@@ -493,6 +493,25 @@ void vae_res_block(ltx_ctx* ctx, VaeModel* m, int group, int block, float* x, in
     HIP_CHECK(hipStreamSynchronize(st));  // the scratch buffers above go out of scope
 }
 
+void vae_upsample(ltx_ctx* ctx, VaeModel* m, int group, const float* x, int F, int H, int W, float* out) {
+    LTX_REQUIRE(group >= 0 && group < 3, "vae_upsample: group %d (0..2)", group);
+    LTX_REQUIRE(x && out && F >= 1 && H >= 2 && W >= 2, "vae_upsample: bad arguments (F=%d H=%d W=%d)", F, H, W);
+    hipStream_t st = ctx->stream;
+    const int C = m->groups[group].C;
+    const Dims d{F, H, W};
+    DevBuf hb;
+    hb.ensure((size_t)d.P() * C * 2);
+    launch_cast_f32_bf16(x, hb.as<bf16_t>(), d.P() * C, st);  // the conv reads the bf16 copy of the stream, as in the decode
+    GemmEpilogue e;
+    e.out_f32 = out;
+    e.ld_f32 = C / 2;
+    e.d2s = 1;
+    e.resid_src = x;
+    e.ld_resid = C;
+    conv3d(hb.as<bf16_t>(), d, m->up[group], e, st);
+    HIP_CHECK(hipStreamSynchronize(st));  // the scratch buffer above goes out of scope
+}
+
 int vae_blend_tiles(ltx_ctx* ctx, const float* const* tiles, const int* tile_frames, int n_tiles, int overlap, int H, int W, float* frames,
                     long frames_cap) {
     LTX_REQUIRE(tiles && tile_frames && n_tiles >= 1 && frames && overlap >= 0, "vae_blend_tiles: bad arguments");

@@ -92,6 +92,8 @@ int vae_decode_tile(ltx_ctx* ctx, VaeModel* m, const VaeDecodeArgs& a, int tile_
 // One VAEResBlock3d of the loaded decoder (VideoDecoder.swift:75-131; no timestep conditioning) on a caller-supplied channels-last
 // f32 stream x [F][H][W][C] (device, in place), C = channels of `group`; the kernels and epilogues the decode itself runs.
 void vae_res_block(ltx_ctx* ctx, VaeModel* m, int group, int block, float* x, int F, int H, int W);
+// one VAEDepthToSpaceUpsample3d of the loaded decoder (the stage behind up-block group `group`, 0..2) on a caller-supplied stream
+void vae_upsample(ltx_ctx* ctx, VaeModel* m, int group, const float* x, int F, int H, int W, float* out);
 // Blend raw tiles in tile order over 8*overlap frames, then (x+1)/2 clipped to [0,1] (VideoDecoder.swift:561-592, :501-505).
 // tiles[i] (n_i, 32H, 32W, 3) device f32; tiles[0] may alias `frames`. Returns the blended frame count.
 int vae_blend_tiles(ltx_ctx* ctx, const float* const* tiles, const int* tile_frames, int n_tiles, int overlap, int H, int W, float* frames,
