@@ -152,11 +152,13 @@ def cpu_baseline_vae(F, H, W, budget_s=150.0):
     t0 = time.perf_counter()
     frames = o.decode_video(w, lat)
     el = time.perf_counter() - t0
-    return {"decode_ms": round(1e3 * el, 1), "extrapolated": False, "cores": min(ncores, nthreads), "host_cores": ncores,
-            "blas_threads": nthreads, "tflops": round(vae_flops(F, H, W) / el / 1e12, 3),
+    used = max(o._CONV_BLAS_THREADS, o._HOST_THREADS)
+    return {"decode_ms": round(1e3 * el, 1), "extrapolated": False, "cores": min(ncores, used), "host_cores": ncores,
+            "blas_threads": o._CONV_BLAS_THREADS, "pool_threads": o._HOST_THREADS, "tflops": round(vae_flops(F, H, W) / el / 1e12, 3),
             "unit": f"ms per whole decode of the {F}x{H}x{W} latent",
             "sample": f"ONE whole oracle.decode_video of the {F}x{H}x{W} latent -> {frames.shape[0]}x{frames.shape[1]}x{frames.shape[2]} "
-                      f"frames ({vae_flops(F, H, W) / 1e12:.2f} TFLOP over 42 convs) in {el:.1f} s: numpy f32, {nthreads} BLAS threads + "
+                      f"frames ({vae_flops(F, H, W) / 1e12:.2f} TFLOP over 42 convs) in {el:.1f} s: numpy f32, one sgemm per conv tap on "
+                      f"{o._CONV_BLAS_THREADS} BLAS threads (the fastest setting for that shape on a 256-core host, tools/host_blas_probe.py) + "
                       f"{o._HOST_THREADS} threads for the position-wise passes, {ncores} schedulable host cores"}
 
 
@@ -214,7 +216,10 @@ def cpu_baseline(T, S, F, H, W, budget_s=300.0):
     t0 = time.perf_counter()
     o.transformer_block(wc, 0, x, ctxp, temb, cfg, rope, None)
     per_block = time.perf_counter() - t0
-    common = {"unit": "steps/s", "cores": min(ncores, nthreads), "host_cores": ncores, "blas_threads": nthreads, "kind": "port"}
+    used = max(o._DIT_BLAS_THREADS, o._HOST_THREADS)
+    nthreads = o._DIT_BLAS_THREADS
+    common = {"unit": "steps/s", "cores": min(ncores, used), "host_cores": ncores, "blas_threads": o._DIT_BLAS_THREADS,
+              "pool_threads": o._HOST_THREADS, "kind": "port"}
     if per_block * 48 > budget_s:
         nblk = max(1, int(budget_s / 4 / per_block))
         t0 = time.perf_counter()
@@ -232,7 +237,9 @@ def cpu_baseline(T, S, F, H, W, budget_s=300.0):
                 tflops=round(dit_flops_per_step(T, S) / el / 1e12, 3),
                 sample=f"ONE whole denoise step of the 768x512x25 workload through oracle.denoise (T={T}, S={S}, D=4096, all 48 blocks, "
                        f"{dit_flops_per_step(T, S) / 1e12:.1f} TFLOP incl. the per-step text K/V the reference recomputes) in {el:.1f} s of "
-                       f"numpy/BLAS f32 on {nthreads} BLAS threads ({ncores} schedulable host cores); block weights cycle through "
+                       f"numpy/BLAS f32 on {nthreads} BLAS threads (numpy's OpenBLAS is fastest there at these shapes: 3.4 TFLOP/s against 1.4 "
+                       f"with its default 64, tools/host_blas_probe.py) + {o._HOST_THREADS} threads for the row-wise passes ({ncores} "
+                       f"schedulable host cores); block weights cycle through "
                        f"{ncycle} distinct sets (time does not depend on the values)")
 
 

@@ -30,17 +30,51 @@ F32 = np.float32
 # not depend on it: `_pmap` only ever splits an axis along which `fn` is position-wise.
 _HOST_THREADS = max(1, min(32, int(os.environ.get("LTX_ORACLE_THREADS", os.cpu_count() or 1))))
 _pool = None
+# BLAS threads of the DiT's dense products. numpy's bundled OpenBLAS starts 64 threads on a many-core host and is 2.5x SLOWER with them
+# than with 16 at these shapes (GPU box, 256 cores: 1536 x 4096 x 4096 f32 at 1.4 TFLOP/s with 64 threads, 3.4 with 16, 5.1 with 32 -
+# tools/host_blas_probe.py); the conv path's one large sgemm per tap is fastest at the library default and is left alone.
+_DIT_BLAS_THREADS = max(1, min(int(os.environ.get("LTX_ORACLE_BLAS_THREADS", 16)), os.cpu_count() or 1))
+_CONV_BLAS_THREADS = max(1, min(int(os.environ.get("LTX_ORACLE_CONV_BLAS_THREADS", 64)), os.cpu_count() or 1))
+try:
+    from threadpoolctl import ThreadpoolController as _TPC
+    _tpc = None
+
+    def _dit_blas():
+        global _tpc
+        if _tpc is None:
+            _tpc = _TPC()
+        return _tpc.limit(limits=_DIT_BLAS_THREADS, user_api="blas")
+
+    def _conv_blas():
+        """the conv path's one tall sgemm per tap: scipy's OpenBLAS starts a thread per core (256 on the GPU box: 0.7 TFLOP/s on the
+        128-channel tap shape) and is fastest with 64 (5.7 TFLOP/s; tools/host_blas_probe.py)"""
+        global _tpc
+        if _tpc is None:
+            _tpc = _TPC()
+        return _tpc.limit(limits=_CONV_BLAS_THREADS, user_api="blas")
+except Exception:  # noqa: BLE001 - threadpoolctl missing: the library default
+    import contextlib
+
+    def _dit_blas():
+        return contextlib.nullcontext()
+
+    def _conv_blas():
+        return contextlib.nullcontext()
 _in_worker = threading.local()  # a slab function that itself calls `_pmap` runs that inner call inline (no nested submission)
 
 
-def _pmap(fn, x, axis, out_dtype=F32):
+_PMAP_MIN = 1 << 22  # elements below which a pass runs inline (tests lower it to exercise the slab path on small inputs)
+
+
+def _pmap(fn, x, axis, out_dtype=F32, with_slice=False):
     """out = fn(x), computed slab by slab along `axis` on a thread pool. `fn` must map a slab to the same slab of the result
-    (same shape), i.e. be position-wise along `axis`. Small inputs run inline."""
+    (same shape), i.e. be position-wise along `axis`; with_slice: fn(slab, slice) also gets the slab's index range (for operands that
+    are indexed by the same axis, e.g. rotary tables by token). Small inputs run inline."""
     global _pool
     n = x.shape[axis]
     k = min(_HOST_THREADS, n)
-    if k <= 1 or x.size < (1 << 22) or getattr(_in_worker, "on", False):
-        return np.asarray(fn(x), dtype=out_dtype)
+    if k <= 1 or x.size < _PMAP_MIN or getattr(_in_worker, "on", False):
+        return np.asarray(fn(x, slice(0, n)) if with_slice else fn(x), dtype=out_dtype)
     if _pool is None:
         _pool = ThreadPoolExecutor(_HOST_THREADS)
     out = np.empty(x.shape, out_dtype)
@@ -51,7 +85,7 @@ def _pmap(fn, x, axis, out_dtype=F32):
         sl[axis] = slice(cuts[i], cuts[i + 1])
         _in_worker.on = True
         try:
-            out[tuple(sl)] = fn(x[tuple(sl)])
+            out[tuple(sl)] = fn(x[tuple(sl)], sl[axis]) if with_slice else fn(x[tuple(sl)])
         finally:
             _in_worker.on = False
 
@@ -217,20 +251,30 @@ def apply_split_rope(x, cos, sin, num_heads):
     """applySplitRotaryEmb (LTXRoPE.swift:84-149). x [B,T,H*D] f32; cos/sin [T, H*D/2]."""
     b, t, hd = x.shape
     d = hd // num_heads
-    xh = x.reshape(b, t, num_heads, 2, d // 2).astype(F32)
-    c = cos.reshape(1, t, num_heads, d // 2)
-    s = sin.reshape(1, t, num_heads, d // 2)
-    first, second = xh[:, :, :, 0], xh[:, :, :, 1]
-    out = np.stack([first * c - second * s, second * c + first * s], axis=3)
-    return out.reshape(b, t, hd).astype(F32)
+
+    def f(xs, ts):  # a slab of tokens and its rows of the tables
+        n = xs.shape[1]
+        xh = xs.reshape(b, n, num_heads, 2, d // 2).astype(F32, copy=False)
+        c = cos[ts].reshape(1, n, num_heads, d // 2)
+        s_ = sin[ts].reshape(1, n, num_heads, d // 2)
+        first, second = xh[:, :, :, 0], xh[:, :, :, 1]
+        return np.stack([first * c - second * s_, second * c + first * s_], axis=3).reshape(b, n, hd)
+
+    return _pmap(f, x, 1, with_slice=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # small ops
 # ---------------------------------------------------------------------------------------------------------------
+def _tokens(fn, x):
+    """fn over the token axis (second to last) of a [.., T, D] array on the thread pool; fn is row-wise (reductions over D only)."""
+    return _pmap(fn, x, x.ndim - 2) if x.ndim >= 2 else np.asarray(fn(x), dtype=F32)
+
+
 def linear(x, w, b=None):
     """Linear with weights [out,in] (MLXNN.Linear): f32 accumulate."""
-    y = x.astype(F32, copy=False) @ w.astype(F32, copy=False).T
+    with _dit_blas():
+        y = x.astype(F32, copy=False) @ w.astype(F32, copy=False).T
     if b is not None:
         y += b.astype(F32, copy=False)
     return y
@@ -238,26 +282,37 @@ def linear(x, w, b=None):
 
 def rms_norm(x, weight=None, eps=1e-6):
     """MLXFast.rmsNorm (LTXAttention.swift:12-33): x * rsqrt(mean(x^2) + eps) * w over the last axis."""
-    x = x.astype(F32)
-    ms = np.mean(x.astype(np.float64) ** 2, axis=-1, keepdims=True)
-    y = x * (1.0 / np.sqrt(ms + eps)).astype(F32)
-    if weight is not None:
-        y = y * weight.astype(F32)
-    return y.astype(F32)
+    wf = None if weight is None else weight.astype(F32)
+
+    def f(v):
+        v = v.astype(F32, copy=False)
+        ms = np.mean(v.astype(np.float64) ** 2, axis=-1, keepdims=True)
+        y = v * (1.0 / np.sqrt(ms + eps)).astype(F32)
+        if wf is not None:
+            y = y * wf
+        return y.astype(F32, copy=False)
+
+    return _tokens(f, x)
 
 
 def layer_norm(x, eps=1e-6):
     """LayerNorm(affine: false) (LTXTransformer.swift:96)."""
-    x64 = x.astype(np.float64)
-    mu = x64.mean(-1, keepdims=True)
-    var = ((x64 - mu) ** 2).mean(-1, keepdims=True)
-    return ((x64 - mu) / np.sqrt(var + eps)).astype(F32)
+    def f(v):
+        x64 = v.astype(np.float64)
+        mu = x64.mean(-1, keepdims=True)
+        var = ((x64 - mu) ** 2).mean(-1, keepdims=True)
+        return ((x64 - mu) / np.sqrt(var + eps)).astype(F32)
+
+    return _tokens(f, x)
 
 
 def gelu_tanh(x):
     """MLXNN.geluApproximate (LTXFeedForward.swift:13-17)."""
-    x = x.astype(F32)
-    return (F32(0.5) * x * (F32(1.0) + np.tanh(F32(0.7978845608028654) * (x + F32(0.044715) * x * x * x)))).astype(F32)
+    def f(v):
+        v = v.astype(F32, copy=False)
+        return (F32(0.5) * v * (F32(1.0) + np.tanh(F32(0.7978845608028654) * (v + F32(0.044715) * v * v * v)))).astype(F32, copy=False)
+
+    return _tokens(f, x)
 
 
 def silu(x):
@@ -266,7 +321,9 @@ def silu(x):
 
 
 def sdpa(q, k, v, num_heads, scale, bias=None):
-    """MLXFast.scaledDotProductAttention on [B,T,H*D] inputs (LTXAttention.swift:192-214). bias [B,S] additive."""
+    """MLXFast.scaledDotProductAttention on [B,T,H*D] inputs (LTXAttention.swift:192-214). bias [B,S] additive.
+    Per batch element: the scores of a group of heads as one batched product, the softmax of the group on the thread pool (it is
+    head-wise), then P.V batched - the same products and the same element-wise steps as a loop over single heads."""
     b, tq, hd = q.shape
     tk = k.shape[1]
     d = hd // num_heads
@@ -274,15 +331,25 @@ def sdpa(q, k, v, num_heads, scale, bias=None):
     kh = k.reshape(b, tk, num_heads, d).transpose(0, 2, 1, 3).astype(F32)
     vh = v.reshape(b, tk, num_heads, d).transpose(0, 2, 1, 3).astype(F32)
     out = np.empty((b, num_heads, tq, d), F32)
+    grp = max(1, min(num_heads, (1 << 28) // max(1, tq * tk)))  # heads per group: at most 1 GiB of f32 scores at a time
     for bi in range(b):
-        for h in range(num_heads):
-            s = (qh[bi, h] @ kh[bi, h].T) * F32(scale)
-            if bias is not None:
-                s = s + bias[bi][None, :].astype(F32)
-            s = s - s.max(-1, keepdims=True)
-            p = np.exp(s)
-            p = p / p.sum(-1, keepdims=True)
-            out[bi, h] = p @ vh[bi, h]
+        bias_row = None if bias is None else bias[bi][None, None, :].astype(F32)
+
+        def softmax(sc):
+            sc = sc * F32(scale)
+            if bias_row is not None:
+                sc = sc + bias_row
+            sc = sc - sc.max(-1, keepdims=True)
+            p = np.exp(sc)
+            return p / p.sum(-1, keepdims=True)
+
+        for h0 in range(0, num_heads, grp):
+            h1 = min(num_heads, h0 + grp)
+            with _dit_blas():
+                sc = np.matmul(qh[bi, h0:h1], kh[bi, h0:h1].transpose(0, 2, 1))
+            p = _pmap(softmax, sc, 0)
+            with _dit_blas():
+                np.matmul(p, vh[bi, h0:h1], out=out[bi, h0:h1])
     return out.transpose(0, 2, 1, 3).reshape(b, tq, hd)
 
 
@@ -569,14 +636,15 @@ def _conv_taps_blas(xp, wt, bias):
     rows = xp.reshape(-1, c)
     acc = np.empty((t * hp * wp, o), F32)
     acc[:] = 0.0 if bias is None else bias.astype(F32)[None, :]
-    for kt in range(kt_n):
-        for kh in range(3):
-            for kw in range(3):
-                off = (kt * hp + kh) * wp + kw
-                # acc[:n] += rows[off:off+n] @ wt[kt,kh,kw], as the column-major product acc^T += W^T @ rows^T (all three
-                # operands are Fortran-contiguous views, so the BLAS call works in place)
-                r = sgemm(1.0, wt[kt, kh, kw].T, rows[off:off + n].T, beta=1.0, c=acc[:n].T, overwrite_c=1)
-                assert np.shares_memory(r, acc)
+    with _conv_blas():
+        for kt in range(kt_n):
+            for kh in range(3):
+                for kw in range(3):
+                    off = (kt * hp + kh) * wp + kw
+                    # acc[:n] += rows[off:off+n] @ wt[kt,kh,kw], as the column-major product acc^T += W^T @ rows^T (all three
+                    # operands are Fortran-contiguous views, so the BLAS call works in place)
+                    r = sgemm(1.0, wt[kt, kh, kw].T, rows[off:off + n].T, beta=1.0, c=acc[:n].T, overwrite_c=1)
+                    assert np.shares_memory(r, acc)
     a4 = acc.reshape(t, hp, wp, o)
     out = np.empty((o, t, h, wd), F32)
     if _pool is None:
@@ -587,6 +655,23 @@ def _conv_taps_blas(xp, wt, bias):
 
     list(_pool.map(take, range(t)))
     return out
+
+
+def _taps_first(weight):
+    """(O, I, kT, 3, 3) -> [kT][3][3][I][O] f32 contiguous (the tap loop's W_tap operands), one tap per pool task."""
+    global _pool
+    o, i, kt_n = weight.shape[0], weight.shape[1], weight.shape[2]
+    wt = np.empty((kt_n, 3, 3, i, o), F32)
+    if _pool is None:
+        _pool = ThreadPoolExecutor(_HOST_THREADS)
+
+    def one(j):
+        kt, r = divmod(j, 9)
+        kh, kw = divmod(r, 3)
+        wt[kt, kh, kw] = weight[:, :, kt, kh, kw].T
+
+    list(_pool.map(one, range(kt_n * 9)))
+    return wt
 
 
 def _pad_channels_last(x1, t_src, mode):
@@ -617,7 +702,7 @@ def conv3d_full(x, weight, bias, causal=False):
     """Conv3dFull (VideoConvolution.swift:202-348): reflect pad H/W by 1, replicate pad T (1+1, or 2+0 causal), 27 taps, bias,
     f32 accumulation. BLAS-speed form (`_conv_taps_blas`); same tap order (kt, kh, kw) as `conv3d_full_einsum`."""
     b, c, t, h, wd = x.shape
-    wt = np.ascontiguousarray(weight.astype(F32).transpose(2, 3, 4, 1, 0))       # [3,3,3,C,O]
+    wt = _taps_first(weight)
     t_src = [min(max(pf - (2 if causal else 1), 0), t - 1) for pf in range(t + 2)]
     out = np.empty((b, weight.shape[0], t, h, wd), F32)
     for bi in range(b):
@@ -1012,7 +1097,7 @@ def conv_nd_zero(x, weight, bias):
         t_src = list(range(t))
     else:
         t_src = [None] + list(range(t)) + [None]
-    wt = np.ascontiguousarray(weight.astype(F32).transpose(2, 3, 4, 1, 0))
+    wt = _taps_first(weight)
     out = np.empty((b, weight.shape[0], t, h, w), F32)
     for bi in range(b):
         out[bi] = _conv_taps_blas(_pad_channels_last(x[bi].astype(F32, copy=False), t_src, "zero"), wt, bias)
@@ -1316,7 +1401,7 @@ def conv3d_causal_zero(x, weight, bias, causal=True):
     = first frame twice in front (causal) or replicate 1+1. BLAS-speed form (`_conv_taps_blas`)."""
     b, c, t, h, wd = x.shape
     t_src = [min(max(pf - (2 if causal else 1), 0), t - 1) for pf in range(t + 2)]
-    wt = np.ascontiguousarray(weight.astype(F32).transpose(2, 3, 4, 1, 0))
+    wt = _taps_first(weight)
     out = np.empty((b, weight.shape[0], t, h, wd), F32)
     for bi in range(b):
         out[bi] = _conv_taps_blas(_pad_channels_last(x[bi].astype(F32, copy=False), t_src, "zero"), wt, bias)
