@@ -105,6 +105,32 @@ def test_conv_nd_zero_and_causal_zero_vs_torch(oracle, per_frame):
         assert np.allclose(oracle.conv3d_causal_zero(x, w, b, causal), ref, atol=1e-4)
 
 
+def test_threaded_passes_do_not_change_a_bit(oracle):
+    """The oracle runs its row-wise passes (norms, GELU, RoPE, softmax per head, PixelNorm + SiLU) slab by slab on a thread pool above a
+    size threshold. Forcing the slab path on small inputs must reproduce the inline results exactly, for the DiT and for the decoder."""
+    rng = np.random.default_rng(3)
+    cfg = oracle.DiTConfig(num_layers=2, num_heads=4, caption_channels=64)
+    w = oracle.synth_dit_weights(cfg, seed=5)
+    F, H, W, S = 3, 8, 12, 40
+    lat = oracle.bf16_round(rng.standard_normal((2, F * H * W, 128)).astype(np.float32))
+    cx = oracle.bf16_round(rng.standard_normal((2, S, 64)).astype(np.float32))
+    mask = (rng.random((2, S)) > 0.2).astype(np.int32)
+    mask[:, 0] = 1
+    wv = oracle.synth_vae_weights(channels=(64, 32, 16, 8), seed=9)
+    vlat = rng.standard_normal((1, 128, 2, 3, 4)).astype(np.float32)
+    keep = oracle._PMAP_MIN
+    try:
+        oracle._PMAP_MIN = 1 << 40
+        a = oracle.dit_forward(w, cfg, lat, cx, np.array([0.7, 0.3], np.float32), mask, F, H, W)
+        va = oracle.decode_video(wv, vlat, channels=(64, 32, 16, 8))
+        oracle._PMAP_MIN = 16
+        b = oracle.dit_forward(w, cfg, lat, cx, np.array([0.7, 0.3], np.float32), mask, F, H, W)
+        vb = oracle.decode_video(wv, vlat, channels=(64, 32, 16, 8))
+    finally:
+        oracle._PMAP_MIN = keep
+    assert np.array_equal(a, b) and np.array_equal(va, vb)
+
+
 def test_depth_to_space_and_unpatchify_index_maps(oracle):
     # D2S: out[c, 2t+dt, 2h+dh, 2w+dw] = in[((c*2+dt)*2+dh)*2+dw, t, h, w]  (VideoDecoder.swift:201-213)
     x = np.arange(16 * 2 * 3 * 4, dtype=np.float32).reshape(1, 16, 2, 3, 4)
