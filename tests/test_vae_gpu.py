@@ -80,6 +80,31 @@ def test_conv3d_random_shapes_integer_exact(gpu_ctx):
         assert torch.equal(out, ref), (F, H, W, Cin, Cout, float((out - ref).abs().max()))
 
 
+@pytest.mark.parametrize("F,H,W,Cin,Cout", [(9, 64, 96, 64, 128), (11, 100, 48, 64, 128), (5, 64, 96, 64, 256), (9, 121, 48, 64, 96), (2, 140, 192, 128, 128)])
+def test_conv3d_halo_persistent_launches_integer_exact(gpu_ctx, F, H, W, Cin, Cout):
+    """Round 4: above one round of tiles the halo-staged kernel is persistent (one workgroup per CU walks its XCD's chunk of the tile order
+    and requests the next tile's operands from inside the epilogue). Tile counts just above the CU count, with chunk remainders: 288 tiles
+    in the blocked order, 275 in the plain order (25 tiles per frame), 320 over two column tiles (supertile order), 273 with a ragged last
+    tile and 96 of 128 columns, 280 whole-row tiles at two channel halves - against torch's conv3d on integer data, exactly."""
+    import torch.nn.functional as F_
+
+    rng = np.random.default_rng(F * 1000 + H * 100 + W + Cin + Cout)
+    x = torch.from_numpy(rng.integers(-2, 3, (1, Cin, F, H, W)).astype(np.float32)).cuda()
+    w = torch.from_numpy(rng.integers(-2, 3, (Cout, Cin, 3, 3, 3)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rng.integers(-4, 5, (Cout,)).astype(np.float32)).cuda()
+    xp = F_.pad(x, (1, 1, 1, 1, 0, 0), mode="reflect")
+    xp = torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], 2)
+    ref = F_.conv3d(xp.double(), w.double(), b.double())[0].permute(1, 2, 3, 0).float()
+    xd = x[0].permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)
+    wd = torch.from_numpy(relayout(w.cpu().numpy())).to(torch.bfloat16).cuda()
+    assert ((F * H * W + 191) // 192) * ((Cout + 127) // 128) > 256
+    for _ in range(2):  # twice: the second launch finds the first one's lines in the caches
+        out = torch.full((F, H, W, Cout), float("nan"), device="cuda")
+        gpu_ctx.op_conv3d(xd, wd, b, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), (F, H, W, Cin, Cout, float((out - ref).abs().max()))
+
+
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("F,H,W,Cin,Cout", [(3, 7, 48, 64, 128), (2, 5, 64, 128, 96), (3, 6, 96, 192, 128), (2, 3, 192, 64, 256),
                                             (1, 4, 384, 128, 128), (5, 4, 48, 64, 128), (1, 2, 192, 64, 128), (2, 2, 576, 64, 80)])
