@@ -106,3 +106,25 @@ def test_full_depth_48_layers_config1_vs_oracle(ltx, oracle, full48_host):
     r, c = rel_l2(got, ref), _cos(got, ref)
     print(f"full width, 48 blocks, T={T}, S={S}: rel-L2 {r:.3e}, cos {c:.6f}")
     assert np.isfinite(got).all() and r <= 3e-2 and c >= 0.999, (r, c)
+
+
+def test_48_layer_cfg_loop_vs_oracle(ltx, oracle, full48_host):
+    """BASELINE configs[2]'s loop body at the reference's depth: dev schedule, CFG 4.0 on a [negative, positive] pair with masked text keys,
+    guidance rescale 0.7 (LTXPipeline.swift:820-865, LatentUtils.swift:131-183) - three steps through all 48 blocks on config 1's latent.
+    CFG multiplies the difference of two forwards by 4, so the per-forward deviation (2.4e-3 .. 2.9e-3) is amplified: bound 5e-2, the one the
+    reduced-width CFG test states."""
+    ctx, cfg, ocfg, w = full48_host
+    F, H, W, S = 2, 8, 8, 64
+    rng = np.random.default_rng(21)
+    noise = rng.standard_normal((1, 128, F, H, W)).astype(np.float32)
+    ctx2 = oracle.bf16_round(rng.standard_normal((2, S, 3840)).astype(np.float32))   # [negative, positive]
+    mask = (rng.random((2, S)) > 0.2).astype(np.int32)
+    mask[:, 0] = 1
+    sig = ltx.sigmas(False, 3, F * H * W)
+    lat0 = noise * sig[0]
+    got = ctx.denoise(lat0, sig, ltx.f32_to_bf16_bits(ctx2), mask, F, H, W, cfg_scale=4.0, guidance_rescale=0.7)
+    t0 = time.time()
+    ref = oracle.denoise(w, ocfg, lat0, sig, ctx2[1:2], mask[1:2], F, H, W, cfg_scale=4.0, rescale=0.7, neg_context=ctx2[0:1], neg_mask=mask[0:1])
+    r, c = rel_l2(got, ref), _cos(got, ref)
+    print(f"full width, 48 blocks, 3-step CFG 4.0 + rescale loop: rel-L2 {r:.3e}, cos {c:.6f} (oracle {time.time() - t0:.0f} s)")
+    assert np.isfinite(got).all() and r <= 5e-2 and c >= 0.999, (r, c)
