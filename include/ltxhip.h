@@ -356,6 +356,12 @@ typedef struct ltx_denoise_options {
      *                          multiples of 8): per transformer block one all-gather of K rows and one of V^T, per forward one
      *                          all-gather of the velocity slices. */
     int shard;
+    /* Per-step diagnostics, optional: a HOST array of 4 * (n_sigmas - 1) floats that receives, for every step, the mean and the
+     * (population) standard deviation of the guided velocity and of the latent after the Euler update - the numbers the reference logs
+     * under --profile ("Step i: ... vel mean=, std=, latent mean=, std=", LTXPipeline.swift:945-951). With it the call ends with a
+     * stream synchronisation (the device entry point is otherwise asynchronous). NULL = none. A maintainer with the reference on a Mac
+     * can compare these lines for the same weights, embeddings and noise without touching the reference's code. */
+    float* step_stats;
 } ltx_denoise_options;
 enum { LTX_SHARD_NONE = 0, LTX_SHARD_CFG = 1, LTX_SHARD_SEQUENCE = 2 };
 

@@ -553,16 +553,20 @@ class Context:
     # ---- denoise loop ----
     @staticmethod
     def _options(cfg_scale=1.0, guidance_rescale=0.0, stg_scale=0.0, stg_blocks=(29,), ge_gamma=0.0, cond_latent=None,
-                 image_cond_noise_scale=0.0, cond_noise=None, shard=SHARD_NONE):
-        """cond_latent / cond_noise (image-to-video): numpy arrays for the host entry point, torch tensors for the device one."""
+                 image_cond_noise_scale=0.0, cond_noise=None, shard=SHARD_NONE, step_stats=None):
+        """cond_latent / cond_noise (image-to-video): numpy arrays for the host entry point, torch tensors for the device one.
+        step_stats: a C-contiguous float32 numpy array [n_steps, 4] that receives (velocity mean, velocity std, latent mean, latent std)
+        per step - the reference's --profile diagnostics (LTXPipeline.swift:945-951)."""
         arr = (C.c_int * max(1, len(stg_blocks)))(*stg_blocks)
         if isinstance(cond_latent, np.ndarray):
             cond_latent = np.ascontiguousarray(cond_latent, dtype=np.float32)
         if isinstance(cond_noise, np.ndarray):
             cond_noise = np.ascontiguousarray(cond_noise, dtype=np.float32)
+        if step_stats is not None:
+            assert isinstance(step_stats, np.ndarray) and step_stats.dtype == np.float32 and step_stats.flags["C_CONTIGUOUS"] and step_stats.shape[-1] == 4
         o = DenoiseOptions(cfg_scale, guidance_rescale, stg_scale, C.cast(arr, C.POINTER(C.c_int)), len(stg_blocks), ge_gamma,
-                           _ptr(cond_latent), image_cond_noise_scale, _ptr(cond_noise), int(shard))
-        o._keep = (arr, cond_latent, cond_noise)
+                           _ptr(cond_latent), image_cond_noise_scale, _ptr(cond_noise), int(shard), _ptr(step_stats))
+        o._keep = (arr, cond_latent, cond_noise, step_stats)
         return o
 
     def denoise(self, latent, sigmas_, context_bf16, mask, F, H, W, on_progress=None, **opts):

@@ -33,7 +33,7 @@ class DenoiseOptions(C.Structure):
     _fields_ = [("cfg_scale", C.c_float), ("guidance_rescale", C.c_float), ("stg_scale", C.c_float),
                 ("stg_blocks", C.POINTER(C.c_int)), ("n_stg_blocks", C.c_int), ("ge_gamma", C.c_float),
                 ("cond_latent", C.c_void_p), ("image_cond_noise_scale", C.c_float), ("cond_noise", C.c_void_p),
-                ("shard", C.c_int)]
+                ("shard", C.c_int), ("step_stats", C.c_void_p)]
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_float, C.c_void_p)

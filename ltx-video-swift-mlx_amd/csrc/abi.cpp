@@ -849,6 +849,7 @@ static void fill_params(DenoiseParams& p, const ltx_denoise_options* o) {
     p.image_cond_noise_scale = o->image_cond_noise_scale;
     p.cond_noise = o->cond_noise;
     p.shard = o->shard;
+    p.step_stats = o->step_stats;
 }
 
 int ltx_denoise_dev(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* sigmas, int n_sigmas,

@@ -1,5 +1,6 @@
 // pipeline.cpp - see pipeline.h.
 #include "pipeline.h"
+#include <math.h>
 
 #include "dist.h"
 #include "dit.h"
@@ -110,6 +111,11 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
     };
 
     const int steps = p.n_sigmas - 1;
+    float* step_stats_dev = nullptr;
+    if (p.step_stats) {
+        ctx->dn_step_stats.ensure((size_t)steps * 16);
+        step_stats_dev = ctx->dn_step_stats.as<float>();
+    }
     for (int step = 0; step < steps; ++step) {
         const float sigma = p.sigmas[step], sigma_next = p.sigmas[step + 1];
         if (p.progress) p.progress(step, steps, sigma, p.user);  // before the forward (LTXPipeline.swift:805-810)
@@ -186,5 +192,17 @@ void denoise_run(ltx_ctx* ctx, const DenoiseParams& p) {
             have_prev = true;
         }
         launch_euler_step(p.latent, v, sigma, sigma_next, n, st, i2v ? HW : 0, p.F);  // I2V: frames 1+ only (:2344-2357)
+        if (step_stats_dev) {  // velocity.mean / sqrt(variance), latent.mean / sqrt(variance) (LTXPipeline.swift:945-951)
+            launch_mean_var(v, n, 1, step_stats_dev + 4 * step, st);
+            launch_mean_var(p.latent, n, 1, step_stats_dev + 4 * step + 2, st);
+        }
+    }
+    if (step_stats_dev) {
+        HIP_CHECK(hipMemcpyAsync(p.step_stats, step_stats_dev, (size_t)steps * 16, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (int i = 0; i < steps; ++i) {  // variance -> standard deviation
+            p.step_stats[4 * i + 1] = sqrtf(p.step_stats[4 * i + 1]);
+            p.step_stats[4 * i + 3] = sqrtf(p.step_stats[4 * i + 3]);
+        }
     }
 }

@@ -40,6 +40,9 @@ struct DenoiseParams {
     //     [T/N][C] velocity slices per forward; scheduler arithmetic redundant on every rank. CFG runs as two sequential B=1
     //     forwards, as generateVideo does (LTXPipeline.swift:829-848).
     int shard = 0;
+    // optional HOST array [n_sigmas-1][4]: mean / population std of the guided velocity and of the latent after each step
+    // (the reference's --profile diagnostics, LTXPipeline.swift:945-951); the run then ends with a stream synchronisation
+    float* step_stats = nullptr;
 };
 
 enum { SHARD_NONE = 0, SHARD_CFG = 1, SHARD_SEQUENCE = 2 };

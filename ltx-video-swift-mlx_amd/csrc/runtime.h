@@ -141,7 +141,7 @@ struct ltx_ctx {
     int n_loaded = 0, n_missing = 0, n_unmatched = 0;
     Profiler prof;
     // denoise-loop scratch (device)
-    DevBuf dn_tokens, dn_vel_tok, dn_vel, dn_vel2, dn_vel3, dn_prev, dn_ts, dn_stats, dn_lat2;
+    DevBuf dn_tokens, dn_vel_tok, dn_vel, dn_vel2, dn_vel3, dn_prev, dn_ts, dn_stats, dn_lat2, dn_step_stats;
     DevBuf dn_rowmap;  // I2V token -> timestep-group map
     DevBuf dn_vel_slice;  // sequence-sharded loop: this rank's [T/N][C] velocity rows before the all-gather
     DevBuf i2v_cond, i2v_noise;  // staged image latent / re-noising draws of the host-pointer denoise entry

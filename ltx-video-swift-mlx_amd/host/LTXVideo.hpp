@@ -122,9 +122,15 @@ struct GenerationProgress {
     double progress() const { return double(currentStep) / double(totalSteps); }
 };
 using GenerationProgressCallback = std::function<void(const GenerationProgress&)>;
+// what the reference logs per step under --profile (LTXPipeline.swift:945-951): sigma -> sigmaNext, mean / std of the velocity and of the latent
+struct StepDiagnostics {
+    int step = 0;
+    float sigma = 0, sigmaNext = 0, velocityMean = 0, velocityStd = 0, latentMean = 0, latentStd = 0;
+};
 struct GenerationTimings {
     double textEncoding = 0, vaeDecode = 0;
     std::vector<double> denoiseSteps;
+    std::vector<StepDiagnostics> stepDiagnostics;  // filled when profiling
     double totalDenoise() const { double s = 0; for (double d : denoiseSteps) s += d; return s; }
 };
 struct VideoGenerationResult {
@@ -297,8 +303,16 @@ class LTXPipeline {
             if (b->cb) b->cb(GenerationProgress{step, total, sigma});
         };
         box.last = std::chrono::steady_clock::now();
+        std::vector<float> stepStats;
+        if (profile) {  // the per-step diagnostics the reference logs when profiling (LTXPipeline.swift:945-951)
+            stepStats.assign(size_t(config.numSteps) * 4, 0.0f);
+            opt.step_stats = stepStats.data();
+        }
         check(ltx_denoise(ctx_, latent.data(), F, H, W, sig, config.numSteps + 1, ctxBits.data(), mask.data(), emb.S, &opt, thunk, &box));
         timings.denoiseSteps.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - box.last).count());
+        for (int i = 0; i < config.numSteps && profile; ++i)
+            timings.stepDiagnostics.push_back(StepDiagnostics{i, sig[i], sig[i + 1], stepStats[4 * i], stepStats[4 * i + 1], stepStats[4 * i + 2],
+                                                              stepStats[4 * i + 3]});
         VideoGenerationResult r = decode(latent, F, H, W, config, vaeNoise, timings);
         r.seed = config.seed.value_or(0);
         r.generationTime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

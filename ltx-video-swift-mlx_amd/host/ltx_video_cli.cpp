@@ -295,6 +295,13 @@ int run_generate(const Args& a) {
     if (a.profile && r.timings) {
         std::cout << "\nProfile:\n  denoise total: " << r.timings->totalDenoise() << "s over " << r.timings->denoiseSteps.size()
                   << " steps\n  VAE decode: " << r.timings->vaeDecode << "s\n";
+        // the reference's per-step line, same format (LTXPipeline.swift:951), so that two --profile logs can be diffed
+        for (const auto& d : r.timings->stepDiagnostics) {
+            char line[256];
+            snprintf(line, sizeof(line), "  Step %d: \xcf\x83=%.4f\xe2\x86\x92%.4f, vel mean=%.4f, std=%.4f, latent mean=%.4f, std=%.4f", d.step, d.sigma,
+                     d.sigmaNext, d.velocityMean, d.velocityStd, d.latentMean, d.latentStd);
+            std::cout << line << "\n";
+        }
     }
     return 0;
 }

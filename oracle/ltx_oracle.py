@@ -544,7 +544,7 @@ def euler_step(latent, velocity, sigma, sigma_next):
 
 def denoise(w, cfg, latent, sigmas_, context, mask, F, H, W, cfg_scale=1.0, rescale=0.0, stg_scale=0.0,
             stg_blocks=(29,), ge_gamma=0.0, neg_context=None, neg_mask=None, num_layers=None, cond_latent=None,
-            image_cond_noise_scale=0.0, cond_noise=None):
+            image_cond_noise_scale=0.0, cond_noise=None, step_stats=None):
     """generateVideo's loop (LTXPipeline.swift:800-956), T2V. latent [1,C,F,H,W] f32 already scaled by sigmas[0].
     Image-to-video (denoise(...) :2191-2401 with conditioningMask / conditionedLatent): cond_latent [1,C,1,H,W] is the encoded
     image; frame 0 is that latent (:2092-2094), optionally re-noised per step with cond_noise[step] * scale * sigma^2
@@ -587,6 +587,9 @@ def denoise(w, cfg, latent, sigmas_, context, mask, F, H, W, cfg_scale=1.0, resc
             latent = np.concatenate([latent[:, :, 0:1], euler_step(latent[:, :, 1:], v[:, :, 1:], sg, sn)], axis=2)
         else:
             latent = euler_step(latent, v, sg, sn)
+        if step_stats is not None:  # the reference's --profile line (LTXPipeline.swift:945-951): mean and sqrt(population variance)
+            step_stats.append((float(v.mean(dtype=np.float64)), float(v.std(dtype=np.float64)), float(latent.mean(dtype=np.float64)),
+                               float(latent.std(dtype=np.float64))))
     return latent
 
 

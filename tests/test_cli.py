@@ -68,6 +68,11 @@ def test_cli_generate_end_to_end(ltx, oracle, tmp_path):
                      "--caption-channels", "128", "--profile", "--png-dir", str(tmp_path))
     assert rc == 0, se
     assert "Step 8/8" in so and "Generated 9 frames (64x64)" in so
+    # --profile: the reference's per-step diagnostics line (LTXPipeline.swift:951), one per step, sigma schedule = the distilled table
+    import re
+    diag = re.findall(r"  Step (\d): σ=([0-9.]+)→([0-9.]+), vel mean=(-?[0-9.]+), std=([0-9.]+), latent mean=(-?[0-9.]+), std=([0-9.]+)", so)
+    assert [int(d[0]) for d in diag] == list(range(8)), so
+    assert diag[0][1] == "1.0000" and diag[7][2] == "0.0000" and all(float(d[4]) > 0 and float(d[6]) > 0 for d in diag)
     meta = json.loads(open(str(out) + ".json").read())
     assert meta == {"frames": 9, "height": 64, "width": 64, "channels": 3, "dtype": "float32", "range": [0, 1], "seed": 7}
     frames = np.fromfile(out, np.float32).reshape(9, 64, 64, 3)

@@ -61,6 +61,32 @@ def test_denoise_cfg_rescale_stg_ge(ltx, oracle, gpu_ctx, model):
     assert rel_l2(got, ref) <= 5e-2, rel_l2(got, ref)
 
 
+def test_denoise_step_diagnostics_match_the_oracle(ltx, oracle, gpu_ctx, model):
+    """ltx_denoise_options.step_stats: per step the mean / population std of the guided velocity and of the latent after the Euler update -
+    what the reference logs under --profile (LTXPipeline.swift:945-951, four decimals) - against the same statistics of oracle.denoise, with
+    CFG + rescale on; asking for them must not change the latent."""
+    cfg, ocfg, w = model
+    F, H, W, S = 2, 4, 6, 24
+    noise, ctx2 = _inputs(oracle, ocfg, F, H, W, S, 41, nb=2)
+    sig = ltx.sigmas(False, 5, F * H * W)
+    lat0 = noise * sig[0]
+    stats = np.zeros((len(sig) - 1, 4), np.float32)
+    got = gpu_ctx.denoise(lat0, sig, ltx.f32_to_bf16_bits(ctx2), None, F, H, W, cfg_scale=3.0, guidance_rescale=0.5, step_stats=stats)
+    plain = gpu_ctx.denoise(lat0, sig, ltx.f32_to_bf16_bits(ctx2), None, F, H, W, cfg_scale=3.0, guidance_rescale=0.5)
+    assert np.array_equal(got, plain)
+    ref_stats = []
+    ref = oracle.denoise(w, ocfg, lat0, sig, ctx2[1:2], None, F, H, W, cfg_scale=3.0, rescale=0.5, neg_context=ctx2[0:1], step_stats=ref_stats)
+    ref_stats = np.asarray(ref_stats, np.float32)
+    assert stats.shape == ref_stats.shape and np.isfinite(stats).all() and (stats[:, 1] > 0).all() and (stats[:, 3] > 0).all()
+    # the last row's latent statistics are those of the returned latent, exactly as numpy computes them in f32-safe precision
+    assert abs(float(got.mean(dtype=np.float64)) - stats[-1, 2]) <= 1e-5 and abs(float(got.std(dtype=np.float64)) - stats[-1, 3]) <= 1e-5
+    err = np.abs(stats - ref_stats)
+    print("step diagnostics, max abs difference to the oracle per column (vel mean, vel std, latent mean, latent std):", err.max(0))
+    assert (err[:, 0] <= 2e-3).all() and (err[:, 2] <= 2e-3).all()
+    assert (err[:, 1] <= 2e-2 * ref_stats[:, 1]).all() and (err[:, 3] <= 1e-2 * ref_stats[:, 3]).all()
+    assert rel_l2(got, ref) <= 5e-2
+
+
 def test_denoise_single_step_bitwise_repeatable(ltx, oracle, gpu_ctx, model):
     cfg, ocfg, w = model
     F, H, W, S = 2, 3, 5, 17
