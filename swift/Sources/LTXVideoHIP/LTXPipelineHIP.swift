@@ -140,7 +140,8 @@ public final class LTXPipelineHIP {
                                                   cond_latent: imageLatent == nil ? nil : img.baseAddress,
                                                   image_cond_noise_scale: config.imageCondNoiseScale,
                                                   cond_noise: injectionNoise == nil ? nil : inj.baseAddress,
-                                                  shard: Int32(config.shard))
+                                                  shard: Int32(config.shard),
+                                                  step_stats: nil)  // per-step --profile diagnostics: pass a [Float](4 * numSteps) to get them
                     try check(ltx_denoise(ctx, &latent, f, h, w, sig, Int32(config.numSteps + 1), text.embeddings, text.mask,
                                           Int32(text.tokens), &opt, thunk, Unmanaged.passUnretained(box).toOpaque()))
                 }
