@@ -90,7 +90,9 @@ def oracle_run(cfg, w, fhw, emb, mask, noise, sig):
 
 def report(stats, sig, final):
     lines = [line(i, float(sig[i]), float(sig[i + 1]), stats[i]) for i in range(len(stats))]
-    lines.append(f"  final latent: mean={float(final.mean(dtype=np.float64)):.4f}, std={float(final.std(dtype=np.float64)):.4f}")
+    # the reference's "[DIAG] Final latent: mean=, std=, min=, max=" (LTXPipeline.swift:960-964; it prints Swift's shortest float form)
+    lines.append(f"  [DIAG] Final latent: mean={float(final.mean(dtype=np.float64)):.4f}, std={float(final.std(dtype=np.float64)):.4f}, "
+                 f"min={float(final.min()):.4f}, max={float(final.max()):.4f}")
     return lines
 
 
