@@ -6,6 +6,7 @@
 // prompt_embeddings [1,S,3840], prompt_mask [1,S], optional negative_embeddings / negative_mask) - the CLI-level
 // equivalent of the reference's PrecomputedEmbeddings hook - the VAE from `--vae-weights`, and frames are written as a
 // raw float32 (F,H,W,3) file plus a JSON sidecar instead of an MP4.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -306,6 +307,86 @@ int run_generate(const Args& a) {
     return 0;
 }
 
+// `ltx-video bench`: the headline measurement WITHOUT Python or PyTorch - this binary links libltxhip.so only and talks to it through
+// the C ABI with host pointers (so the figure is PCIe-inclusive: per step 0.4 MB of latent in and out; the 7.9 MB text context crosses
+// once, the library recognises unchanged context bytes). Synthetic weights of the reference architecture generated on the device, a
+// seeded N(0,1) latent and context generated here. bench.py (HBM-resident inputs, roofline, CPU baseline) stays the number of record.
+int run_bench(int argc, char** argv) {
+    int width = 768, height = 512, frames = 25, steps = 20, warmup = 5, S = 1024, layers = 48, decodes = 3;
+    for (int i = 2; i < argc; ++i) {
+        const std::string k = argv[i];
+        auto need = [&]() -> int { if (i + 1 >= argc) throw ValidationError("missing value for " + k); return std::stoi(argv[++i]); };
+        if (k == "-w" || k == "--width") width = need();
+        else if (k == "-h" || k == "--height") height = need();
+        else if (k == "-f" || k == "--frames") frames = need();
+        else if (k == "--steps") steps = need();
+        else if (k == "--warmup") warmup = need();
+        else if (k == "--text-keys") S = need();
+        else if (k == "--num-layers") layers = need();
+        else if (k == "--decodes") decodes = need();
+        else throw ValidationError("Unknown bench option '" + k + "'");
+    }
+    ltx_ctx* ctx = nullptr;
+    auto ck = [&](int st) { if (st != 0) throw LTXError(LTXError::generationFailed, ctx ? ltx_last_error(ctx) : "ltx_ctx_create failed"); };
+    ck(ltx_ctx_create(0, &ctx));
+    ltx_transformer_config cfg;
+    ltx_transformer_config_default(&cfg);
+    cfg.num_layers = layers;
+    ck(ltx_dit_init_synthetic(ctx, &cfg, 1234));
+    int F, H, W;
+    if (ltx_latent_shape(width, height, frames, &F, &H, &W) != 0) throw ValidationError("bad width / height / frames");
+    const size_t n = size_t(128) * F * H * W;
+    std::vector<float> latent = generateNoise(n, 42);
+    std::vector<float> cf = generateNoise(size_t(S) * cfg.caption_channels, 43);
+    std::vector<uint16_t> context(cf.size());
+    for (size_t i = 0; i < cf.size(); ++i) {  // f32 -> bf16 bits, round to nearest even
+        uint32_t u;
+        std::memcpy(&u, &cf[i], 4);
+        context[i] = uint16_t((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    }
+    std::vector<int32_t> mask(S, 1);
+    float sig[16];
+    const int ns = ltx_sigmas(1, 8, F * H * W, sig, 16);
+    if (ns != 9) throw LTXError(LTXError::generationFailed, "ltx_sigmas");
+    // as a host uses the entry point: ONE call runs the steps of a generation (the distilled schedule has eight); `count` steps are
+    // issued as calls of at most eight (patchify + forward + unpatchify + Euler per step inside the library)
+    auto run_steps = [&](int count, uint64_t seed) {
+        for (int done = 0; done < count;) {
+            const int k = std::min(8, count - done);
+            latent = generateNoise(n, seed + uint64_t(done));
+            for (float& v : latent) v *= sig[0];
+            ck(ltx_denoise(ctx, latent.data(), F, H, W, sig, k + 1, context.data(), mask.data(), S, nullptr, nullptr, nullptr));
+            done += k;
+        }
+    };
+    run_steps(warmup, 100);
+    std::vector<float> keep = latent;
+    const auto t0 = std::chrono::steady_clock::now();
+    run_steps(steps, 7000);
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    double vae_ms = 0;
+    if (decodes > 0) {
+        ck(ltx_vae_init_synthetic(ctx, 77, 0));
+        std::vector<float> vlat = generateNoise(n, 45);
+        std::vector<float> out(size_t(8 * (F - 1) + 1) * H * 32 * W * 32 * 3);
+        int nf = 0;
+        ck(ltx_vae_decode(ctx, vlat.data(), F, H, W, 0, 0.f, nullptr, 0, 1, out.data(), long(out.size()), &nf));
+        const auto v0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < decodes; ++i) ck(ltx_vae_decode(ctx, vlat.data(), F, H, W, 0, 0.f, nullptr, 0, 1, out.data(), long(out.size()), &nf));
+        vae_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - v0).count() / decodes;
+    }
+    char line[1024];
+    snprintf(line, sizeof(line),
+             "{\"metric\": \"DiT denoise steps/sec, %dx%dx%d distilled (ltx-video bench: C ABI with host pointers, no Python, no PyTorch)\", "
+             "\"value\": %.4f, \"unit\": \"steps/s\", \"ms_per_step\": %.3f, \"steps\": %d, \"warmup\": %d, \"tokens\": %d, \"text_keys\": %d, "
+             "\"layers\": %d, \"dtype\": \"bf16\", \"data\": \"synthetic\", \"pcie_inclusive\": true, \"vae_decode_ms_host_pointers\": %.2f, "
+             "\"build\": \"%s\"}",
+             width, height, frames, steps / el, 1e3 * el / steps, steps, warmup, F * H * W, S, layers, vae_ms, ltx_build_info());
+    std::cout << line << "\n";
+    ltx_ctx_destroy(ctx);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -324,6 +405,7 @@ int main(int argc, char** argv) {
         }
         if (sub == "download") throw ValidationError("download is not available: this path has no network access");
         if (sub == "generate") return run_generate(parse_generate(argc, argv, 2));
+        if (sub == "bench") return run_bench(argc, argv);
         throw ValidationError("Unknown subcommand '" + sub + "'");
     } catch (const ValidationError& e) {
         std::cerr << "Error: " << e.what() << "\n";

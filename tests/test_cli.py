@@ -93,6 +93,21 @@ def test_cli_generate_end_to_end(ltx, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_bench_runs_without_python_on_the_data_path():
+    """`ltx-video bench`: the headline loop driven by the compiled host alone - it links libltxhip.so only (no Python, no PyTorch) and
+    uses the C ABI with host pointers. Two layers and a small clip here; the full-size line is quoted in DESIGN.md section 5."""
+    rc, so, se = run("bench", "-w", "256", "-h", "256", "-f", "9", "--steps", "3", "--warmup", "1", "--text-keys", "64", "--num-layers", "2",
+                     "--decodes", "1")
+    assert rc == 0, se
+    line = json.loads(so.strip().splitlines()[-1])
+    assert line["unit"] == "steps/s" and line["value"] > 0 and line["tokens"] == 128 and line["layers"] == 2 and line["pcie_inclusive"] is True
+    assert line["vae_decode_ms_host_pointers"] > 0
+    import subprocess
+    ldd = subprocess.run(["ldd", CLI], capture_output=True, text=True).stdout
+    assert "libltxhip" in ldd and "torch" not in ldd and "python" not in ldd.lower()
+
+
+@pytest.mark.gpu
 def test_cli_connector_and_image_inputs_are_validated(ltx, oracle, tmp_path):
     """--gemma-hidden-states / --image-tensor (text-embedding connector and image-to-video inputs of this build): shape contracts
     are checked before any model work; the full-size models behind them are covered by test_connector_gpu / test_vae_encoder_gpu."""
