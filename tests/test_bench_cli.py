@@ -79,3 +79,17 @@ def test_two_rank_replica_line_rehearsed_on_one_gpu():
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["scaling"] == "weak" and "rehearsal" in out
     assert len(out["per_rank_ms_per_step"]) == 2 and out["value"] > 0
     assert abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) < 0.05 * out["value"]   # whole-job steps/s = ranks x steps / max time
+
+
+def test_cpu_baseline_legs_run_on_a_small_case():
+    """bench.py's cpu_baseline legs (the oracle timed on the host): the whole-unit path and the whole-blocks fallback, on a case small enough
+    for the CPU suite - the driver's bench line depends on these helpers never raising."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    r = bench.cpu_baseline(T=16, S=8, F=1, H=4, W=4, budget_s=1e9)          # whole step
+    assert r["extrapolated"] is False and r["kind"] == "port" and r["value"] > 0 and r["cores"] >= 1 and "ONE whole denoise step" in r["sample"]
+    r2 = bench.cpu_baseline(T=16, S=8, F=1, H=4, W=4, budget_s=1e-9)        # a host too slow for the budget: whole blocks, said so
+    assert r2["extrapolated"] is True and r2["value"] > 0 and "scaled x48/" in r2["sample"]
+    v = bench.cpu_baseline_vae(1, 2, 2, budget_s=1e9)
+    assert v["extrapolated"] is False and v["decode_ms"] > 0 and "ONE whole oracle.decode_video" in v["sample"]
