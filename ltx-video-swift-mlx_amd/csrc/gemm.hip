@@ -38,6 +38,7 @@ LTX_DEVFN int reflect_idx(int i, int n) {
 LTX_DEVFN int clamp_idx(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 // x / d == __umulhi(x, magic_u32(d)) for every x with x * d < 2^32 (d >= 2): the runtime divisors of the conv index arithmetic (W, H,
 // slab rows) as multiply-high constants - an integer division by a runtime value is ~35 VALU instructions, and a tile needs dozens
+// (d == 1 has no 32-bit constant - callers divide by 1 themselves; W, H >= 2 is checked by the launcher)
 LTX_DEVFN unsigned magic_u32(int d) { return (unsigned)((0x100000000ull + (unsigned long long)(d - 1)) / (unsigned long long)d); }
 
 // compile-time loop: the body gets an integral_constant, so accumulator arrays are only ever indexed with constants
