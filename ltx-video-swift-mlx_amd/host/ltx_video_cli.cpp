@@ -360,7 +360,6 @@ int run_bench(int argc, char** argv) {
         }
     };
     run_steps(warmup, 100);
-    std::vector<float> keep = latent;
     const auto t0 = std::chrono::steady_clock::now();
     run_steps(steps, 7000);
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
