@@ -50,13 +50,22 @@ final class PinParityTests: XCTestCase {
             width: meta["width"] as! Int, height: meta["height"] as! Int, numFrames: meta["frames"] as! Int, numSteps: 8, cfgScale: 1.0)
         config.seed = UInt64(meta["seed"] as! Int)
 
-        LTXDebug.isEnabled = true                                           // the diagnostics go through LTXDebug.log
-        var log: [String] = []
-        LTXDebug.sink = { log.append($0) }                                  // (or capture stdout - whichever the checkout offers)
+        // the diagnostics go through LTXDebug.log = print("[LTX] ...") on stdout (LTXVideo.swift:171-176): capture stdout in a file
+        LTXDebug.enableDebugMode()
+        let capture = FileManager.default.temporaryDirectory.appendingPathComponent("ltx_pin_stdout.txt")
+        FileManager.default.createFile(atPath: capture.path, contents: nil)
+        let saved = dup(STDOUT_FILENO)
+        let fh = try FileHandle(forWritingTo: capture)
+        fflush(stdout)
+        dup2(fh.fileDescriptor, STDOUT_FILENO)
+        defer { fflush(stdout); dup2(saved, STDOUT_FILENO); close(saved) }
         _ = try await pipeline.generateVideo(
             prompt: "pinning case", config: config,
             precomputedEmbeddings: .init(promptEmbeddings: emb, promptMask: mask), profile: true)
+        fflush(stdout)
+        dup2(saved, STDOUT_FILENO)
 
+        let log = try String(contentsOf: capture).split(separator: "\n").map(String.init)
         let got = log.filter { $0.contains("Step ") && $0.contains("vel mean=") }
         let want = try String(contentsOf: URL(fileURLWithPath: dir).appendingPathComponent("expected_oracle.txt"))
             .split(separator: "\n").filter { $0.contains("vel mean=") }.map(String.init)
