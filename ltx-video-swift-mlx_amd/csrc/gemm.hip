@@ -2392,6 +2392,43 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         const double e = (double)tiles / (double)(rounds * c.slots) * c.f * fill;
         if (e > be + 1e-9) { be = e; best = c.cfg; }
     }
+    // Ragged last round of the 192x256 kernel (round 4). With T = 9984 tokens the N = 4096 launches are 52 x 16 = 832 tiles = 3.25 rounds:
+    // the fourth round runs 64 workgroups, K-long, on a quarter of the chip (19 % of the launch). Rows are independent, so such a launch is
+    // split by rows into a head whose tiles are a whole number of rounds (48 row tiles = 768 tiles) and a tail (4 row tiles = 768 rows)
+    // that goes through this function again - as 128 tiles of 192x128 on the ring kernel it takes half the time of the K-long quarter
+    // round. Same kernels per output element as an unsplit launch of each part: bit-identical to those; LTX_GEMM_ROWSPLIT=0 = off (A/B).
+    static const bool rowsplit_on = !(getenv("LTX_GEMM_ROWSPLIT") && atoi(getenv("LTX_GEMM_ROWSPLIT")) == 0);
+    if (best == 75 && rowsplit_on && !a.ep.out_bf16_t && !a.ep.bias_m && a.split_k <= 1) {
+        const int ncu = device_cu_count();
+        const int tm = a.M / 192, tn = a.N / 256;
+        const long tiles = (long)tm * tn;
+        const long rem = tiles % ncu;
+        // the gate vector of a residual launch is indexed by m / rows_per_batch (or a row map): a row offset keeps that meaning only inside
+        // one batch element
+        const bool gate_ok = !a.ep.gate || a.ep.gate_rowmap || a.ep.rows_per_batch >= a.M;
+        if (tiles > ncu && rem > 0 && rem <= ncu / 2 && gate_ok) {
+            int g = tn, h = ncu;
+            while (h) { const int t = g % h; g = h; h = t; }  // gcd(tn, ncu)
+            const int step = ncu / g;                          // row tiles per whole number of rounds
+            const int tm_head = (tm / step) * step;
+            if (tm_head > 0 && tm_head < tm) {
+                auto rows = [&](int row0, int nrows) {
+                    GemmArgs s = a;
+                    GemmEpilogue& e = s.ep;
+                    s.A = a.A + (long)row0 * a.lda;
+                    s.M = nrows;
+                    if (e.out_f32) e.out_f32 += (long)row0 * e.ld_f32;
+                    if (e.out_bf16) e.out_bf16 += (long)row0 * e.ld_bf16;
+                    if (e.resid_src) e.resid_src += (long)row0 * e.ld_resid;
+                    if (e.gate_rowmap) e.gate_rowmap += row0;
+                    return s;
+                };
+                launch_gemm_bf16_cfg(rows(0, tm_head * 192), 75, stream);
+                launch_gemm_bf16(rows(tm_head * 192, a.M - tm_head * 192), stream);
+                return;
+            }
+        }
+    }
     launch_gemm_bf16_cfg(a, best, stream);
 }
 

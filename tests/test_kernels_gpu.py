@@ -564,3 +564,38 @@ def test_qknorm_rope(gpu_ctx, oracle, ltx, use_rope):
         ref = oracle.apply_split_rope(ref, cos, sin, heads)
     ref = ref.reshape(B * T, D)
     assert np.abs(as_f32(out) - ref).max() <= 2 ** -8 * np.abs(ref).max() + 1e-4
+
+
+def test_gemm_row_split_of_a_ragged_last_round(gpu_ctx):
+    """Round 4: a launch whose 192x256 tiling ends in a mostly empty round (T = 9984: 52 x 16 tiles = 3.25 rounds of 256 CUs) is split by rows
+    into whole rounds on the 192x256 kernel and a tail that takes the launcher's choice for its own shape. Exact on integer data against torch,
+    rows of the head bit-equal to the unsplit 192x256 launch, the gated-residual form (in place on the f32 stream, bf16 mirror) included."""
+    torch.manual_seed(5)
+    M, N, K = 9984, 4096, 256
+    A = torch.randint(-2, 3, (M, K), device="cuda").to(torch.bfloat16)
+    B = torch.randint(-2, 3, (N, K), device="cuda").to(torch.bfloat16)
+    bias = torch.randint(-4, 5, (N,), device="cuda").float()
+    ref = A.float() @ B.float().T + bias
+    out = torch.full((M, N), float("nan"), device="cuda")
+    gpu_ctx.op_gemm(A, B, bias, out_f32=out)                    # the launcher's choice: head + tail
+    whole = torch.full((M, N), float("nan"), device="cuda")
+    gpu_ctx.op_gemm(A, B, bias, tile_cfg=75, out_f32=whole)     # one 192x256 launch, 3.25 rounds
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(whole, ref)
+    Ar = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    Br = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+    o1 = torch.empty((M, N), device="cuda")
+    o2 = torch.empty((M, N), device="cuda")
+    gpu_ctx.op_gemm(Ar, Br, bias, out_f32=o1)
+    gpu_ctx.op_gemm(Ar, Br, bias, tile_cfg=75, out_f32=o2)
+    torch.cuda.synchronize()
+    assert torch.equal(o1[:9216], o2[:9216])                    # 48 row tiles = three whole rounds: the same kernel, the same bits
+    assert float((o1[9216:] - o2[9216:]).abs().max()) <= 1e-4 * float(o2.abs().max())
+    # gated residual, in place, with the bf16 mirror
+    x = torch.randint(-3, 4, (M, N), device="cuda").float()
+    gate = torch.randint(-2, 3, (1, N), device="cuda").float()
+    want = x + gate * ref
+    mirror = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    gpu_ctx.op_gemm_gated_residual(A, B, bias, gate, 1.0, x, mirror)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want) and torch.equal(mirror.float(), want.to(torch.bfloat16).float())
