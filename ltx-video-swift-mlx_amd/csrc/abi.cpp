@@ -1013,6 +1013,7 @@ int ltx_op_gemm_bf16(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* 
             tile_cfg %= 100;
             if (ctx->op_ws.ensure((size_t)g.split_k * M * N * 4)) HIP_CHECK(hipStreamSynchronize(ctx->stream));
             g.split_ws = ctx->op_ws.as<float>();
+            g.split_ws_elems = (long)(ctx->op_ws.bytes / 4);
         }
         if (tile_cfg < 0) launch_gemm_bf16(g, ctx->stream); else launch_gemm_bf16_cfg(g, tile_cfg, ctx->stream);
     });

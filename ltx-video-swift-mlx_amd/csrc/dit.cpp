@@ -241,7 +241,9 @@ void ensure_workspace(DiTModel* m, int B, int T, hipStream_t st) {
     m->ws_ada.ensure((size_t)8 * 6 * D * 4);
     m->ws_mod.ensure((size_t)8 * m->L * 6 * D * 4);
     m->ws_modout.ensure((size_t)8 * 2 * D * 4);
-    m->ws_splitk.ensure((size_t)8 << 22);  // 8 M floats: split-K partials of the few-tile GEMMs at small token counts
+    // 8 M floats: split-K partials of the few-tile GEMMs at small token counts; two slices of [rows][D] where a one-round launch may run
+    // as two K halves of the 192x256 kernel
+    m->ws_splitk.ensure(std::max((size_t)8 << 22, rows <= 1536 ? (size_t)2 * rows * D * 4 : (size_t)0));
     m->ws_rows = (int)rows;
     m->ws_B = B;
     m->ws_Tpad = Tpad;

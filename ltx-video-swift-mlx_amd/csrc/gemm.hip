@@ -1814,12 +1814,20 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_dtl(const GemmArgs g)
     const int ao = (row0 * (int)g.lda + ((pch ^ ((row0 >> 1) & 7)) << 3)) * 2;
     const int bo = (row0 * (int)g.ldb + ((pch ^ ((row0 >> 1) & 7)) << 3)) * 2;
     const uint32_t sa = (uint32_t)(32 * g.lda * 2), sb = (uint32_t)(32 * g.ldb * 2);
-    const bf16_t* At = g.A + (long)m0 * g.lda;
-    const bf16_t* Bt = g.B + (long)n0 * g.ldb;
+    // deterministic split-K (round 4): grid.y = K range; each range writes its raw partial tile to its workspace slice, the finish pass
+    // adds the slices in order and applies the epilogue
+    int kt0 = 0, nkt = g.K / BK;
+    if (g.split_k > 1) {
+        const int z = blockIdx.y;
+        kt0 = (int)((long)nkt * z / g.split_k);
+        nkt = (int)((long)nkt * (z + 1) / g.split_k) - kt0;
+    }
+    const bf16_t* At = g.A + (long)m0 * g.lda + (long)kt0 * BK;
+    const bf16_t* Bt = g.B + (long)n0 * g.ldb + (long)kt0 * BK;
     const uint32_t alo = (uint32_t)(uintptr_t)At, ahi = (uint32_t)((uintptr_t)At >> 32);
     const uint32_t blo = (uint32_t)(uintptr_t)Bt, bhi = (uint32_t)((uintptr_t)Bt >> 32);
-    const uint32_t arec = (uint32_t)(((long)(BM - 1) * g.lda + g.K) * 2), brec = (uint32_t)(((long)(BN - 1) * g.ldb + g.K) * 2);
-    const uint32_t nk = (uint32_t)(g.K / BK);
+    const uint32_t arec = (uint32_t)(((long)(BM - 1) * g.lda + (long)nkt * BK) * 2), brec = (uint32_t)(((long)(BN - 1) * g.ldb + (long)nkt * BK) * 2);
+    const uint32_t nk = (uint32_t)nkt;
     const uint32_t wlds = (uint32_t)wave * 1024u;
     const int frow = lane & 15, fsw = (lane >> 1) & 7;
     const int foff0 = frow * ROW_BYTES + ((((lane >> 4) + 0) ^ fsw) << 4);
@@ -1852,8 +1860,22 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_dtl(const GemmArgs g)
     float* scr = (float*)(smem + wave * (32 * WN * 4));
     // LDS byte address of this lane's first scratch element (the dynamic LDS of this kernel starts at 0, as the main loop assumes)
     const unsigned scr_lane = (unsigned)(wave * (32 * WN * 4) + ((((lane >> 4) * 4) * WN + (lane & 15)) * 4));
-    const GemmEpilogue& ep = g.ep;
     const int gn = n0 + wc * WN + (lane % LPR) * 4;
+    if (g.split_k > 1) {  // raw partial tile -> this K range's slice of the workspace
+        float* ws = g.split_ws + (long)blockIdx.y * g.M * g.N;
+        static_for<0, 3>([&](auto grp_c) {
+            constexpr int grp = decltype(grp_c)::value;
+#include "gemm_asm_192x256_dump.inc"
+#pragma unroll 4
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int row = it * RPI + lane / LPR;
+                *(f32x4*)(ws + (long)(m0 + wr * WM + grp * 32 + row) * g.N + gn) = *(const f32x4*)(scr + row * WN + (lane % LPR) * 4);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        });
+        return;
+    }
+    const GemmEpilogue& ep = g.ep;
     const f32x4 bias = ep.bias_n ? *(const f32x4*)(ep.bias_n + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
     const float* rbase = ep.resid_src ? ep.resid_src : ep.out_f32;
     const long rld = ep.resid_src ? ep.ld_resid : ep.ld_f32;
@@ -2099,8 +2121,9 @@ static void launch_asm(const GemmArgs& a, hipStream_t stream) {
 
 static bool gemm_dtl_takes(const GemmArgs& a) {
     // lda / ldb % 8: the LDS-DMA pieces are 16-byte loads; the epilogue of this kernel has no clip / PixelNorm / tile-window form
-    return !a.conv && a.split_k <= 1 && a.M % 192 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 64 && !a.ep.d2s && !a.ep.out_bf16_t &&
-           a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.ep.pn_out && !a.ep.clip01 && a.tile_count == 0 && a.win_rows == 0;
+    return !a.conv && a.M % 192 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 64 && !a.ep.d2s && !a.ep.out_bf16_t &&
+           a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.ep.pn_out && !a.ep.clip01 && a.tile_count == 0 && a.win_rows == 0 &&
+           (a.split_k <= 1 || (a.split_ws && a.split_k <= a.K / 64 && (long)a.split_k * a.M * a.N <= a.split_ws_elems));
 }
 static void launch_dtl(const GemmArgs& a, hipStream_t stream) {
     LTX_REQUIRE(gemm_dtl_takes(a), "gemm: the 192x256 kernel needs a dense A.B^T with M %% 192 == 0, N %% 256 == 0, K %% 64 == 0 (M=%d N=%d K=%d)",
@@ -2108,8 +2131,14 @@ static void launch_dtl(const GemmArgs& a, hipStream_t stream) {
     constexpr int smem = (2 * 192 + 3 * 256) * ROW_BYTES;  // two activation slots, three weight slots
     static PerDeviceOnce attr_set;
     attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_kernel_dtl, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
-    hipLaunchKernelGGL(gemm_bf16_kernel_dtl, dim3((a.M / 192) * (a.N / 256)), dim3(256), smem, stream, a);
+    hipLaunchKernelGGL(gemm_bf16_kernel_dtl, dim3((a.M / 192) * (a.N / 256), a.split_k > 1 ? a.split_k : 1), dim3(256), smem, stream, a);
     HIP_CHECK(hipGetLastError());
+    if (a.split_k > 1) {
+        const long total = (long)a.M * (a.N / 4);
+        const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+        HIP_CHECK(hipGetLastError());
+    }
 }
 
 #ifdef LTX_EXPERIMENTS
@@ -2192,7 +2221,7 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
                     "gemm: the transposed bf16 output takes bias_n only, no split-K, ld %% 4 == 0 (ld=%ld M=%d cfg=%d)", e.ld_bf16_t, a.M, cfg);
     }
     validate(a);
-    LTX_REQUIRE(a.split_k <= 1 || (cfg >= 20 && cfg < 32) || cfg == 90, "gemm: split-K needs a ring kernel or the weight-streaming kernel (tile cfg %d)", cfg);
+    LTX_REQUIRE(a.split_k <= 1 || (cfg >= 20 && cfg < 32) || cfg == 90 || cfg == 75, "gemm: split-K needs a ring kernel, the 192x256 kernel or the weight-streaming kernel (tile cfg %d)", cfg);
     LTX_REQUIRE(!a.Bq || cfg == 90 || cfg == 29 || cfg == 30, "gemm: quantised codes are read by the few-row ring kernel only (tile cfg %d)", cfg);
     ProfScope prof(a.conv ? PROF_CONV : PROF_GEMM, 2.0 * (a.win_rows ? a.win_rows : a.M) * a.N * a.K, stream);  // a tile window's rows
     // cfg 0..2: v1 (2-stage, one barrier + full drain per K-tile); cfg 10..: v2 (ring + counted vmcnt)
@@ -2402,6 +2431,23 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
             }
             launch_gemm_bf16_cfg(b, cfg, stream);
             return;
+        }
+        // At most one round of 192x128 ring tiles with a long reduction (the FFN's second GEMM at 1536 tokens: 256 tiles, K = 16384) runs as
+        // K ranges of the 192x256 kernel, whose main loop reads half the fragments per MFMA, plus the finish pass: 36.46 -> 35.75 ms per
+        // headline step on one box. LTX_DTL_SPLITK=0 turns it off; LTX_DTL_SPLITK_MINK = least K per range (8192).
+        static const bool dtl_split = !(getenv("LTX_DTL_SPLITK") && atoi(getenv("LTX_DTL_SPLITK")) == 0);
+        static const int dtl_mink = getenv("LTX_DTL_SPLITK_MINK") ? atoi(getenv("LTX_DTL_SPLITK_MINK")) : 8192;
+        if (dtl_split && !a.Bq && a.M % 192 == 0 && a.N % 256 == 0 && dtl_mink >= 64) {
+            const long t1 = (long)(a.M / 192) * (a.N / 256);
+            const int ncu = device_cu_count();
+            long s = ncu / t1;
+            if (s > a.K / dtl_mink) s = a.K / dtl_mink;
+            while (s > 1 && s * a.M * a.N > a.split_ws_elems) --s;
+            b.split_k = (int)s;
+            if (s >= 2 && s * t1 > ncu / 2 && gemm_dtl_takes(b)) {
+                launch_gemm_bf16_cfg(b, 75, stream);
+                return;
+            }
         }
         b.split_k = 1;
         b.split_ws = nullptr;

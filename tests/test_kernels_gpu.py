@@ -599,3 +599,31 @@ def test_gemm_row_split_of_a_ragged_last_round(gpu_ctx):
     gpu_ctx.op_gemm_gated_residual(A, B, bias, gate, 1.0, x, mirror)
     torch.cuda.synchronize()
     assert torch.equal(x, want) and torch.equal(mirror.float(), want.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("splits,K", [(2, 1024), (3, 448), (2, 64 * 5)])
+def test_gemm_192x256_split_k(gpu_ctx, splits, K):
+    """Round 4: deterministic split-K on the 192x256 kernel (grid.y = K range, raw partial tiles to the workspace, the ring kernels' finish
+    pass applies the epilogue): exact on integer data (uneven K ranges included), bias + GELU applied once, bit-repeatable."""
+    torch.manual_seed(7)
+    M, N = 384, 1024
+    A = torch.randint(-2, 3, (M, K), device="cuda").to(torch.bfloat16)
+    B = torch.randint(-2, 3, (N, K), device="cuda").to(torch.bfloat16)
+    bias = torch.randint(-4, 5, (N,), device="cuda").float()
+    ref = A.float() @ B.float().T + bias
+    out = torch.full((M, N), float("nan"), device="cuda")
+    mir = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    gpu_ctx.op_gemm(A, B, bias, tile_cfg=splits * 100 + 75, out_f32=out, out_bf16=mir)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(mir.float(), ref.to(torch.bfloat16).float())
+    Ar = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    Br = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+    o1 = torch.empty((M, N), device="cuda")
+    o2 = torch.empty((M, N), device="cuda")
+    o3 = torch.empty((M, N), device="cuda")
+    gpu_ctx.op_gemm(Ar, Br, bias, act=1, tile_cfg=splits * 100 + 75, out_f32=o1)
+    gpu_ctx.op_gemm(Ar, Br, bias, act=1, tile_cfg=splits * 100 + 75, out_f32=o2)
+    gpu_ctx.op_gemm(Ar, Br, bias, act=1, tile_cfg=75, out_f32=o3)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+    assert float((o1 - o3).abs().max()) <= 1e-4 * float(o3.abs().max()) + 1e-5
