@@ -478,6 +478,14 @@ int ltx_op_value_projection_t(ltx_ctx* ctx, const uint16_t* X, long ldx, int tok
 int ltx_op_gemm_bf16_gated_residual(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb,
                                     const float* bias, const float* gate, float gate_scalar, int M, int N, int K,
                                     float* x, long ldx, uint16_t* mirror_bf16, long ld_mirror);
+/* the same update followed by the adaLN pass over the updated rows: xn[m][:] = bf16(rms_norm(x[m][:]) * (1 + scale) + shift)
+ * (LTXTransformerBlock.swift:72-92: a block's last residual update and the next block's first norm-modulate). fused != 0: the way the
+ * DiT graph launches the pair (the norm rides on the GEMM's split-K finish pass where the launch has one); fused == 0: two launches.
+ * Both give the same bits. */
+int ltx_op_gemm_bf16_gated_residual_norm(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                                         const float* bias, const float* gate, float gate_scalar, int M, int N, int K,
+                                         float* x, long ldx, const float* scale, const float* shift, float eps,
+                                         uint16_t* xn, long ldxn, int fused);
 /* out[m][n] = sum_k in_act(a[m][k]) W[n][k] + bias[n], f32 x bf16 -> f32, M <= 8 */
 int ltx_op_gemv_f32(ltx_ctx* ctx, const float* a, long lda, const uint16_t* W, long ldw, const float* bias, float* out,
                     long ldo, int M, int N, int K, int in_act);

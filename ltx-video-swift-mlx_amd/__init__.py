@@ -623,6 +623,13 @@ class Context:
                                                      gate_scalar, M, N, K, _ptr(x), x.stride(0), _ptr(mirror),
                                                      mirror.stride(0) if mirror is not None else 0))
 
+    def op_gemm_gated_residual_norm(self, A, B, bias, gate, gate_scalar, x, scale, shift, xn, eps=1e-6, fused=True):
+        M, K = A.shape
+        N = B.shape[0]
+        self._ck(lib.ltx_op_gemm_bf16_gated_residual_norm(self._h, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(bias), _ptr(gate),
+                                                          gate_scalar, M, N, K, _ptr(x), x.stride(0), _ptr(scale), _ptr(shift), eps,
+                                                          _ptr(xn), xn.stride(0), int(fused)))
+
     def op_gemv(self, a, W, bias, out, in_act=0):
         M, K = a.shape
         N = W.shape[0]

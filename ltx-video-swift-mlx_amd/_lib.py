@@ -164,6 +164,7 @@ SIGNATURES = {
     "ltx_op_gemm_bf16": (_i, [_vp, _vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _l]),
     "ltx_op_value_projection_t": (_i, [_vp, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _l]),
     "ltx_op_gemm_bf16_gated_residual": (_i, [_vp, _vp, _l, _vp, _l, _vp, _vp, _f, _i, _i, _i, _vp, _l, _vp, _l]),
+    "ltx_op_gemm_bf16_gated_residual_norm": (_i, [_vp, _vp, _l, _vp, _l, _vp, _vp, _f, _i, _i, _i, _vp, _l, _vp, _vp, _f, _vp, _l, _i]),
     "ltx_op_gemv_f32": (_i, [_vp, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i]),
     "ltx_op_attention": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _f, _vp]),
     "ltx_attention_key_splits": (_i, [_i, _i, _i, _i]),

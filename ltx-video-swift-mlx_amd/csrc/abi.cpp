@@ -1077,6 +1077,36 @@ int ltx_op_gemm_bf16_gated_residual(ltx_ctx* ctx, const uint16_t* A, long lda, c
     });
 }
 
+int ltx_op_gemm_bf16_gated_residual_norm(ltx_ctx* ctx, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                                         const float* bias, const float* gate, float gate_scalar, int M, int N, int K,
+                                         float* x, long ldx, const float* scale, const float* shift, float eps,
+                                         uint16_t* xn, long ldxn, int fused) {
+    if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;
+    return guarded(ctx, [&] {
+        LTX_REQUIRE(A && B && x && scale && shift && xn, "ltx_op_gemm_bf16_gated_residual_norm: null argument");
+        GemmArgs g;
+        g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+        g.ep.bias_n = bias;
+        g.ep.out_f32 = x; g.ep.ld_f32 = ldx;
+        g.ep.resid = 1;
+        g.ep.gate = gate; g.ep.gate_bstride = 0; g.ep.rows_per_batch = M; g.ep.gate_scalar = gate_scalar;
+        // the DiT graph's launches bring a workspace and leave the split to the launcher
+        if (ctx->op_ws.ensure((size_t)2 * M * N * 4)) HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        g.split_k = 0;
+        g.split_ws = ctx->op_ws.as<float>();
+        g.split_ws_elems = (long)(ctx->op_ws.bytes / 4);
+        NormAfter na;
+        na.scale = scale; na.shift = shift; na.mod_bstride = 0; na.rows_per_batch = M;
+        na.out = xn; na.ldo = ldxn; na.eps = eps; na.norm_kind = LTX_NORM_RMS;
+        if (fused) {
+            launch_gemm_bf16(g, ctx->stream, &na);
+        } else {
+            launch_gemm_bf16(g, ctx->stream);
+            launch_norm_mod(x, ldx, scale, shift, 0, M, xn, ldxn, M, N, LTX_NORM_RMS, eps, 0, ctx->stream);
+        }
+    });
+}
+
 int ltx_op_gemv_f32(ltx_ctx* ctx, const float* a, long lda, const uint16_t* W, long ldw, const float* bias, float* out,
                     long ldo, int M, int N, int K, int in_act) {
     if (!ctx) return LTX_ERR_INVALID_CONFIGURATION;

@@ -430,11 +430,13 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     }
     const long mod_bs = (long)L * 6 * D;  // batch stride of mod
 
+    bool xn_ready = false;  // the previous block's last GEMM launch already wrote this block's first adaLN rows (NormAfter)
     for (int l = 0; l < L; ++l) {
         const DiTBlock& blk = m->blocks[l];
         const float* ml = mod + (long)l * 6 * D;  // rows: 0 shift_msa 1 scale_msa 2 gate_msa 3 shift_mlp 4 scale_mlp 5 gate_mlp
         if (!blk.skip_attn) {
-            launch_norm_mod(x, D, ml + 1 * D, ml + 0 * D, mod_bs, T, xn, D, (int)rows, D, LTX_NORM_RMS, eps, l == 0 ? 1 : 0, st, rmap);
+            if (!xn_ready) launch_norm_mod(x, D, ml + 1 * D, ml + 0 * D, mod_bs, T, xn, D, (int)rows, D, LTX_NORM_RMS, eps, l == 0 ? 1 : 0, st, rmap);
+            xn_ready = false;
             // Sequence parallelism on the native transport: the V^T gather (and its interleave) runs on the side stream under
             // the q|k projection and its norm + RoPE pass; only the K gather stays on the critical path. Same kernels, same
             // operands, same order of every reduction: the bits do not depend on which stream carried a collective.
@@ -541,7 +543,24 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             e2.gate_rowmap = rmap;
             // no bf16 mirror here: the next reader of xb is a cross-attention q projection, and by then either this block's successor has
             // rewritten it (attention-out epilogue) or, when that block skips self-attention, the cast above has
-            gemm_linear(ffh, 4 * D, blk.ff2, (int)rows, e2, st, sk);
+            // the next block opens with the adaLN pass over the stream this launch finishes: it rides on the launch (gemm.h NormAfter)
+            if (l + 1 < L && !m->blocks[l + 1].skip_attn) {
+                const float* mn = mod + (long)(l + 1) * 6 * D;
+                NormAfter na;
+                na.scale = mn + 1 * D;
+                na.shift = mn + 0 * D;
+                na.mod_bstride = mod_bs;
+                na.rows_per_batch = T;
+                na.out = xn;
+                na.ldo = D;
+                na.eps = eps;
+                na.norm_kind = LTX_NORM_RMS;
+                na.row_map = rmap;
+                gemm_linear(ffh, 4 * D, blk.ff2, (int)rows, e2, st, sk, &na);
+                xn_ready = true;
+            } else {
+                gemm_linear(ffh, 4 * D, blk.ff2, (int)rows, e2, st, sk);
+            }
         }
     }
     // 6. output head: LayerNorm (no affine) * (1+scale) + shift -> proj_out (LTXTransformer.swift:208-224)

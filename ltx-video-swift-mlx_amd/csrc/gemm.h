@@ -115,6 +115,24 @@ int gemm_suggest_split_k(int M, int N, int K);
 
 // Launches on `stream`. Picks the tile shape from (M,N). Throws LtxError on invalid shapes.
 void launch_gemm_bf16(const GemmArgs& args, hipStream_t stream);
+
+// The adaLN pass that reads this GEMM's f32 output next (launch_norm_mod's arguments; x = args.ep.out_f32): handed to the launcher so that a
+// launch which ends in a split-K finish pass - a row-wise pass over the same stream - applies the norm there instead of in a launch of
+// its own (round 4: the FFN's second GEMM + the next block's first adaLN pass). Every other launch runs launch_norm_mod behind the GEMM:
+// the caller never launches the pass itself.
+struct NormAfter {
+    const float* scale = nullptr;
+    const float* shift = nullptr;
+    long mod_bstride = 0;
+    int rows_per_batch = 1;
+    bf16_t* out = nullptr;
+    long ldo = 0;
+    float eps = 1e-6f;
+    int norm_kind = 0;  // LTX_NORM_RMS
+    int round_norm_bf16 = 0;
+    const int32_t* row_map = nullptr;
+};
+void launch_gemm_bf16(const GemmArgs& args, hipStream_t stream, const NormAfter* norm_after);
 // can a launch of this shape take B as 8-bit codes (GemmArgs::Bq)?
 bool gemm_takes_codes(int M, int N, int K);
 bool gemm_fewrow_takes(int M, int N, int K, int splits);

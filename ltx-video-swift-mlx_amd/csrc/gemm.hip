@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "gemm.h"
+#include "elementwise.h"
 
 #include <stdlib.h>
 #include "runtime.h"
@@ -1771,6 +1772,98 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     }
 }
 
+// split-K finish of R whole rows of N = 4096 per workgroup + the RMS norm / adaLN modulation of the finished rows (NormAfter): the rows
+// are in registers when their f32 values are stored, so the pass that would read them back next is applied here. The finish arithmetic is
+// splitk_finish_kernel's and the norm arithmetic norm_mod_rows_kernel's (elementwise.hip), in the same order: the bf16 rows are
+// bit-identical to the two launches (tests/test_kernels_gpu.py).
+template <int R>
+__global__ __launch_bounds__(256) void splitk_finish_norm_kernel(const float* __restrict__ ws, int S, int M, GemmEpilogue ep, NormAfter na) {
+    constexpr int N = 4096, NV = 4;
+    __shared__ float red[4][R];
+    const int row0 = blockIdx.x * R;
+    const long nb = row0 / na.rows_per_batch;  // the launcher guarantees that the R rows lie in one batch element
+    const float* sc = na.scale + nb * na.mod_bstride;
+    const float* sh = na.shift + nb * na.mod_bstride;
+    f32x4 v[R][NV], s4[NV], h4[NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long m = (row0 + r) < M ? (row0 + r) : M - 1;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (threadIdx.x + j * 256) * 4;
+            f32x4 t = *(const f32x4*)(ws + m * N + c);
+            for (int z = 1; z < S; ++z) t += *(const f32x4*)(ws + ((long)z * M + m) * N + c);
+            if (ep.bias_n) t += *(const f32x4*)(ep.bias_n + c);
+            if (ep.resid) {
+                const float* rs = (ep.resid_src ? ep.resid_src + m * ep.ld_resid : ep.out_f32 + m * ep.ld_f32) + c;
+                const f32x4 r4 = *(const f32x4*)rs;
+                f32x4 gt = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
+                if (ep.gate) gt = *(const f32x4*)(ep.gate + (m / ep.rows_per_batch) * ep.gate_bstride + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = r4[e] + gt[e] * t[e];
+            }
+            v[r][j] = t;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        s4[j] = *(const f32x4*)(sc + (threadIdx.x + j * 256) * 4);
+        h4[j] = *(const f32x4*)(sh + (threadIdx.x + j * 256) * 4);
+    }
+    float ss[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a += v[r][j][e] * v[r][j][e];
+        ss[r] = wave_reduce_sum(a);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) red[w][r] = ss[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (row0 + r >= M) break;
+        const long m = row0 + r;
+        const float ms = (red[0][r] + red[1][r] + red[2][r] + red[3][r]) / (float)N;
+        const float rstd = rsqrtf(ms + na.eps);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (threadIdx.x + j * 256) * 4;
+            if (ep.out_f32) *(f32x4*)(ep.out_f32 + m * ep.ld_f32 + c) = v[r][j];
+            if (ep.out_bf16) {
+                uint2 pk;
+                pk.x = pack_bf16x2(v[r][j][0], v[r][j][1]);
+                pk.y = pack_bf16x2(v[r][j][2], v[r][j][3]);
+                *(uint2*)(ep.out_bf16 + m * ep.ld_bf16 + c) = pk;
+            }
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = v[r][j][e] * rstd;
+                if (na.round_norm_bf16) y[e] = bf16_to_f32(f32_to_bf16(y[e]));
+                y[e] = y[e] * (1.0f + s4[j][e]) + h4[j][e];
+            }
+            uint2 pk;
+            pk.x = pack_bf16x2(y[0], y[1]);
+            pk.y = pack_bf16x2(y[2], y[3]);
+            *(uint2*)(na.out + m * na.ldo + c) = pk;
+        }
+    }
+}
+// what splitk_finish_norm_kernel covers of the two passes' options
+static bool finish_takes_norm(const GemmArgs& a, const NormAfter& na) {
+    const GemmEpilogue& e = a.ep;
+    return a.N == 4096 && e.out_f32 && !e.out_bf16_t && !e.bias_m && e.act == LTX_ACT_NONE && !e.round_bf16 && !e.gate_rowmap && !e.d2s &&
+           !e.pn_out && na.norm_kind == 0 && na.scale && na.shift && !na.row_map && na.out && na.ldo % 4 == 0 && e.ld_f32 % 4 == 0 &&
+           na.rows_per_batch % 2 == 0 && (!e.gate || e.rows_per_batch % 2 == 0) && a.M % 2 == 0;
+}
+
 template <int BM, int BN, bool CONV>
 void launch_one(const GemmArgs& a, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
@@ -2125,7 +2218,7 @@ static bool gemm_dtl_takes(const GemmArgs& a) {
            a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.ep.pn_out && !a.ep.clip01 && a.tile_count == 0 && a.win_rows == 0 &&
            (a.split_k <= 1 || (a.split_ws && a.split_k <= a.K / 64 && (long)a.split_k * a.M * a.N <= a.split_ws_elems));
 }
-static void launch_dtl(const GemmArgs& a, hipStream_t stream) {
+static void launch_dtl(const GemmArgs& a, hipStream_t stream, const NormAfter* na = nullptr) {
     LTX_REQUIRE(gemm_dtl_takes(a), "gemm: the 192x256 kernel needs a dense A.B^T with M %% 192 == 0, N %% 256 == 0, K %% 64 == 0 (M=%d N=%d K=%d)",
                 a.M, a.N, a.K);
     constexpr int smem = (2 * 192 + 3 * 256) * ROW_BYTES;  // two activation slots, three weight slots
@@ -2134,10 +2227,17 @@ static void launch_dtl(const GemmArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(gemm_bf16_kernel_dtl, dim3((a.M / 192) * (a.N / 256), a.split_k > 1 ? a.split_k : 1), dim3(256), smem, stream, a);
     HIP_CHECK(hipGetLastError());
     if (a.split_k > 1) {
-        const long total = (long)a.M * (a.N / 4);
-        const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+        if (na) {
+            LTX_REQUIRE(finish_takes_norm(a, *na), "gemm: the fused finish + norm pass needs N = 4096, an RMS norm with modulation and no row maps");
+            hipLaunchKernelGGL(splitk_finish_norm_kernel<2>, dim3(a.M / 2), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.ep, *na);
+        } else {
+            const long total = (long)a.M * (a.N / 4);
+            const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+            hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+        }
         HIP_CHECK(hipGetLastError());
+    } else {
+        LTX_REQUIRE(!na, "gemm: a norm pass can only ride on a split-K finish");
     }
 }
 
@@ -2308,6 +2408,43 @@ int gemm_suggest_split_k(int M, int N, int K) {
     return s < 1 ? 1 : (int)s;
 }
 
+// At most one round of 192x128 ring tiles with a long reduction (the FFN's second GEMM at 1536 tokens: 256 tiles, K = 16384) runs as K
+// ranges of the 192x256 kernel, whose main loop reads half the fragments per MFMA, plus the finish pass: 36.46 -> 35.75 ms per headline
+// step on one box. -> number of ranges, 0 = not this launch. LTX_DTL_SPLITK=0 turns it off; LTX_DTL_SPLITK_MINK = least K per range
+// (8192; with 2048 the three K = 4096 launches of a block split too and the step LOSES 1.3 ms).
+static int dtl_split_for(const GemmArgs& a) {
+    static const bool dtl_split = !(getenv("LTX_DTL_SPLITK") && atoi(getenv("LTX_DTL_SPLITK")) == 0);
+    static const int dtl_mink = getenv("LTX_DTL_SPLITK_MINK") ? atoi(getenv("LTX_DTL_SPLITK_MINK")) : 8192;
+    if (!dtl_split || dtl_mink < 64 || a.conv || a.Bq || !a.split_ws || a.split_k != 0 || a.M % 192 != 0 || a.N % 256 != 0 || a.ep.d2s) return 0;
+    if (gemm_suggest_split_k(a.M, a.N, a.K) > 1) return 0;  // fewer than 160 ring tiles: the ring kernel's own split-K
+    const long t1 = (long)(a.M / 192) * (a.N / 256);
+    const int ncu = device_cu_count();
+    long s = ncu / t1;
+    if (s > a.K / dtl_mink) s = a.K / dtl_mink;
+    while (s > 1 && s * a.M * a.N > a.split_ws_elems) --s;
+    if (s < 2 || s * t1 <= ncu / 2) return 0;
+    GemmArgs b = a;
+    b.split_k = (int)s;
+    return gemm_dtl_takes(b) ? (int)s : 0;
+}
+
+void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream, const NormAfter* na) {
+    LTX_REQUIRE(na && a.ep.out_f32 && !a.conv, "gemm: norm_after needs a dense launch with an f32 output");
+    static const bool fuse_on = !(getenv("LTX_FINISH_NORM") && atoi(getenv("LTX_FINISH_NORM")) == 0);  // A/B hook
+    const int s2 = (fuse_on && finish_takes_norm(a, *na)) ? dtl_split_for(a) : 0;
+    if (s2) {
+        GemmArgs b = a;
+        b.split_k = s2;
+        validate(b);
+        ProfScope prof(PROF_GEMM, 2.0 * a.M * a.N * a.K, stream);
+        launch_dtl(b, stream, na);
+        return;
+    }
+    launch_gemm_bf16(a, stream);
+    launch_norm_mod(a.ep.out_f32, a.ep.ld_f32, na->scale, na->shift, na->mod_bstride, na->rows_per_batch, na->out, na->ldo, a.M, a.N, na->norm_kind,
+                    na->eps, na->round_norm_bf16, stream, na->row_map);
+}
+
 void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     // A/B hook: LTX_GEMM_GROUP_M="N:g,..." overrides the supertile height of dense launches with that N (tile_coords)
     GemmArgs a = a_in;
@@ -2432,22 +2569,10 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
             launch_gemm_bf16_cfg(b, cfg, stream);
             return;
         }
-        // At most one round of 192x128 ring tiles with a long reduction (the FFN's second GEMM at 1536 tokens: 256 tiles, K = 16384) runs as
-        // K ranges of the 192x256 kernel, whose main loop reads half the fragments per MFMA, plus the finish pass: 36.46 -> 35.75 ms per
-        // headline step on one box. LTX_DTL_SPLITK=0 turns it off; LTX_DTL_SPLITK_MINK = least K per range (8192).
-        static const bool dtl_split = !(getenv("LTX_DTL_SPLITK") && atoi(getenv("LTX_DTL_SPLITK")) == 0);
-        static const int dtl_mink = getenv("LTX_DTL_SPLITK_MINK") ? atoi(getenv("LTX_DTL_SPLITK_MINK")) : 8192;
-        if (dtl_split && !a.Bq && a.M % 192 == 0 && a.N % 256 == 0 && dtl_mink >= 64) {
-            const long t1 = (long)(a.M / 192) * (a.N / 256);
-            const int ncu = device_cu_count();
-            long s = ncu / t1;
-            if (s > a.K / dtl_mink) s = a.K / dtl_mink;
-            while (s > 1 && s * a.M * a.N > a.split_ws_elems) --s;
-            b.split_k = (int)s;
-            if (s >= 2 && s * t1 > ncu / 2 && gemm_dtl_takes(b)) {
-                launch_gemm_bf16_cfg(b, 75, stream);
-                return;
-            }
+        if (const int s2 = dtl_split_for(a)) {
+            b.split_k = s2;
+            launch_gemm_bf16_cfg(b, 75, stream);
+            return;
         }
         b.split_k = 1;
         b.split_ws = nullptr;

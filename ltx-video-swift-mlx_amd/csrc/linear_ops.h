@@ -28,7 +28,7 @@ inline void set_weights(GemmArgs& g, const LinearW& w, bool codes, hipStream_t s
 }
 
 // Y = X . W^T (+ bias unless the epilogue brings its own)
-inline void gemm_linear(const bf16_t* A, long lda, const LinearW& w, int M, GemmEpilogue ep, hipStream_t s, SplitWs ws = {}) {
+inline void gemm_linear(const bf16_t* A, long lda, const LinearW& w, int M, GemmEpilogue ep, hipStream_t s, SplitWs ws = {}, const NormAfter* norm_after = nullptr) {
     GemmArgs g;
     g.A = A;
     g.lda = lda;
@@ -44,7 +44,7 @@ inline void gemm_linear(const bf16_t* A, long lda, const LinearW& w, int M, Gemm
         g.split_ws = ws.p;
         g.split_ws_elems = ws.elems;
     }
-    launch_gemm_bf16(g, s);
+    if (norm_after) launch_gemm_bf16(g, s, norm_after); else launch_gemm_bf16(g, s);
 }
 
 // V^T[d][token] = W_v[d][:] . X[token][:] + b_v[d]  (swapped operands -> the attention kernel's Vt layout)

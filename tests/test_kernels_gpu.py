@@ -627,3 +627,32 @@ def test_gemm_192x256_split_k(gpu_ctx, splits, K):
     torch.cuda.synchronize()
     assert torch.equal(o1, o2)
     assert float((o1 - o3).abs().max()) <= 1e-4 * float(o3.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("M,K", [(1536, 16384), (1536, 4096), (384, 16384)])
+def test_gated_residual_with_the_next_norm_on_its_finish_pass(gpu_ctx, M, K):
+    """Round 4: the FFN's second GEMM at 1536 tokens ends in a split-K finish pass, and the next block's adaLN pass rides on it
+    (NormAfter, gemm.h). The pair launched the DiT graph's way and as two launches give the same bits on the f32 stream and on the bf16
+    norm rows; launches without a finish pass (K = 4096; 384 rows: the ring kernel's own split) take the two-launch path inside the
+    launcher. Against torch: the update within the bf16-product tolerance, the norm rows within bf16 rounding of torch's norm of x."""
+    torch.manual_seed(11)
+    N = 4096
+    A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    B = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda") * 0.1
+    gate = torch.randn(1, N, device="cuda") * 0.5
+    scale = torch.randn(N, device="cuda") * 0.2
+    shift = torch.randn(N, device="cuda") * 0.2
+    x0 = torch.randn(M, N, device="cuda")
+    xa, xb_ = x0.clone(), x0.clone()
+    na = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    nb = torch.empty_like(na)
+    gpu_ctx.op_gemm_gated_residual_norm(A, B, bias, gate, 1.0, xa, scale, shift, na, fused=True)
+    gpu_ctx.op_gemm_gated_residual_norm(A, B, bias, gate, 1.0, xb_, scale, shift, nb, fused=False)
+    torch.cuda.synchronize()
+    assert torch.equal(xa, xb_)
+    assert torch.equal(na.view(torch.int16), nb.view(torch.int16))
+    want = x0 + gate * (A.float() @ B.float().T + bias)
+    assert float((xa - want).abs().max()) <= 2e-3 * float(want.abs().max())
+    nrm = xa * torch.rsqrt((xa * xa).mean(dim=1, keepdim=True) + 1e-6) * (1 + scale) + shift
+    assert float((na.float() - nrm).abs().max()) <= 2 ** -7 * float(nrm.abs().max())
