@@ -69,6 +69,9 @@ def main():
             tot_f += 2.0 * 1024.0 * sum(f)
             tot_w += 1024.0 * sum(w)
             n_gemm += max(len(f), len(w))
+        elif k.startswith("splitk_finish"):  # the finish pass belongs to its GEMM launch: bytes counted, no launch of its own
+            tot_f += 2.0 * 1024.0 * sum(f)
+            tot_w += 1024.0 * sum(w)
     if n_gemm:  # the dense (DiT) GEMM launches: bench.py's roofline.traffic
         out["gemm_all"] = {"launches": n_gemm, "hbm_bytes_per_launch": (tot_f + tot_w) / n_gemm,
                            "fetch_bytes_per_launch": tot_f / n_gemm, "write_bytes_per_launch": tot_w / n_gemm}
