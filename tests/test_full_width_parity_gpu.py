@@ -234,3 +234,28 @@ def test_config5_tiled_vae_decode_180_frames(ltx):
         assert cur == 180
     finally:
         ctx.close()
+
+
+def test_batch_of_two_with_the_norm_on_the_finish_pass(two_layer):
+    """Round 4: at 2 x 768 tokens the FFN's second GEMM has 1536 rows, runs as two K halves of the 192x256 kernel, and block 1's adaLN
+    pass rides on its finish pass with TWO batch elements in the launch (gate and modulation rows picked per batch element inside the
+    fused kernel). Each sample of the pair, at its own timestep, against its own B = 1 forward (768 rows: ring kernel, separate passes)."""
+    ctx, cfg, ocfg, w = two_layer
+    F, H, W, S = 2, 16, 24, 256
+    T = F * H * W
+    rng = np.random.default_rng(5)
+    lat = rng.standard_normal((2, T, 128)).astype(np.float32)
+    cx = rng.standard_normal((2, S, 3840)).astype(np.float32)
+    sig = (0.3, 0.9)
+    vel2 = torch.empty((2, T, 128), dtype=torch.float32, device="cuda")
+    ts2 = torch.tensor(sig, dtype=torch.float32, device="cuda")
+    ctx.dit_forward_dev(_dev_bf16(lat), _dev_bf16(cx), ts2, None, F, H, W, vel2, ctx_version=0)
+    torch.cuda.synchronize()
+    pair = vel2.cpu().numpy()
+    for b in range(2):
+        one = _forward(ctx, lat[b:b + 1], cx[b:b + 1], sig[b], None, F, H, W)
+        print(f"sample {b} of the pair vs its own forward: rel-L2 {rel_l2(pair[b:b + 1], one):.3e}")
+        # two launch shapes = two rounding sequences, each ~2.3e-3 from the oracle at this depth: 3.1e-3 apart (the same with the split
+        # and the fused pass turned off); a wrong batch element's gate or modulation row is > 1e-1
+        assert rel_l2(pair[b:b + 1], one) <= 5e-3, (b, rel_l2(pair[b:b + 1], one))
+    assert rel_l2(pair[0:1], pair[1:2]) > 0.1  # the two samples really differ
