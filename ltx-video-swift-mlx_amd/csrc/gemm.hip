@@ -2229,7 +2229,13 @@ static void launch_dtl(const GemmArgs& a, hipStream_t stream, const NormAfter* n
     if (a.split_k > 1) {
         if (na) {
             LTX_REQUIRE(finish_takes_norm(a, *na), "gemm: the fused finish + norm pass needs N = 4096, an RMS norm with modulation and no row maps");
-            hipLaunchKernelGGL(splitk_finish_norm_kernel<2>, dim3(a.M / 2), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.ep, *na);
+            // rows per workgroup (A/B hook: 1, 2 or 4): one row = 1536 workgroups, six per CU in flight - 34.77 / 34.85 / 35.26 ms per step
+            // with 1 / 2 / 4 on one box (the pass loads three streams per row, unlike norm_mod_rows_kernel, where two rows won)
+            static const int fr = getenv("LTX_FINISH_ROWS") ? atoi(getenv("LTX_FINISH_ROWS")) : 1;
+            if (fr != 2 && fr != 4) hipLaunchKernelGGL(splitk_finish_norm_kernel<1>, dim3(a.M), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.ep, *na);
+            else if (fr == 4 && a.M % 4 == 0 && na->rows_per_batch % 4 == 0 && (!a.ep.gate || a.ep.rows_per_batch % 4 == 0))
+                hipLaunchKernelGGL(splitk_finish_norm_kernel<4>, dim3(a.M / 4), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.ep, *na);
+            else hipLaunchKernelGGL(splitk_finish_norm_kernel<2>, dim3(a.M / 2), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.ep, *na);
         } else {
             const long total = (long)a.M * (a.N / 4);
             const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
