@@ -92,11 +92,13 @@ LTX_DEVFN float gelu_tanh(float x) {
     // 0.5 (1 + tanh u) = 1 / (1 + exp(-2u)): one v_exp_f32 and one v_rcp_f32 instead of the library tanhf (a branchy ~30-instruction
     // sequence that the FFN epilogue runs 96 times per lane and tile on the SIMDs that also issue the MFMAs). |error| <= 2e-7 * |x|,
     // far inside the bf16 rounding of the stored value; exp overflow for very negative u gives x / inf = -0, the correct limit.
-    return __fdividef(x, 1.0f + __expf(-2.0f * u));
+    // (round 4: written as x * v_rcp_f32(...). __fdividef compiles to the full IEEE division here - v_div_scale x2, v_rcp, four FMAs,
+    // v_div_fmas, v_div_fixup per element, found in the 192x256 kernel's ISA - and the FFN-up launch spent 13.6 us of 175 in this function)
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
 }
 // x * sigmoid(x) with one v_exp_f32 and one v_rcp_f32 (relative error ~2e-7, far inside the bf16 rounding of every stored value); the
 // IEEE division it replaces is a ten-instruction sequence that the conv epilogues run per element on the SIMDs that issue the MFMAs
-LTX_DEVFN float silu_f(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
+LTX_DEVFN float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: four row rotations, no LDS crossbar
 LTX_DEVFN float row16_allsum(float v) {
