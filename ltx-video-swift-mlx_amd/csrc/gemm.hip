@@ -1995,11 +1995,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_dtl(const GemmArgs g)
             constexpr int buf = grp & 1;
             if constexpr (grp + 1 < 3) fetch(std::integral_constant<int, grp + 1>{}, std::integral_constant<int, (grp + 1) & 1>{});
 #include "gemm_asm_192x256_dump.inc"
+            static_for<0, 2>([&](auto half_c) {
+            constexpr int half = decltype(half_c)::value;
+            f32x4 vv[NITG / 2];  // the scratch reads of eight two-row steps issued together
 #pragma unroll
-            for (int it = 0; it < NITG; ++it) {
+            for (int i2 = 0; i2 < NITG / 2; ++i2) vv[i2] = *(const f32x4*)(scr + ((half * (NITG / 2) + i2) * RPI + lane / LPR) * WN + (lane % LPR) * 4);
+#pragma unroll
+            for (int i2 = 0; i2 < NITG / 2; ++i2) {
+                const int it = half * (NITG / 2) + i2;
                 const int row = it * RPI + lane / LPR;
                 const int gm = m0 + wr * WM + grp * 32 + row;
-                f32x4 v = *(const f32x4*)(scr + row * WN + (lane % LPR) * 4);
+                f32x4 v = vv[i2];
                 v += bias;
                 if (ep.bias_m) {
                     const float bm = ep.bias_m[gm];
@@ -2029,19 +2035,24 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_dtl(const GemmArgs g)
                     *(uint2*)(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn) = pk;
                 }
             }
+            });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the scratch is rewritten by the next dump
         });
         return;
     }
+    // plain stores (residual launches returned above): the 16 scratch reads of a group are issued together (round 4: the rolled loop
+    // waited for one ds_read_b128 per two rows - ~100 cycles x 48 per tile with nothing else to issue on a one-wave SIMD)
     static_for<0, 3>([&](auto grp_c) {
         constexpr int grp = decltype(grp_c)::value;
+        constexpr int NITG = 32 / RPI;
 #include "gemm_asm_192x256_dump.inc"
-#pragma unroll 2
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int row = it * RPI + lane / LPR;
-            const int gm = m0 + wr * WM + grp * 32 + row;
-            f32x4 v = *(const f32x4*)(scr + row * WN + (lane % LPR) * 4);
-            v += bias;
+        f32x4 vv[NITG];
+#pragma unroll
+        for (int it = 0; it < NITG; ++it) vv[it] = *(const f32x4*)(scr + (it * RPI + lane / LPR) * WN + (lane % LPR) * 4);
+#pragma unroll
+        for (int it = 0; it < NITG; ++it) {
+            const int gm = m0 + wr * WM + grp * 32 + it * RPI + lane / LPR;
+            f32x4 v = vv[it] + bias;
             if (ep.bias_m) {
                 const float bm = ep.bias_m[gm];
                 v += f32x4{bm, bm, bm, bm};
@@ -2056,13 +2067,6 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_dtl(const GemmArgs g)
             if (ep.round_bf16) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
-            }
-            if (ep.resid) {
-                const f32x4 rs = *(const f32x4*)(rbase + (long)gm * rld + gn);
-                f32x4 gt = f32x4{ep.gate_scalar, ep.gate_scalar, ep.gate_scalar, ep.gate_scalar};
-                if (ep.gate) gt = *(const f32x4*)(ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[gm] : gm / ep.rows_per_batch) * ep.gate_bstride + gn);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
             }
             if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn) = v;
             if (ep.out_bf16) {
