@@ -1707,7 +1707,9 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__
                 for (int e = 0; e < 8; ++e) {
                     float x = av[e];
                     if (in_act == LTX_ACT_SILU) x = silu_f(x);
-                    accv[m] += x * wf[e];
+                    // an explicit fma: left to contraction, the compiler fused this for some rows m and emitted (packed) mul + add for
+                    // others, so identical rows of a batch differed by an ulp (round 4: found by the batch-consistency test)
+                    accv[m] = __builtin_fmaf(x, wf[e], accv[m]);
                 }
             }
         }

@@ -656,3 +656,21 @@ def test_gated_residual_with_the_next_norm_on_its_finish_pass(gpu_ctx, M, K):
     assert float((xa - want).abs().max()) <= 2e-3 * float(want.abs().max())
     nrm = xa * torch.rsqrt((xa * xa).mean(dim=1, keepdim=True) + 1e-6) * (1 + scale) + shift
     assert float((na.float() - nrm).abs().max()) <= 2 ** -7 * float(nrm.abs().max())
+
+
+@pytest.mark.parametrize("in_act", [0, 2])
+def test_gemv_rows_of_a_batch_are_computed_alike(gpu_ctx, in_act):
+    """The timestep / adaLN path runs this kernel with one row per batch element: identical rows must give identical bits (left to
+    FMA contraction, the compiler fused the accumulate for some rows and not for others; the full-size batch-consistency test saw the
+    1-ulp difference 48 layers later as 1.5e-2)."""
+    torch.manual_seed(0)
+    for K, N in ((256, 4096), (4096, 24576)):
+        a1 = torch.randn(1, K, device="cuda")
+        a = a1.repeat(4, 1).contiguous()
+        Wt = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda")
+        out = torch.empty((4, N), device="cuda")
+        gpu_ctx.op_gemv(a, Wt, b, out, in_act=in_act)
+        torch.cuda.synchronize()
+        for r in range(1, 4):
+            assert torch.equal(out[0], out[r]), (K, N, r)
