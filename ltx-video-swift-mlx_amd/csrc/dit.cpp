@@ -454,10 +454,23 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
                     launch_sp_vt_interleave(m->ws_sp_vtg.as<bf16_t>(), vt_full, NW, D, T, TfullPad, side);
                 }
             }
+            // The q|k projection is stored as bf16 (round 4) - what the reference's bf16 Linear hands its RMSNorm (LTXAttention.swift:173-189)
+            // and half the bytes of the round trip to the norm + RoPE pass: 34.82 -> 34.60 ms per step, rows 2.02 -> 1.77 ms, and the 48-layer
+            // headline forward sits 2.419e-3 from the oracle against 2.416e-3 with the f32 store (LTX_QK_F32=1 restores it for A/B). The choice
+            // does not depend on the row count, so sequence-parallel ranks and single-GPU runs round alike.
+            static const bool qk_f32 = getenv("LTX_QK_F32") && atoi(getenv("LTX_QK_F32")) == 1;
+            const bool qkb = !qk_f32;
             GemmEpilogue eqk;
-            eqk.out_f32 = qk;
-            eqk.ld_f32 = 2 * D;
+            if (qkb) {
+                eqk.out_bf16 = (bf16_t*)qk;
+                eqk.ld_bf16 = 2 * D;
+            } else {
+                eqk.out_f32 = qk;
+                eqk.ld_f32 = 2 * D;
+            }
             gemm_linear(xn, D, blk.qk1, (int)rows, eqk, st, sk);
+            if (qkb) launch_qknorm_rope2(qk, blk.qn1, q, (const float*)((const bf16_t*)qk + D), blk.kn1, k, 2 * D, D, rope_c, rope_s, T, (int)rows, D, eps, st, kAttnQueryPrescale, true);
+            else
             launch_qknorm_rope2(qk, blk.qn1, q, qk + D, blk.kn1, k, 2 * D, D, rope_c, rope_s, T, (int)rows, D, eps, st, kAttnQueryPrescale);
             AttnArgs at;
             if (!sp) {
@@ -505,8 +518,15 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             GemmEpilogue eq;
             eq.out_f32 = qc;
             eq.ld_f32 = D;
+            static const bool q2_f32 = getenv("LTX_QK_F32") && atoi(getenv("LTX_QK_F32")) == 1;
+            const bool q2b = !q2_f32;  // bf16 projection output, as for the self-attention q|k above
+            if (q2b) {
+                eq.out_f32 = nullptr;
+                eq.out_bf16 = (bf16_t*)qc;
+                eq.ld_bf16 = D;
+            }
             gemm_linear(xb, D, blk.q2, (int)rows, eq, st, sk);
-            launch_qknorm_rope(qc, D, blk.qn2, nullptr, nullptr, T, q, D, (int)rows, D, eps, st, kAttnQueryPrescale);
+            launch_qknorm_rope(qc, D, blk.qn2, nullptr, nullptr, T, q, D, (int)rows, D, eps, st, kAttnQueryPrescale, q2b);
             AttnArgs at;
             at.Q = q; at.ldq = D; at.q_bstride = (long)T * D;
             at.K = cc->k.as<bf16_t>() + (size_t)l * B * S * D; at.ldk = D; at.k_bstride = (long)S * D;

@@ -21,12 +21,12 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
 // q and k of a fused projection in ONE launch (job 1 optional: x1 == nullptr)
 void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const float* x1, const float* w1, bf16_t* out1,
                          long ldx, long ldo, const float* cosT, const float* sinT, int T, int rows, int D, float eps,
-                         hipStream_t stream, float out_scale0 = 1.0f);
+                         hipStream_t stream, float out_scale0 = 1.0f, bool x_bf16 = false);
 // out_scale0 / out_scale: multiplier applied to job 0's (the query's) normed + rotated row before its single rounding to bf16. The
 // DiT folds the softmax scale and log2(e) into it (kAttnQueryPrescale), so that the attention kernel's scores arrive as base-2
 // exponents: one rounding of q as before, and 48 multiplies per key tile less in the kernel (AttnArgs::q_prescaled).
 void launch_qknorm_rope(const float* x, long ldx, const float* w, const float* cosT, const float* sinT, int T,
-                        bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t stream, float out_scale = 1.0f);
+                        bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t stream, float out_scale = 1.0f, bool x_bf16 = false);
 
 // sequence-parallel self-attention: gathered V^T blocks [N][D][Tn] -> one V^T [D][ld] with rank r's keys at columns r*Tn ..
 void launch_sp_vt_interleave(const bf16_t* gathered, bf16_t* vt, int N, int D, int Tn, long ld, hipStream_t stream);

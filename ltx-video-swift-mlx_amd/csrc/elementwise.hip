@@ -186,13 +186,24 @@ struct QkJob {
     long ldx, ldo;
     float out_scale;  // multiplies the normed (and rotated) row before its ONE rounding to bf16 (1 = plain)
 };
-template <int NP>
+// four consecutive elements of a q / k projection row as f32: the row is f32, or (XB) bf16 at the same element offsets
+template <bool XB>
+LTX_DEVFN f32x4 qk_load4(const float* x_row, int col) {
+    if constexpr (XB) {
+        const uint2 u = *(const uint2*)((const bf16_t*)x_row + col);
+        return f32x4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                     __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+    } else {
+        return *(const f32x4*)(x_row + col);
+    }
+}
+template <int NP, bool XB = false>
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkJob j0, QkJob j1, const float* __restrict__ cosT,
                                                           const float* __restrict__ sinT, int T, int D, float eps) {
     __shared__ float red[4];
     const QkJob job = blockIdx.y ? j1 : j0;
     const int row = blockIdx.x;
-    const float* xr = job.x + (long)row * job.ldx;
+    const float* xr = XB ? (const float*)((const bf16_t*)job.x + (long)row * job.ldx) : job.x + (long)row * job.ldx;
     // pair chunk p (0 .. D/8-1): head = p / 16, i4 = p % 16 ; a at head*128 + i4*4, b at +64
     const int npair = D >> 3;
     const int t = row % T;
@@ -203,8 +214,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkJob j0, QkJob j1, co
         va[j] = vb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p < npair) {
             const int col = (p >> 4) * 128 + (p & 15) * 4;
-            va[j] = *(const f32x4*)(xr + col);
-            vb[j] = *(const f32x4*)(xr + col + 64);
+            va[j] = qk_load4<XB>(xr, col);
+            vb[j] = qk_load4<XB>(xr, col + 64);
         }
     }
 #pragma unroll
@@ -633,7 +644,7 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
 
 // R rows per workgroup of qknorm_rope_kernel (D = 4096): the norm weights are fetched once per R rows instead of once per row
 // (they are as many bytes as a row), every row is loaded before the first reduction, the R sums share one barrier pair.
-template <int R>
+template <int R, bool XB = false>
 __global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(QkJob j0, QkJob j1, const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                                int T, int rows, float eps) {
     constexpr int NP = 2, D = 4096;
@@ -651,11 +662,11 @@ __global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(QkJob j0, QkJob j
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int row = (row0 + r) < rows ? (row0 + r) : rows - 1;
-        const float* xr = job.x + (long)row * job.ldx;
+        const float* xr = XB ? (const float*)((const bf16_t*)job.x + (long)row * job.ldx) : job.x + (long)row * job.ldx;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            va[r][j] = *(const f32x4*)(xr + col[j]);
-            vb[r][j] = *(const f32x4*)(xr + col[j] + 64);
+            va[r][j] = qk_load4<XB>(xr, col[j]);
+            vb[r][j] = qk_load4<XB>(xr, col[j] + 64);
         }
     }
 #pragma unroll
@@ -730,7 +741,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(QkJob j0, QkJob j
 // The self-attention pair (q and k of the same tokens) in one workgroup: R rows of BOTH jobs share one fetch of the rotary tables
 // (a table row is as many bytes as the f32 row it rotates; with one workgroup per job the second fetch came from L2 / Infinity Cache,
 // 768 workgroups later) and one barrier pair.
-template <int R>
+template <int R, bool XB = false>
 __global__ __launch_bounds__(256) void qknorm_rope_pair_kernel(QkJob j0, QkJob j1, const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                                int T, int rows, float eps) {
     constexpr int NP = 2, D = 4096, NJ = 2;
@@ -750,11 +761,11 @@ __global__ __launch_bounds__(256) void qknorm_rope_pair_kernel(QkJob j0, QkJob j
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = (row0 + r) < rows ? (row0 + r) : rows - 1;
-            const float* xr = job.x + (long)row * job.ldx;
+            const float* xr = XB ? (const float*)((const bf16_t*)job.x + (long)row * job.ldx) : job.x + (long)row * job.ldx;
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                va[q][r][j] = *(const f32x4*)(xr + col[j]);
-                vb[q][r][j] = *(const f32x4*)(xr + col[j] + 64);
+                va[q][r][j] = qk_load4<XB>(xr, col[j]);
+                vb[q][r][j] = qk_load4<XB>(xr, col[j] + 64);
             }
         }
     }
@@ -822,39 +833,46 @@ __global__ __launch_bounds__(256) void qknorm_rope_pair_kernel(QkJob j0, QkJob j
 
 void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const float* x1, const float* w1, bf16_t* out1,
                          long ldx, long ldo, const float* cosT, const float* sinT, int T, int rows, int D, float eps,
-                         hipStream_t stream, float out_scale0) {
+                         hipStream_t stream, float out_scale0, bool x_bf16) {
     LTX_REQUIRE(D % 128 == 0 && D <= MAXV * 1024 && ldx % 4 == 0 && ldo % 4 == 0, "qknorm_rope: D=%d", D);
+
     const QkJob j0{x0, w0, out0, ldx, ldo, out_scale0}, j1{x1, w1, out1, ldx, ldo, 1.0f};
 #ifdef LTX_EXPERIMENTS  // timing ablation: LTX_ABL_ROWS bit 1 drops the q|k pass, bit 2 the cross-attention q pass, after two forwards' worth of calls
     { static const int abl = getenv("LTX_ABL_ROWS") ? atoi(getenv("LTX_ABL_ROWS")) : 0; static long c2 = 0, c1 = 0;
       if (x1 && (abl & 2) && ++c2 > 200) return; if (!x1 && (abl & 4) && ++c1 > 300) return; }
 #endif
-    // algorithmic bytes: the f32 rows in, the bf16 rows out, cos/sin rows once per job
-    ProfScope prof(PROF_ELEM, (double)rows * D * (x1 ? 2 : 1) * (4 + 2 + (cosT ? 4 : 0)), stream);
+    // algorithmic bytes: the f32 (or bf16) rows in, the bf16 rows out, cos/sin rows once per job
+    ProfScope prof(PROF_ELEM, (double)rows * D * (x1 ? 2 : 1) * ((x_bf16 ? 2 : 4) + 2 + (cosT ? 4 : 0)), stream);
     const dim3 grid(rows, x1 ? 2 : 1);
     const int t = T < 1 ? 1 : T;
     static const bool no_pair = getenv("LTX_QKNORM_NO_PAIR") != nullptr;  // A/B hook
     if (D == 4096 && rows >= 512 && x1 && cosT && !no_pair) {  // q and k of the same tokens: one fetch of the tables (2.64 -> 2.54 ms of row passes per step)
         constexpr int R = 2;  // 1 and 3 rows per workgroup: within the run-to-run noise of the forward (round 3)
-        hipLaunchKernelGGL(qknorm_rope_pair_kernel<R>, dim3((rows + R - 1) / R), dim3(256), 0, stream, j0, j1, cosT, sinT, t, rows, eps);
+        if (x_bf16) hipLaunchKernelGGL((qknorm_rope_pair_kernel<R, true>), dim3((rows + R - 1) / R), dim3(256), 0, stream, j0, j1, cosT, sinT, t, rows, eps);
+        else hipLaunchKernelGGL(qknorm_rope_pair_kernel<R>, dim3((rows + R - 1) / R), dim3(256), 0, stream, j0, j1, cosT, sinT, t, rows, eps);
         HIP_CHECK(hipGetLastError());
         return;
     }
     if (D == 4096 && rows >= 512) {   // the DiT at full width: R rows per workgroup share one fetch of the norm weights
         constexpr int R = 2;
-        hipLaunchKernelGGL(qknorm_rope_rows_kernel<R>, dim3((rows + R - 1) / R, x1 ? 2 : 1), dim3(256), 0, stream, j0, j1, cosT, sinT, t, rows, eps);
+        if (x_bf16) hipLaunchKernelGGL((qknorm_rope_rows_kernel<R, true>), dim3((rows + R - 1) / R, x1 ? 2 : 1), dim3(256), 0, stream, j0, j1, cosT, sinT, t, rows, eps);
+        else hipLaunchKernelGGL(qknorm_rope_rows_kernel<R>, dim3((rows + R - 1) / R, x1 ? 2 : 1), dim3(256), 0, stream, j0, j1, cosT, sinT, t, rows, eps);
         HIP_CHECK(hipGetLastError());
         return;
     }
-    if (D <= 2048) hipLaunchKernelGGL(qknorm_rope_kernel<1>, grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
+    if (x_bf16) {
+        if (D <= 2048) hipLaunchKernelGGL((qknorm_rope_kernel<1, true>), grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
+        else if (D <= 4096) hipLaunchKernelGGL((qknorm_rope_kernel<2, true>), grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
+        else hipLaunchKernelGGL((qknorm_rope_kernel<4, true>), grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
+    } else if (D <= 2048) hipLaunchKernelGGL(qknorm_rope_kernel<1>, grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
     else if (D <= 4096) hipLaunchKernelGGL(qknorm_rope_kernel<2>, grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
     else hipLaunchKernelGGL(qknorm_rope_kernel<4>, grid, dim3(256), 0, stream, j0, j1, cosT, sinT, t, D, eps);
     HIP_CHECK(hipGetLastError());
 }
 
 void launch_qknorm_rope(const float* x, long ldx, const float* w, const float* cosT, const float* sinT, int T,
-                        bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t stream, float out_scale) {
-    launch_qknorm_rope2(x, w, out, nullptr, nullptr, nullptr, ldx, ldo, cosT, sinT, T, rows, D, eps, stream, out_scale);
+                        bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t stream, float out_scale, bool x_bf16) {
+    launch_qknorm_rope2(x, w, out, nullptr, nullptr, nullptr, ldx, ldo, cosT, sinT, T, rows, D, eps, stream, out_scale, x_bf16);
 }
 
 void launch_cast_f32_bf16(const float* x, bf16_t* out, long n, hipStream_t stream) {
