@@ -103,6 +103,9 @@ struct GemmArgs {
     // B's LDS-DMA loads with the non-temporal policy (once-read weights of a few-row launch: they should not displace the activations
     // every column tile re-reads from the L2). Set by launch_gemm_bf16 for its few-row path; 128x64 ring instance only.
     int b_nt = 0;
+    // 192x256 kernel's split-K only: the partial tiles go to the workspace as bf16 (round 4) - the rounding the reference's bf16 Linear
+    // applies to the whole product, here applied to each K range's share before the f32 finish; half the bytes of the partial round trip
+    int split_bf16 = 0;
 };
 
 // tile_cfg 90 (experiments build only): a weight-streaming kernel for M <= 128 that loads MFMA fragments straight from global memory

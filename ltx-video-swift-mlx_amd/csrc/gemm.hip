@@ -1728,14 +1728,23 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__
 
 // split-K finish: out = epilogue(sum_z ws[z]) - every epilogue option except the depth-to-space stores; partials are summed in
 // ascending z, so the result does not depend on scheduling.
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int S, int M, int N, GemmEpilogue ep) {
+// one 16-byte (f32) or 8-byte (bf16) group of a partial slice
+LTX_DEVFN f32x4 ws_load4(const float* ws, long idx, int ws_bf16) {
+    if (ws_bf16) {
+        const uint2 u = *(const uint2*)((const bf16_t*)ws + idx);
+        return f32x4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                     __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+    }
+    return *(const f32x4*)(ws + idx);
+}
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int S, int M, int N, GemmEpilogue ep, int ws_bf16 = 0) {
     const long n4 = N >> 2;
     const long total = (long)M * n4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long m = i / n4;
         const int c = (int)(i - m * n4) * 4;
-        f32x4 v = *(const f32x4*)(ws + m * N + c);
-        for (int z = 1; z < S; ++z) v += *(const f32x4*)(ws + ((long)z * M + m) * N + c);
+        f32x4 v = ws_load4(ws, m * N + c, ws_bf16);
+        for (int z = 1; z < S; ++z) v += ws_load4(ws, ((long)z * M + m) * N + c, ws_bf16);
         if (ep.bias_n) v += *(const f32x4*)(ep.bias_n + c);
         if (ep.bias_m) {
             const float bm = ep.bias_m[m];
@@ -1779,7 +1788,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 // splitk_finish_kernel's and the norm arithmetic norm_mod_rows_kernel's (elementwise.hip), in the same order: the bf16 rows are
 // bit-identical to the two launches (tests/test_kernels_gpu.py).
 template <int R>
-__global__ __launch_bounds__(256) void splitk_finish_norm_kernel(const float* __restrict__ ws, int S, int M, GemmEpilogue ep, NormAfter na) {
+__global__ __launch_bounds__(256) void splitk_finish_norm_kernel(const float* __restrict__ ws, int S, int M, GemmEpilogue ep, NormAfter na, int ws_bf16) {
     constexpr int N = 4096, NV = 4;
     __shared__ float red[4][R];
     const int row0 = blockIdx.x * R;
@@ -1793,8 +1802,8 @@ __global__ __launch_bounds__(256) void splitk_finish_norm_kernel(const float* __
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c = (threadIdx.x + j * 256) * 4;
-            f32x4 t = *(const f32x4*)(ws + m * N + c);
-            for (int z = 1; z < S; ++z) t += *(const f32x4*)(ws + ((long)z * M + m) * N + c);
+            f32x4 t = ws_load4(ws, m * N + c, ws_bf16);
+            for (int z = 1; z < S; ++z) t += ws_load4(ws, ((long)z * M + m) * N + c, ws_bf16);
             if (ep.bias_n) t += *(const f32x4*)(ep.bias_n + c);
             if (ep.resid) {
                 const float* rs = (ep.resid_src ? ep.resid_src + m * ep.ld_resid : ep.out_f32 + m * ep.ld_f32) + c;
@@ -1958,13 +1967,22 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_dtl(const GemmArgs g)
     const int gn = n0 + wc * WN + (lane % LPR) * 4;
     if (g.split_k > 1) {  // raw partial tile -> this K range's slice of the workspace
         float* ws = g.split_ws + (long)blockIdx.y * g.M * g.N;
+        bf16_t* wsb = (bf16_t*)g.split_ws + (long)blockIdx.y * g.M * g.N;
         static_for<0, 3>([&](auto grp_c) {
             constexpr int grp = decltype(grp_c)::value;
 #include "gemm_asm_192x256_dump.inc"
 #pragma unroll 4
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int row = it * RPI + lane / LPR;
-                *(f32x4*)(ws + (long)(m0 + wr * WM + grp * 32 + row) * g.N + gn) = *(const f32x4*)(scr + row * WN + (lane % LPR) * 4);
+                const f32x4 v = *(const f32x4*)(scr + row * WN + (lane % LPR) * 4);
+                if (g.split_bf16) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)(wsb + (long)(m0 + wr * WM + grp * 32 + row) * g.N + gn) = pk;
+                } else {
+                    *(f32x4*)(ws + (long)(m0 + wr * WM + grp * 32 + row) * g.N + gn) = v;
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         });
@@ -2100,7 +2118,7 @@ void launch_m32(const GemmArgs& a, hipStream_t stream) {
     if (a.split_k > 1) {
         const long total = (long)a.M * (a.N / 4);
         const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep, 0);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -2138,7 +2156,7 @@ void launch_v2(const GemmArgs& a, hipStream_t stream) {
         }
         const long total = (long)rows * (a.N / 4);
         const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, rows, a.N, e);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, rows, a.N, e, 0);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -2160,7 +2178,7 @@ void launch_fewrow(const GemmArgs& a, hipStream_t stream) {
     if (a.split_k > 1) {
         const long total = (long)a.M * (a.N / 4);
         const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep, 0);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -2238,14 +2256,14 @@ static void launch_dtl(const GemmArgs& a, hipStream_t stream, const NormAfter* n
             // rows per workgroup (A/B hook: 1, 2 or 4): one row = 1536 workgroups, six per CU in flight - 34.77 / 34.85 / 35.26 ms per step
             // with 1 / 2 / 4 on one box (the pass loads three streams per row, unlike norm_mod_rows_kernel, where two rows won)
             static const int fr = getenv("LTX_FINISH_ROWS") ? atoi(getenv("LTX_FINISH_ROWS")) : 1;
-            if (fr != 2 && fr != 4) hipLaunchKernelGGL(splitk_finish_norm_kernel<1>, dim3(a.M), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.ep, *na);
+            if (fr != 2 && fr != 4) hipLaunchKernelGGL(splitk_finish_norm_kernel<1>, dim3(a.M), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.ep, *na, a.split_bf16);
             else if (fr == 4 && a.M % 4 == 0 && na->rows_per_batch % 4 == 0 && (!a.ep.gate || a.ep.rows_per_batch % 4 == 0))
-                hipLaunchKernelGGL(splitk_finish_norm_kernel<4>, dim3(a.M / 4), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.ep, *na);
-            else hipLaunchKernelGGL(splitk_finish_norm_kernel<2>, dim3(a.M / 2), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.ep, *na);
+                hipLaunchKernelGGL(splitk_finish_norm_kernel<4>, dim3(a.M / 4), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.ep, *na, a.split_bf16);
+            else hipLaunchKernelGGL(splitk_finish_norm_kernel<2>, dim3(a.M / 2), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.ep, *na, a.split_bf16);
         } else {
             const long total = (long)a.M * (a.N / 4);
             const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-            hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+            hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep, a.split_bf16);
         }
         HIP_CHECK(hipGetLastError());
     } else {
@@ -2289,7 +2307,7 @@ static void launch_stream(const GemmArgs& a_in, hipStream_t stream) {
     if (a.split_k > 1) {
         const long total = (long)a.M * (a.N / 4);
         const int fgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_finish_kernel, dim3(fgrid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(fgrid), dim3(256), 0, stream, a.split_ws, a.split_k, a.M, a.N, a.ep, 0);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -2424,6 +2442,11 @@ int gemm_suggest_split_k(int M, int N, int K) {
 // ranges of the 192x256 kernel, whose main loop reads half the fragments per MFMA, plus the finish pass: 36.46 -> 35.75 ms per headline
 // step on one box. -> number of ranges, 0 = not this launch. LTX_DTL_SPLITK=0 turns it off; LTX_DTL_SPLITK_MINK = least K per range
 // (8192; with 2048 the three K = 4096 launches of a block split too and the step LOSES 1.3 ms).
+// partial tiles of those launches as bf16 (GemmArgs::split_bf16); LTX_SPLIT_F32=1 keeps them f32 (A/B)
+static int dtl_split_bf16() {
+    static const int v = !(getenv("LTX_SPLIT_F32") && atoi(getenv("LTX_SPLIT_F32")) == 1);
+    return v;
+}
 static int dtl_split_for(const GemmArgs& a) {
     static const bool dtl_split = !(getenv("LTX_DTL_SPLITK") && atoi(getenv("LTX_DTL_SPLITK")) == 0);
     static const int dtl_mink = getenv("LTX_DTL_SPLITK_MINK") ? atoi(getenv("LTX_DTL_SPLITK_MINK")) : 8192;
@@ -2447,6 +2470,7 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream, const NormAfter* na
     if (s2) {
         GemmArgs b = a;
         b.split_k = s2;
+        b.split_bf16 = dtl_split_bf16();
         validate(b);
         ProfScope prof(PROF_GEMM, 2.0 * a.M * a.N * a.K, stream);
         launch_dtl(b, stream, na);
@@ -2583,6 +2607,7 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         }
         if (const int s2 = dtl_split_for(a)) {
             b.split_k = s2;
+            b.split_bf16 = dtl_split_bf16();
             launch_gemm_bf16_cfg(b, 75, stream);
             return;
         }

@@ -652,8 +652,11 @@ def test_gated_residual_with_the_next_norm_on_its_finish_pass(gpu_ctx, M, K):
     torch.cuda.synchronize()
     assert torch.equal(xa, xb_)
     assert torch.equal(na.view(torch.int16), nb.view(torch.int16))
-    want = x0 + gate * (A.float() @ B.float().T + bias)
-    assert float((xa - want).abs().max()) <= 2e-3 * float(want.abs().max())
+    prod = A.float() @ B.float().T + bias
+    want = x0 + gate * prod
+    # the K ranges' partial tiles cross the workspace as bf16 (GemmArgs::split_bf16): two roundings of at most 2^-9 of a partial's
+    # magnitude each, scaled by the gate - the rounding the reference's bf16 Linear applies to the whole product
+    assert float((xa - want).abs().max()) <= 2e-3 * float(want.abs().max()) + 2 ** -8 * float((gate * prod).abs().max())
     nrm = xa * torch.rsqrt((xa * xa).mean(dim=1, keepdim=True) + 1e-6) * (1 + scale) + shift
     assert float((na.float() - nrm).abs().max()) <= 2 ** -7 * float(nrm.abs().max())
 
