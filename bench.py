@@ -58,9 +58,9 @@ PEAK_BF16_TFLOPS = 2500.0
 SUSTAINED_BF16_TFLOPS = 2000.0
 HBM_PEAK_GBPS = 8000.0
 # (file, key): since round 4 one collection carries the dense GEMM launches ("gemm_all") and the VAE conv launches ("conv_all") side by side
-TRAFFIC_FILES = (("r04_pmc_traffic_v2.json", "gemm_all"), ("r04_pmc_traffic.json", "gemm_all"), ("r03_pmc_traffic.json", "gemm_all"), ("r02_pmc_traffic_v2.json", "gemm_all"),
+TRAFFIC_FILES = (("r04_pmc_traffic_v3.json", "gemm_all"), ("r04_pmc_traffic_v2.json", "gemm_all"), ("r04_pmc_traffic.json", "gemm_all"), ("r03_pmc_traffic.json", "gemm_all"), ("r02_pmc_traffic_v2.json", "gemm_all"),
                  ("r02_pmc_traffic.json", "gemm_all"), ("r01_pmc_traffic.json", "gemm_all"))
-VAE_TRAFFIC_FILES = (("r04_pmc_traffic_v2.json", "conv_all"), ("r04_pmc_traffic.json", "conv_all"), ("r03_pmc_traffic_vae_v2.json", "gemm_all"), ("r03_pmc_traffic_vae.json", "gemm_all"),
+VAE_TRAFFIC_FILES = (("r04_pmc_traffic_v3.json", "conv_all"), ("r04_pmc_traffic_v2.json", "conv_all"), ("r04_pmc_traffic.json", "conv_all"), ("r03_pmc_traffic_vae_v2.json", "gemm_all"), ("r03_pmc_traffic_vae.json", "gemm_all"),
                      ("r02_pmc_traffic_vae.json", "gemm_all"))
 
 
