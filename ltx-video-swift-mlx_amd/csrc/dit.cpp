@@ -330,6 +330,16 @@ DiTModel::CtxCache* prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardA
 
 }  // namespace
 
+// The q|k projection and the cross-attention q projection are stored as bf16 (round 4) - what the reference's bf16 Linear hands its RMSNorm
+// (LTXAttention.swift:173-189) and half the bytes of the round trip to the norm + RoPE pass: 34.82 -> 34.60 ms per step, rows 2.02 -> 1.77 ms,
+// and the 48-layer headline forward sits 2.419e-3 from the oracle against 2.416e-3 with the f32 store (LTX_QK_F32=1 restores it for A/B). The
+// choice depends on nothing but this hook, so sequence-parallel ranks and single-GPU runs round alike. The f32 workspaces (ws_qk, ws_qc) are
+// reused at half their size.
+static bool qk_store_bf16() {
+    static const bool v = !(getenv("LTX_QK_F32") && atoi(getenv("LTX_QK_F32")) == 1);
+    return v;
+}
+
 void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     const int D = m->D, L = m->L, B = a.B;
     const int Tfull = a.F * a.H * a.W;
@@ -454,12 +464,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
                     launch_sp_vt_interleave(m->ws_sp_vtg.as<bf16_t>(), vt_full, NW, D, T, TfullPad, side);
                 }
             }
-            // The q|k projection is stored as bf16 (round 4) - what the reference's bf16 Linear hands its RMSNorm (LTXAttention.swift:173-189)
-            // and half the bytes of the round trip to the norm + RoPE pass: 34.82 -> 34.60 ms per step, rows 2.02 -> 1.77 ms, and the 48-layer
-            // headline forward sits 2.419e-3 from the oracle against 2.416e-3 with the f32 store (LTX_QK_F32=1 restores it for A/B). The choice
-            // does not depend on the row count, so sequence-parallel ranks and single-GPU runs round alike.
-            static const bool qk_f32 = getenv("LTX_QK_F32") && atoi(getenv("LTX_QK_F32")) == 1;
-            const bool qkb = !qk_f32;
+            const bool qkb = qk_store_bf16();
             GemmEpilogue eqk;
             if (qkb) {
                 eqk.out_bf16 = (bf16_t*)qk;
@@ -518,8 +523,7 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             GemmEpilogue eq;
             eq.out_f32 = qc;
             eq.ld_f32 = D;
-            static const bool q2_f32 = getenv("LTX_QK_F32") && atoi(getenv("LTX_QK_F32")) == 1;
-            const bool q2b = !q2_f32;  // bf16 projection output, as for the self-attention q|k above
+            const bool q2b = qk_store_bf16();
             if (q2b) {
                 eq.out_f32 = nullptr;
                 eq.out_bf16 = (bf16_t*)qc;

@@ -2016,45 +2016,45 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_dtl(const GemmArgs g)
             if constexpr (grp + 1 < 3) fetch(std::integral_constant<int, grp + 1>{}, std::integral_constant<int, (grp + 1) & 1>{});
 #include "gemm_asm_192x256_dump.inc"
             static_for<0, 2>([&](auto half_c) {
-            constexpr int half = decltype(half_c)::value;
-            f32x4 vv[NITG / 2];  // the scratch reads of eight two-row steps issued together
+                constexpr int half = decltype(half_c)::value;
+                f32x4 vv[NITG / 2];  // the scratch reads of eight two-row steps issued together
 #pragma unroll
-            for (int i2 = 0; i2 < NITG / 2; ++i2) vv[i2] = *(const f32x4*)(scr + ((half * (NITG / 2) + i2) * RPI + lane / LPR) * WN + (lane % LPR) * 4);
+                for (int i2 = 0; i2 < NITG / 2; ++i2) vv[i2] = *(const f32x4*)(scr + ((half * (NITG / 2) + i2) * RPI + lane / LPR) * WN + (lane % LPR) * 4);
 #pragma unroll
-            for (int i2 = 0; i2 < NITG / 2; ++i2) {
-                const int it = half * (NITG / 2) + i2;
-                const int row = it * RPI + lane / LPR;
-                const int gm = m0 + wr * WM + grp * 32 + row;
-                f32x4 v = vv[i2];
-                v += bias;
-                if (ep.bias_m) {
-                    const float bm = ep.bias_m[gm];
-                    v += f32x4{bm, bm, bm, bm};
+                for (int i2 = 0; i2 < NITG / 2; ++i2) {
+                    const int it = half * (NITG / 2) + i2;
+                    const int row = it * RPI + lane / LPR;
+                    const int gm = m0 + wr * WM + grp * 32 + row;
+                    f32x4 v = vv[i2];
+                    v += bias;
+                    if (ep.bias_m) {
+                        const float bm = ep.bias_m[gm];
+                        v += f32x4{bm, bm, bm, bm};
+                    }
+                    if (ep.act == LTX_ACT_GELU_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                    } else if (ep.act == LTX_ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+                    if (ep.round_bf16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
+                    }
+                    f32x4 gt = gtu;
+                    if (ep.gate && !gate_uniform)
+                        gt = *(const f32x4*)(ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[gm] : gm / ep.rows_per_batch) * ep.gate_bstride + gn);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = rs[buf][it][e] + gt[e] * v[e];
+                    if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn) = v;
+                    if (ep.out_bf16) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(v[0], v[1]);
+                        pk.y = pack_bf16x2(v[2], v[3]);
+                        *(uint2*)(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn) = pk;
+                    }
                 }
-                if (ep.act == LTX_ACT_GELU_TANH) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-                } else if (ep.act == LTX_ACT_SILU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                }
-                if (ep.round_bf16) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
-                }
-                f32x4 gt = gtu;
-                if (ep.gate && !gate_uniform)
-                    gt = *(const f32x4*)(ep.gate + (long)(ep.gate_rowmap ? ep.gate_rowmap[gm] : gm / ep.rows_per_batch) * ep.gate_bstride + gn);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rs[buf][it][e] + gt[e] * v[e];
-                if (ep.out_f32) *(f32x4*)(ep.out_f32 + (long)gm * ep.ld_f32 + gn) = v;
-                if (ep.out_bf16) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]);
-                    pk.y = pack_bf16x2(v[2], v[3]);
-                    *(uint2*)(ep.out_bf16 + (long)gm * ep.ld_bf16 + gn) = pk;
-                }
-            }
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the scratch is rewritten by the next dump
         });
