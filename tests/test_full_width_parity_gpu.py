@@ -259,3 +259,51 @@ def test_batch_of_two_with_the_norm_on_the_finish_pass(two_layer):
         # and the fused pass turned off); a wrong batch element's gate or modulation row is > 1e-1
         assert rel_l2(pair[b:b + 1], one) <= 5e-3, (b, rel_l2(pair[b:b + 1], one))
     assert rel_l2(pair[0:1], pair[1:2]) > 0.1  # the two samples really differ
+
+
+_HOOK_SCRIPT = r"""
+import importlib, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.environ["LTX_REPO"])
+ltx = importlib.import_module("ltx-video-swift-mlx_amd")
+ctx = ltx.Context(0)
+ctx.dit_init_synthetic(ltx.default_transformer_config(num_layers=2), seed=99)
+F, H, W, S = 4, 16, 24, 256
+T = F * H * W
+lat = torch.empty((1, T, 128), dtype=torch.bfloat16, device="cuda"); ctx.op_fill_normal_bf16(lat, seed=3)
+c = torch.empty((1, S, 3840), dtype=torch.bfloat16, device="cuda"); ctx.op_fill_normal_bf16(c, seed=4)
+ts = torch.full((1,), 0.7, dtype=torch.float32, device="cuda")
+vel = torch.empty((1, T, 128), dtype=torch.float32, device="cuda")
+ctx.dit_forward_dev(lat, c, ts, None, F, H, W, vel, ctx_version=0, mask_all_ones=True)
+torch.cuda.synchronize()
+np.save(sys.argv[1], vel.cpu().numpy())
+ctx.close()
+"""
+
+
+def test_round4_ab_hooks_restore_the_previous_paths(tmp_path):
+    """The round-4 changes of the headline forward each keep an A/B hook (LTX_DTL_SPLITK=0: FFN-down on the ring kernel; LTX_FINISH_NORM=0:
+    the adaLN pass as its own launch; LTX_QK_F32=1: f32 q / k projection store; LTX_SPLIT_F32=1: f32 split partials). A 2-layer full-width
+    forward at the headline token count, run in a subprocess per setting (the hooks are read once per process): the fused-norm hook is
+    bit-neutral, the others move the result by rounding only."""
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        out = tmp_path / ("v_" + "_".join(f"{k}{v}" for k, v in extra.items()) + ".npy")
+        env = dict(os.environ, LTX_REPO=repo, **{k: str(v) for k, v in extra.items()})
+        r = subprocess.run([sys.executable, "-c", _HOOK_SCRIPT, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return np.load(out)
+
+    base = run({})
+    assert np.isfinite(base).all()
+    assert np.array_equal(run({"LTX_FINISH_NORM": 0}), base)
+    for hook in ({"LTX_DTL_SPLITK": 0}, {"LTX_QK_F32": 1}, {"LTX_SPLIT_F32": 1}):
+        other = run(hook)
+        r = rel_l2(other, base)
+        assert 0 < r <= 3e-3, (hook, r)
