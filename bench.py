@@ -337,7 +337,7 @@ def main():
                     help="launcher self-test: ranks rendezvous over gloo, count themselves and print the line without touching a GPU")
     ap.add_argument("--sp-overlap", action="store_true",
                     help="--mode sp / the sp extra leg: run each block's V^T gather on the library's side stream under the q|k projection "
-                         "(LTX_SP_OVERLAP=1; off by default until a multi-GPU run has confirmed it)")
+                         "(library option sp_overlap = 1; off by default until a multi-GPU run has confirmed it)")
     ap.add_argument("--quant", type=int, choices=(0, 4, 8), default=0,
                     help="--mode sp: quantise the transformer to this many bits (MLX affine, group 64) after the bf16 run and report both - "
                          "BASELINE configs[4] names a qint8 transformer")
@@ -347,8 +347,6 @@ def main():
     ap.add_argument("--selftest-legs", choices=("hang", "error", "ok"), default=None,
                     help="with --launch-check: drive the extra-legs guard with a fake leg that hangs / raises / returns (no GPU)")
     args = ap.parse_args()
-    if args.sp_overlap:
-        os.environ["LTX_SP_OVERLAP"] = "1"  # read once by the library at its first sequence-parallel forward; inherited by spawned ranks
     if args.rehearse_one_gpu and (args.mode != "replica" or args.extra_legs):
         # every rank on cuda:0 over gloo: only the replica path (no RCCL communicator inside the library) can run like that - two ranks of
         # one RCCL group on one device end in a duplicate-GPU error or in the watchdog
@@ -417,6 +415,8 @@ def main():
     ltx = importlib.import_module("ltx-video-swift-mlx_amd")
     dmod = importlib.import_module("ltx-video-swift-mlx_amd.dist")
     ctx = ltx.Context(local)
+    if args.sp_overlap:
+        ctx.set_option("sp_overlap", 1)  # spawned ranks get --sp-overlap in their own argv; the library never reads the environment
     cfg = ltx.default_transformer_config()
     runner = {"replica": run_replica, "cfg-pair": run_cfg_pair, "sp": run_sp, "vae-tiles": run_vae_tiles}[args.mode]
     out = runner(args, ctx, ltx, dmod, torch, dist, dev, cfg, rank, world, side)

@@ -64,6 +64,11 @@ typedef struct ltx_transformer_config {
  * ---------------------------------------------------------------------------------------------------------- */
 /* LTXVideo.version (LTXVideo.swift, asserted by Tests/LTXVideoTests/LTXVideoTests.swift:9-11) */
 const char* ltx_version(void);
+/* Revision of THIS header's binary interface (struct layouts, entry-point signatures); also the library's soname suffix
+ * (libltxhip.so.2). ltx_version() mirrors the reference's framework version and does not move with it.
+ *   1  rounds 1-4      2  round 5: ltx_denoise_options.struct_size first, ltx_ctx_set_option / ltx_ctx_get_option, no environment hooks */
+#define LTX_ABI_VERSION 2
+int ltx_abi_version(void);
 /* "gfx950;experiments=0|1": whether this build carries the measured-but-not-selected kernels (-DLTX_EXPERIMENTS; the product does not). */
 const char* ltx_build_info(void);
 /* Filled with the reference defaults (LTXConfig.swift:83-177). */
@@ -77,6 +82,17 @@ const char* ltx_last_error(const ltx_ctx* ctx);
  * NULL selects the default (null) stream. A new context starts on a private non-blocking stream. */
 int ltx_ctx_set_stream(ltx_ctx* ctx, void* hip_stream);
 int ltx_ctx_synchronize(ltx_ctx* ctx);
+/* Tuning / A-B switches of the kernel launchers (csrc/options.h holds the table; `ltx_option_info` enumerates it). The library NEVER
+ * reads the environment (the -DLTX_EXPERIMENTS build of tools/ seeds the same table from LTX_<NAME>): this call is the only way to move
+ * a switch, so a host's numerics do not depend on who launched it. Switches flagged `numerics` move results by rounding or accumulation
+ * order only - e.g. "qk_f32" = 1 and "split_f32" = 1 remove the two roundings this path has beyond the reference's;
+ * the others are bit-neutral. The table is process-wide (launchers are shared by all contexts); `ctx` receives the error message.
+ * Unknown key or out-of-range value: LTX_ERR_INVALID_CONFIGURATION. No reference counterpart (MLX has no such switches). */
+int ltx_ctx_set_option(ltx_ctx* ctx, const char* key, int value);
+int ltx_ctx_get_option(const ltx_ctx* ctx, const char* key, int* value);
+/* index 0 .. n-1 -> name / default / range / numerics flag / one-line description; returns the number of options (any pointer may be
+ * NULL; index out of range: only the count is returned). */
+int ltx_option_info(int index, const char** name, int* default_value, int* min_value, int* max_value, int* numerics, const char** doc);
 /* Counts of the last load call: tensors applied / model parameters absent from the file (left at the reference's
  * initial values) / mapped file keys with no parameter (dropped), as logged at ModelDownloader.swift:992-1017. */
 int ltx_load_report(const ltx_ctx* ctx, int* n_loaded, int* n_missing, int* n_unmatched);
@@ -328,8 +344,13 @@ int ltx_rope_tables_1d(int T, int dim, float theta, int max_pos, float* cos_out,
  * before that step's forward (LTXPipeline.swift:805-810). */
 typedef void (*ltx_progress_cb)(int current_step, int total_steps, float sigma, void* user);
 
-/* LTXVideoGenerationConfig's sampling knobs (LTXConfig.swift:216-300) for one denoise run. */
+/* LTXVideoGenerationConfig's sampling knobs (LTXConfig.swift:216-300) for one denoise run.
+ * ABI revision 2: the struct starts with its own size as the CALLER compiled it. The library reads a field only when struct_size covers
+ * it, so a host built against an older header (a shorter struct) stays safe when fields are appended; struct_size == 0 or smaller than
+ * the revision-2 core (everything up to and including `shard`) is rejected with LTX_ERR_INVALID_CONFIGURATION. Initialise with
+ * LTX_DENOISE_OPTIONS_INIT (C / C++) or MemoryLayout<ltx_denoise_options>.size (Swift). */
 typedef struct ltx_denoise_options {
+    uint32_t struct_size;   /* sizeof(ltx_denoise_options) in the caller's translation unit */
     float cfg_scale;        /* > 1 enables CFG; context batch is then [negative, positive] (LatentUtils.swift:104-117) */
     float guidance_rescale; /* phi (LatentUtils.swift:164-183) */
     float stg_scale;        /* STG (LTXPipeline.swift:897-921) */
@@ -363,6 +384,8 @@ typedef struct ltx_denoise_options {
      * can compare these lines for the same weights, embeddings and noise without touching the reference's code. */
     float* step_stats;
 } ltx_denoise_options;
+/* size set, CFG / rescale / STG / GE off, text-to-video, no sharding, no diagnostics */
+#define LTX_DENOISE_OPTIONS_INIT {(uint32_t)sizeof(ltx_denoise_options), 1.0f, 0.0f, 0.0f, NULL, 0, 0.0f, NULL, 0.0f, NULL, 0, NULL}
 enum { LTX_SHARD_NONE = 0, LTX_SHARD_CFG = 1, LTX_SHARD_SEQUENCE = 2 };
 
 /* Replaces the denoise loop of generateVideo (LTXPipeline.swift:800-956) / denoise(...) (:2191-2401), T2V.

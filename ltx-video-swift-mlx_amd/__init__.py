@@ -9,6 +9,7 @@ The directory name contains hyphens (it is the repo's mandated package name), so
 ``importlib.import_module("ltx-video-swift-mlx_amd")`` - ``tests/conftest.py`` and ``bench.py`` do that and alias it
 as ``ltx_amd``.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -122,6 +123,42 @@ def threefry2x32(key, ctr):
     return o
 
 
+
+
+def set_option(key, value):
+    """``ltx_ctx_set_option`` without a context: the launchers' switch table is process-wide (csrc/options.h)."""
+    _check(lib.ltx_ctx_set_option(None, key.encode(), int(value)))
+
+
+def get_option(key):
+    v = C.c_int()
+    _check(lib.ltx_ctx_get_option(None, key.encode(), C.byref(v)))
+    return v.value
+
+
+def option_table():
+    """[(name, default, min, max, numerics, doc)] of every switch (``ltx_option_info``)."""
+    n = lib.ltx_option_info(-1, None, None, None, None, None, None)
+    out = []
+    for i in range(n):
+        name, doc = C.c_char_p(), C.c_char_p()
+        d, lo, hi, num = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lib.ltx_option_info(i, C.byref(name), C.byref(d), C.byref(lo), C.byref(hi), C.byref(num), C.byref(doc))
+        out.append((name.value.decode(), d.value, lo.value, hi.value, bool(num.value), doc.value.decode()))
+    return out
+
+
+@contextlib.contextmanager
+def options(**kv):
+    """Set switches for the duration of a ``with`` block and restore the previous values (tests, A/B runs)."""
+    old = {k: get_option(k) for k in kv}
+    try:
+        for k, v in kv.items():
+            set_option(k, v)
+        yield
+    finally:
+        for k, v in old.items():
+            set_option(k, v)
 
 
 def dist_unique_id():
@@ -285,6 +322,19 @@ class Context:
         if n2 < 0:
             raise LTXError(-n2, lib.ltx_last_error(self._h).decode(errors="replace"))
         return out
+
+    def set_option(self, key, value):
+        """``ltx_ctx_set_option``: move one of the launchers' switches (process-wide; the library never reads the environment)."""
+        self._ck(lib.ltx_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int()
+        self._ck(lib.ltx_ctx_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kv):
+        """``with ctx.options(qk_f32=1): ...`` - set for the block, restore afterwards (the table is process-wide)."""
+        return options(**kv)
 
     def set_stream(self, stream_handle):
         self._ck(lib.ltx_ctx_set_stream(self._h, C.c_void_p(stream_handle)))
@@ -564,7 +614,7 @@ class Context:
             cond_noise = np.ascontiguousarray(cond_noise, dtype=np.float32)
         if step_stats is not None:
             assert isinstance(step_stats, np.ndarray) and step_stats.dtype == np.float32 and step_stats.flags["C_CONTIGUOUS"] and step_stats.shape[-1] == 4
-        o = DenoiseOptions(cfg_scale, guidance_rescale, stg_scale, C.cast(arr, C.POINTER(C.c_int)), len(stg_blocks), ge_gamma,
+        o = DenoiseOptions(C.sizeof(DenoiseOptions), cfg_scale, guidance_rescale, stg_scale, C.cast(arr, C.POINTER(C.c_int)), len(stg_blocks), ge_gamma,
                            _ptr(cond_latent), image_cond_noise_scale, _ptr(cond_noise), int(shard), _ptr(step_stats))
         o._keep = (arr, cond_latent, cond_noise, step_stats)
         return o

@@ -30,7 +30,7 @@ class LTXError(RuntimeError):
 class DenoiseOptions(C.Structure):
     """``ltx_denoise_options``: the sampling knobs of ``LTXVideoGenerationConfig`` (LTXConfig.swift:216-300)."""
 
-    _fields_ = [("cfg_scale", C.c_float), ("guidance_rescale", C.c_float), ("stg_scale", C.c_float),
+    _fields_ = [("struct_size", C.c_uint32), ("cfg_scale", C.c_float), ("guidance_rescale", C.c_float), ("stg_scale", C.c_float),
                 ("stg_blocks", C.POINTER(C.c_int)), ("n_stg_blocks", C.c_int), ("ge_gamma", C.c_float),
                 ("cond_latent", C.c_void_p), ("image_cond_noise_scale", C.c_float), ("cond_noise", C.c_void_p),
                 ("shard", C.c_int), ("step_stats", C.c_void_p)]
@@ -76,6 +76,11 @@ _ip = C.POINTER(C.c_int)
 # name -> (restype, argtypes); every symbol declared in include/ltxhip.h must appear here (tests check both ways)
 SIGNATURES = {
     "ltx_version": (C.c_char_p, []),
+    "ltx_abi_version": (_i, []),
+    "ltx_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "ltx_ctx_get_option": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int)]),
+    "ltx_option_info": (_i, [_i, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                             C.POINTER(C.c_char_p)]),
     "ltx_build_info": (C.c_char_p, []),
     "ltx_transformer_config_default": (None, [C.POINTER(TransformerConfig)]),
     "ltx_ctx_create": (_i, [_i, C.POINTER(_vp)]),

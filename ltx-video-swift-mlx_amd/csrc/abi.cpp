@@ -1,5 +1,6 @@
 // abi.cpp - extern "C" surface of libltxhip.so (declared in include/ltxhip.h). Every entry point converts C++
 // exceptions into an ltx_status + message; nothing here computes on the CPU on behalf of the GPU path.
+#include <stddef.h>
 #include <string.h>
 
 #include <algorithm>
@@ -87,6 +88,35 @@ DiTModel* need_dit(ltx_ctx* ctx) {
 extern "C" {
 
 const char* ltx_version(void) { return "0.1.0"; }
+int ltx_abi_version(void) { return LTX_ABI_VERSION; }
+
+int ltx_ctx_set_option(ltx_ctx* ctx, const char* key, int value) {
+    return guarded(ctx, [&] {
+        const int i = ltx_opt_find(key);
+        LTX_REQUIRE(i >= 0, "ltx_ctx_set_option: unknown option '%s' (ltx_option_info enumerates them)", key ? key : "(null)");
+        const LtxOptInfo& o = ltx_opt_info(i);
+        LTX_REQUIRE(ltx_opt_set(i, value), "ltx_ctx_set_option: %s = %d outside [%d, %d]", o.name, value, o.lo, o.hi);
+    });
+}
+int ltx_ctx_get_option(const ltx_ctx* ctx, const char* key, int* value) {
+    return guarded(const_cast<ltx_ctx*>(ctx), [&] {
+        const int i = ltx_opt_find(key);
+        LTX_REQUIRE(i >= 0 && value, "ltx_ctx_get_option: unknown option '%s'", key ? key : "(null)");
+        *value = ltx_opt((LtxOpt)i);
+    });
+}
+int ltx_option_info(int index, const char** name, int* def, int* lo, int* hi, int* numerics, const char** doc) {
+    if (index >= 0 && index < OPT_COUNT) {
+        const LtxOptInfo& o = ltx_opt_info(index);
+        if (name) *name = o.name;
+        if (def) *def = o.def;
+        if (lo) *lo = o.lo;
+        if (hi) *hi = o.hi;
+        if (numerics) *numerics = o.numerics;
+        if (doc) *doc = o.doc;
+    }
+    return OPT_COUNT;
+}
 
 const char* ltx_build_info(void) {
 #ifdef LTX_EXPERIMENTS
@@ -839,6 +869,12 @@ int ltx_renoise_dev(ltx_ctx* ctx, float* latent, const float* noise, float sigma
 // ---- denoise loop ----
 static void fill_params(DenoiseParams& p, const ltx_denoise_options* o) {
     if (!o) return;
+    // ABI revision 2: the caller declares how much of the struct it knows; nothing past that is read (round-4 advice: a host compiled
+    // against the older, shorter struct must not have `step_stats` read past its end)
+    const size_t sz = o->struct_size;
+    LTX_REQUIRE(sz >= offsetof(ltx_denoise_options, shard) + sizeof(o->shard) && sz <= 4096,
+                "ltx_denoise_options.struct_size = %zu: set it to sizeof(ltx_denoise_options) (LTX_DENOISE_OPTIONS_INIT); this library is ABI revision %d",
+                sz, LTX_ABI_VERSION);
     p.cfg_scale = o->cfg_scale;
     p.guidance_rescale = o->guidance_rescale;
     p.stg_scale = o->stg_scale;
@@ -849,7 +885,7 @@ static void fill_params(DenoiseParams& p, const ltx_denoise_options* o) {
     p.image_cond_noise_scale = o->image_cond_noise_scale;
     p.cond_noise = o->cond_noise;
     p.shard = o->shard;
-    p.step_stats = o->step_stats;
+    if (sz >= offsetof(ltx_denoise_options, step_stats) + sizeof(o->step_stats)) p.step_stats = o->step_stats;
 }
 
 int ltx_denoise_dev(ltx_ctx* ctx, float* latent, int F, int H, int W, const float* sigmas, int n_sigmas,
@@ -1168,7 +1204,7 @@ int ltx_op_fill_normal_f32(ltx_ctx* ctx, float* p, long n, uint64_t seed, float 
 
 /* ---- text-embedding connector ---- */
 namespace {
-ConnectorConfig to_conn_cfg(const ltx_connector_config* c) {
+extern "C++" ConnectorConfig to_conn_cfg(const ltx_connector_config* c) {
     ConnectorConfig k;
     if (c) {
         k.dim = c->dim; k.heads = c->heads; k.layers = c->layers; k.registers = c->registers; k.states = c->states;

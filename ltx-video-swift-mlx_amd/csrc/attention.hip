@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "attention.h"
+#include "options.h"
 #include "runtime.h"
 
 namespace {
@@ -938,7 +939,7 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
     // q_prescaled: every kernel but the prescaled assembly stream computes exp2(score * scale * log2(e)); with Q carrying
     // scale * log2(e) already that factor must be 1, i.e. scale = ln 2
     if (a.q_prescaled) a.scale = 0.6931471805599453f;
-    static const bool plain = getenv("LTX_ATTN_PLAIN_ORDER") != nullptr;  // A/B hook: (query block, head, batch) workgroup order as before round 3
+    const bool plain = ltx_opt(OPT_ATTN_PLAIN_ORDER) != 0;  // A/B option "attn_plain_order": (query block, head, batch) workgroup order as before round 3
     if (plain) a.plain_order = 1;
     LTX_REQUIRE(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "attention: empty problem");
     LTX_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 4 == 0, "attention: leading dims");
@@ -967,14 +968,16 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
         const double cost4 = (double)(wg4 / 512) * 2.3 + (rem4 == 0 ? 0.0 : (rem4 <= 256 ? 1.5 : 2.3));
         const long wgpp = (long)((a.Tq + PP_Q - 1) / PP_Q) * a.H * a.B;
         const double costpp = (double)((wgpp + 255) / 256) * 2.18;
-        const char* impl = getenv("LTX_ATTN_IMPL");
+        const int impl_opt = ltx_opt(OPT_ATTN_IMPL);  // option "attn_impl"
+        const char impl_c[2] = {(char)('0' + impl_opt), 0};
+        const char* impl = impl_opt ? impl_c : nullptr;
         const bool forced = impl && impl[0] >= '1' && impl[0] <= '4';
         bool use_pp = forced ? impl[0] == '2' : (!a.bias && costpp < cost4);
         // the 48-query kernels cover unmasked launches whose query count is a multiple of 192 and key count a multiple of 256
         const bool w48_ok = !a.bias && a.Tq % W48_Q == 0 && a.Tk % (4 * KV_TILE) == 0;
 #ifdef LTX_EXPERIMENTS
         if (impl && impl[0] == '3') {
-            LTX_REQUIRE(w48_ok, "attention: LTX_ATTN_IMPL=3 needs Tq %% 192 == 0, Tk %% 256 == 0 and no mask (Tq=%d Tk=%d)", a.Tq, a.Tk);
+            LTX_REQUIRE(w48_ok, "attention: attn_impl = 3 needs Tq %% 192 == 0, Tk %% 256 == 0 and no mask (Tq=%d Tk=%d)", a.Tq, a.Tk);
             static PerDeviceOnce attr3_set;
             attr3_set.run([&] {
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_ref, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
@@ -990,7 +993,7 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
         // the 32x32 stream (LTX_ATTN_IMPL=5 only: measured slower than the 16x16 stream on every BASELINE shape)
         if (impl && impl[0] == '5') {
             const bool x32_ok = !a.bias && a.q_prescaled && a.Tk % KV_TILE == 0;
-            LTX_REQUIRE(x32_ok, "attention: LTX_ATTN_IMPL=5 takes unmasked launches with prescaled Q and Tk %% 64 == 0 (Tq=%d Tk=%d)", a.Tq, a.Tk);
+            LTX_REQUIRE(x32_ok, "attention: attn_impl = 5 takes unmasked launches with prescaled Q and Tk %% 64 == 0 (Tq=%d Tk=%d)", a.Tq, a.Tk);
             static PerDeviceOnce attr5_set;
             attr5_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_x32_asm, hipFuncAttributeMaxDynamicSharedMemorySize, X32_LDS)); });
             hipLaunchKernelGGL(attn_fwd_kernel_x32_asm, dim3(((a.Tq + X32_Q - 1) / X32_Q) * a.H * a.B), dim3(256), X32_LDS, stream, a);
@@ -1001,7 +1004,7 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
         const bool asm_ok = !a.bias || a.Tk <= 4096;  // any Tq, Tk (ragged tails in the kernel); masked: the bias vector must fit 16 KB of LDS
         const bool use_asm = forced ? impl[0] == '4' : (asm_ok && cost48 < cost4 && cost48 < costpp);
         if (use_asm) {
-            LTX_REQUIRE(asm_ok, "attention: LTX_ATTN_IMPL=4 takes masked launches up to 4096 keys only (Tq=%d Tk=%d)", a.Tq, a.Tk);
+            LTX_REQUIRE(asm_ok, "attention: attn_impl = 4 takes masked launches up to 4096 keys only (Tq=%d Tk=%d)", a.Tq, a.Tk);
             static PerDeviceOnce attr4_set;
             attr4_set.run([&] {
                 HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel_w48_asm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W48_LDS));
@@ -1013,7 +1016,7 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
             AttnArgs k = a;
             k.key_splits = 1;
             const AttnSplitPlan plan = attn_split_plan(a.B, a.H, a.Tq, a.Tk);
-            static const bool no_split = getenv("LTX_ATTN_NO_SPLIT") != nullptr;  // A/B hook
+            const bool no_split = ltx_opt(OPT_ATTN_NO_SPLIT) != 0;  // A/B option "attn_no_split"
             if (plan.splits > 1 && a.split_ws && a.split_ws_bytes >= plan.bytes && !no_split && ((uintptr_t)a.split_ws & 15) == 0 &&
                 ((uintptr_t)a.O & 15) == 0 && a.ldo % 8 == 0 && a.o_bstride % 8 == 0) {
                 k.key_splits = plan.splits;

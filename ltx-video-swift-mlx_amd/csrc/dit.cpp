@@ -9,6 +9,7 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "linear_ops.h"
+#include "options.h"
 
 namespace {
 
@@ -330,14 +331,15 @@ DiTModel::CtxCache* prepare_context(ltx_ctx* ctx, DiTModel* m, const DiTForwardA
 
 }  // namespace
 
-// The q|k projection and the cross-attention q projection are stored as bf16 (round 4) - what the reference's bf16 Linear hands its RMSNorm
-// (LTXAttention.swift:173-189) and half the bytes of the round trip to the norm + RoPE pass: 34.82 -> 34.60 ms per step, rows 2.02 -> 1.77 ms,
-// and the 48-layer headline forward sits 2.419e-3 from the oracle against 2.416e-3 with the f32 store (LTX_QK_F32=1 restores it for A/B). The
-// choice depends on nothing but this hook, so sequence-parallel ranks and single-GPU runs round alike. The f32 workspaces (ws_qk, ws_qc) are
-// reused at half their size.
+// The q|k projection and the cross-attention q projection are stored as bf16 (round 4): half the bytes of the round trip to the norm + RoPE
+// pass (34.82 -> 34.60 ms per step, rows 2.02 -> 1.77 ms). This is a rounding the REFERENCE DOES NOT HAVE: its q / k reach RMSNorm as f32
+// (f32 activations x bf16-rounded weights; LTXAttention.swift:173-189) and the oracle keeps them f32. It was accepted on the
+// measured cost - the 48-layer headline forward sits 2.419e-3 from the oracle against 2.416e-3 with the f32 store, the 8-step loops move in
+// the fourth digit ("extra roundings") - and option "qk_f32" = 1 (ltx_ctx_set_option) restores the f32 store. The
+// choice depends on nothing but that option, so sequence-parallel ranks and single-GPU runs round alike. The f32 workspaces (ws_qk, ws_qc)
+// are reused at half their size.
 static bool qk_store_bf16() {
-    static const bool v = !(getenv("LTX_QK_F32") && atoi(getenv("LTX_QK_F32")) == 1);
-    return v;
+    return ltx_opt(OPT_QK_F32) == 0;
 }
 
 void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
@@ -358,11 +360,10 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             dist_allgather(ctx, send, recv, bytes);
         }
     };
-    // Self-test hook: LTX_SP_SELFTEST=1 sends a ONE-rank group of the native transport through the sequence-parallel branch (gathers of
+    // Self-test option ("sp_selftest" = 1 through ltx_ctx_set_option) sends a ONE-rank group of the native transport through the sequence-parallel branch (gathers of
     // one part, side stream, events): the only way to execute that code where a single GPU is all there is. Output bits == NW = 1 path.
-    // (the environment is consulted LAST, i.e. only on a context that holds a one-rank native group - a test artefact; no production
-    // forward reaches the getenv. The test sets the variable in mid-process, so it cannot be cached in a static.)
-    const bool sp_selftest = NW == 1 && B == 1 && !a.sp_gather && dist_can_overlap(ctx) && dist_world(ctx) == 1 && getenv("LTX_SP_SELFTEST") != nullptr;
+    // (the option is consulted LAST, i.e. only on a context that holds a one-rank native group - a test artefact.)
+    const bool sp_selftest = NW == 1 && B == 1 && !a.sp_gather && dist_can_overlap(ctx) && dist_world(ctx) == 1 && ltx_opt(OPT_SP_SELFTEST) != 0;
     const bool sp = NW > 1 || sp_selftest;
     const int T = Tfull / NW;            // rows this rank evaluates
     const int tok0 = a.sp_rank * T;      // first global token of this rank (NW == 1: 0)
@@ -382,6 +383,11 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
     const int S = a.S, Spad = cc->Spad;
 
     const SplitWs sk{m->ws_splitk.as<float>(), (long)(m->ws_splitk.bytes / 4)};
+    // FFN-down only: when its launch runs as K ranges of the 192x256 kernel (1536 tokens) the partial tiles may cross the workspace as bf16 -
+    // an extra rounding the reference does not have (MLX accumulates the whole product in f32), accepted on its measured cost (headline
+    // forward 2.419e-3 -> 2.457e-3 from the oracle for 0.7 % of the step); option "split_f32" = 1 turns it off
+    SplitWs sk_ff2 = sk;
+    sk_ff2.bf16_partials = true;
     // few tokens: the attention launcher may divide the keys of a launch over workgroups (attention.h, key split) - lend it the room
     {
         // (a sequence-parallel rank's self-attention sees all Tfull keys)
@@ -450,10 +456,10 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
             // Sequence parallelism on the native transport: the V^T gather (and its interleave) runs on the side stream under
             // the q|k projection and its norm + RoPE pass; only the K gather stays on the critical path. Same kernels, same
             // operands, same order of every reduction: the bits do not depend on which stream carried a collective.
-            // Opt-in (LTX_SP_OVERLAP=1, read once) until a run on two or more GPUs has confirmed it: the side-stream gather shares ONE RCCL
+            // Opt-in (option "sp_overlap" = 1) until a run on two or more GPUs has confirmed it: the side-stream gather shares ONE RCCL
             // communicator with the K gather on the context's stream, and no box reachable so far could execute that with two ranks
             // (round-3 advice). The self-test hook always takes the branch - that is what it is for.
-            static const bool sp_overlap_on = getenv("LTX_SP_OVERLAP") && atoi(getenv("LTX_SP_OVERLAP")) != 0;
+            const bool sp_overlap_on = ltx_opt(OPT_SP_OVERLAP) != 0;
             const bool overlap = sp && !a.sp_gather && dist_can_overlap(ctx) && (sp_overlap_on || sp_selftest);
             if (sp) {
                 gemm_vt(xn, D, T, blk.v1, vt, T, st, sk);  // V^T of the local tokens, dense [D][T]
@@ -580,10 +586,10 @@ void dit_forward(ltx_ctx* ctx, DiTModel* m, const DiTForwardArgs& a) {
                 na.eps = eps;
                 na.norm_kind = LTX_NORM_RMS;
                 na.row_map = rmap;
-                gemm_linear(ffh, 4 * D, blk.ff2, (int)rows, e2, st, sk, &na);
+                gemm_linear(ffh, 4 * D, blk.ff2, (int)rows, e2, st, sk_ff2, &na);
                 xn_ready = true;
             } else {
-                gemm_linear(ffh, 4 * D, blk.ff2, (int)rows, e2, st, sk);
+                gemm_linear(ffh, 4 * D, blk.ff2, (int)rows, e2, st, sk_ff2);
             }
         }
     }

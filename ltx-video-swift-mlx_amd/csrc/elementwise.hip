@@ -5,6 +5,7 @@
 
 #include <stdlib.h>
 
+#include "options.h"
 #include "runtime.h"
 
 namespace {
@@ -613,13 +614,13 @@ void launch_norm_mod(const float* x, long ldx, const float* scale, const float* 
     const int rpb = rows_per_batch < 1 ? 1 : rows_per_batch;
 #ifdef LTX_EXPERIMENTS  // timing ablation (experiments library only): LTX_ABL_ROWS bit 0 drops this pass after the first 400 calls - the
     // buffers keep realistic stale values, so what the step then gains is the upper bound of any fusion of the pass (profiles/r04_row_ablation.txt)
-    { static const int abl = getenv("LTX_ABL_ROWS") ? atoi(getenv("LTX_ABL_ROWS")) : 0; static long calls = 0; if ((abl & 1) && ++calls > 400) return; }
+    { const int abl = ltx_opt(OPT_ABL_ROWS); static long calls = 0; if ((abl & 1) && ++calls > 400) return; }
 #endif
     ProfScope prof(PROF_ELEM, (double)rows * D * (4 + 2), stream);  // algorithmic bytes: f32 row in, bf16 row out
     // rows per workgroup: 4 share one fetch of the modulation vectors; at 1536 rows that is 384 workgroups = 1.5 per CU, and two rows per
     // workgroup (768 = 3 per CU) are 10 % faster (9.15 vs 10.2 us alone, 36.39 vs 36.53 ms per forward); no difference from 6144 rows up
-    static const int r_raw = getenv("LTX_NORM_ROWS") ? atoi(getenv("LTX_NORM_ROWS")) : 0;  // A/B hook: 2 or 4, anything else is ignored
-    static const int r_env = (r_raw == 2 || r_raw == 4) ? r_raw : 0;
+    const int r_raw = ltx_opt(OPT_NORM_ROWS);  // A/B option "norm_rows": 2 or 4, anything else is ignored
+    const int r_env = (r_raw == 2 || r_raw == 4) ? r_raw : 0;
     const int R_rows = r_env ? r_env : (rows <= 3072 ? 2 : 4);
     if (norm_kind == LTX_NORM_RMS && scale && !row_map && D == 4096 && rows >= 512 && rpb % R_rows == 0) {
 #define LTX_ROWS_LAUNCH(R)                                                                                                                      \
@@ -838,14 +839,14 @@ void launch_qknorm_rope2(const float* x0, const float* w0, bf16_t* out0, const f
 
     const QkJob j0{x0, w0, out0, ldx, ldo, out_scale0}, j1{x1, w1, out1, ldx, ldo, 1.0f};
 #ifdef LTX_EXPERIMENTS  // timing ablation: LTX_ABL_ROWS bit 1 drops the q|k pass, bit 2 the cross-attention q pass, after two forwards' worth of calls
-    { static const int abl = getenv("LTX_ABL_ROWS") ? atoi(getenv("LTX_ABL_ROWS")) : 0; static long c2 = 0, c1 = 0;
+    { const int abl = ltx_opt(OPT_ABL_ROWS); static long c2 = 0, c1 = 0;
       if (x1 && (abl & 2) && ++c2 > 200) return; if (!x1 && (abl & 4) && ++c1 > 300) return; }
 #endif
     // algorithmic bytes: the f32 (or bf16) rows in, the bf16 rows out, cos/sin rows once per job
     ProfScope prof(PROF_ELEM, (double)rows * D * (x1 ? 2 : 1) * ((x_bf16 ? 2 : 4) + 2 + (cosT ? 4 : 0)), stream);
     const dim3 grid(rows, x1 ? 2 : 1);
     const int t = T < 1 ? 1 : T;
-    static const bool no_pair = getenv("LTX_QKNORM_NO_PAIR") != nullptr;  // A/B hook
+    const bool no_pair = ltx_opt(OPT_QKNORM_NO_PAIR) != 0;  // A/B option "qknorm_no_pair"
     if (D == 4096 && rows >= 512 && x1 && cosT && !no_pair) {  // q and k of the same tokens: one fetch of the tables (2.64 -> 2.54 ms of row passes per step)
         constexpr int R = 2;  // 1 and 3 rows per workgroup: within the run-to-run noise of the forward (round 3)
         if (x_bf16) hipLaunchKernelGGL((qknorm_rope_pair_kernel<R, true>), dim3((rows + R - 1) / R), dim3(256), 0, stream, j0, j1, cosT, sinT, t, rows, eps);

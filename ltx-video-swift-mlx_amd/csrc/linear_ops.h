@@ -4,17 +4,21 @@
 
 #include "dit.h"
 #include "gemm.h"
+#include "options.h"
 
 // optional split-K workspace (floats): when given, launches with few output tiles and a long K split the reduction
 struct SplitWs {
     float* p = nullptr;
     long elems = 0;
+    // the caller accepts bf16 partial tiles when the launcher picks the 192x256 split-K (GemmArgs::split_bf16): an extra rounding the
+    // reference does not have, so it is requested per call site (the DiT's FFN-down Linear) and never by the generic / ABI launches
+    bool bf16_partials = false;
 };
 
 // A quantised Linear whose launch has few rows hands its 8-bit codes to the GEMM, which de-quantises them in its B stage (no scratch
 // matrix: the codes are read once, half the bytes of the bf16 weights); every other launch gets bf16 weights (dit_linear_weights).
 inline bool linear_codes_in_gemm(const LinearW& w, int M, const SplitWs& ws) {
-    static const bool off = getenv("LTX_QB_OFF") != nullptr;  // A/B hook: every launch through the scratch matrix
+    const bool off = ltx_opt(OPT_QB_OFF) != 0;  // A/B option "qb_off": every launch through the scratch matrix
     return !off && !w.w && w.q && w.qbits == 8 && ws.p && gemm_takes_codes(M, w.out, w.in);
 }
 inline void set_weights(GemmArgs& g, const LinearW& w, bool codes, hipStream_t s) {
@@ -43,6 +47,7 @@ inline void gemm_linear(const bf16_t* A, long lda, const LinearW& w, int M, Gemm
         g.split_k = 0;
         g.split_ws = ws.p;
         g.split_ws_elems = ws.elems;
+        g.split_bf16 = ws.bf16_partials ? 1 : 0;
     }
     if (norm_after) launch_gemm_bf16(g, s, norm_after); else launch_gemm_bf16(g, s);
 }

@@ -12,6 +12,7 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "hostmath.h"
+#include "options.h"
 
 namespace {
 
@@ -238,7 +239,7 @@ void conv3d(const bf16_t* x, const Dims& d, const ConvW& cw, GemmEpilogue ep, hi
     g.geom.C = cw.cin;
     g.geom.causal = 0;    // the pipeline builds the decoder with causal:false (LTXPipeline.swift:338)
     g.geom.pad_mode = 0;  // reflect
-    static const bool blk_on = getenv("LTX_CONV_BLOCK") == nullptr || getenv("LTX_CONV_BLOCK")[0] != '0';  // A/B hook
+    const bool blk_on = ltx_opt(OPT_CONV_BLOCK) != 0;  // A/B option "conv_block"
     if (blk_on && (d.H * d.W) % 192 == 0 && ((d.H * d.W) / 192 < 8 || (d.H * d.W) / 192 % 8 == 0)) g.geom.blk_rg = d.H * d.W / 192;
     ep.bias_n = cw.b;
     g.ep = ep;

@@ -287,8 +287,13 @@ class LTXPipeline {
         std::vector<uint16_t> ctxBits;
         std::vector<int32_t> mask;
         buildContext(emb, useCFG, ctxBits, mask);
-        ltx_denoise_options opt{config.cfgScale, config.guidanceRescale, config.stgScale, config.stgBlocks.data(),
-                                int(config.stgBlocks.size()), config.geGamma};
+        ltx_denoise_options opt = LTX_DENOISE_OPTIONS_INIT;
+        opt.cfg_scale = config.cfgScale;
+        opt.guidance_rescale = config.guidanceRescale;
+        opt.stg_scale = config.stgScale;
+        opt.stg_blocks = config.stgBlocks.data();
+        opt.n_stg_blocks = int(config.stgBlocks.size());
+        opt.ge_gamma = config.geGamma;
         if (image) {  // per-token timesteps + frame-0 slice Euler (LTXPipeline.swift:2191-2401)
             opt.cond_latent = image->imageLatent.data();
             opt.image_cond_noise_scale = config.imageCondNoiseScale;
@@ -341,7 +346,7 @@ class LTXPipeline {
         std::vector<uint16_t> ctxBits;
         std::vector<int32_t> mask;
         buildContext(emb, false, ctxBits, mask);
-        ltx_denoise_options opt{1.0f, 0.f, 0.f, nullptr, 0, 0.f};
+        ltx_denoise_options opt = LTX_DENOISE_OPTIONS_INIT;
         struct Box { GenerationProgressCallback cb; } box{onProgress};
         auto thunk = [](int step, int total, float sigma, void* user) {
             Box* b = static_cast<Box*>(user);

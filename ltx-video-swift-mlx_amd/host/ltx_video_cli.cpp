@@ -40,6 +40,7 @@ struct Args {
     std::string noiseRng = "native";
     int vaeTile = 0, vaeOverlap = 1;
     int numLayers = 0, numHeads = 0, captionChannels = 0;  // reduced architectures for tests (0 = reference default)
+    std::vector<std::pair<std::string, int>> hipOptions;   // --hip-option name=value -> ltx_ctx_set_option (the library reads no environment)
 };
 
 [[noreturn]] void usage(int code) {
@@ -52,7 +53,8 @@ struct Args {
                  "  [--transformer-quant bf16|qint8|int4] [--two-stage] [--distilled-lora] [--profile] [--dry-run] [--debug]\n"
                  "  [--embeddings file] [--vae-weights file] [--upscaler-weights file] [--distilled-lora-path file]\n"
                  "  [--vae-tile N] [--vae-overlap N] [--png-dir dir] [--gemma-hidden-states file] [--connector-weights file]\n"
-                 "  [--image-tensor file] [--noise-rng native|mlx]\n";
+                 "  [--image-tensor file] [--noise-rng native|mlx] [--hip-option name=value]...\n"
+                 "options     List the library's launcher switches (name, default, range, numerics flag) for --hip-option\n";
     std::exit(code);
 }
 
@@ -103,6 +105,12 @@ Args parse_generate(int argc, char** argv, int start) {
         else if (k == "--vae-tile") a.vaeTile = std::stoi(need(i));
         else if (k == "--png-dir") a.pngDir = need(i);
         else if (k == "--noise-rng") a.noiseRng = need(i);
+        else if (k == "--hip-option") {
+            const std::string kv = need(i);
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos || eq == 0 || eq + 1 >= kv.size()) throw ValidationError("--hip-option expects name=value, got '" + kv + "'");
+            a.hipOptions.emplace_back(kv.substr(0, eq), std::stoi(kv.substr(eq + 1)));
+        }
         else if (k == "--gemma-hidden-states") a.hiddenStates = need(i);
         else if (k == "--connector-weights") a.connectorWeights = need(i);
         else if (k == "--image-tensor") a.imageTensor = need(i);
@@ -154,6 +162,9 @@ PrecomputedEmbeddings read_embeddings(const std::string& path) {
 
 int run_generate(const Args& a) {
     const std::vector<int> stg = parse_blocks(a.stgBlocks);
+    for (const auto& kv : a.hipOptions)  // process-wide launcher switches (ltx-video options lists them); an unknown name or value is a usage error
+        if (ltx_ctx_set_option(nullptr, kv.first.c_str(), kv.second) != LTX_OK)
+            throw ValidationError("--hip-option " + kv.first + "=" + std::to_string(kv.second) + ": " + ltx_last_error(nullptr));
     // same banner as Generate.run (LTXVideoCLI.swift:138-166)
     std::cout << "LTX-2 Video Generation\n======================\n";
     std::cout << "Mode: " << (a.image.empty() ? "text-to-video" : "image-to-video") << "\n";
@@ -400,6 +411,17 @@ int main(int argc, char** argv) {
             std::cout << "LTX-Video (MI355X / libltxhip) version " << ltx_version() << "\n"
                       << "Models: distilled (8 steps, CFG 1.0, " << unifiedWeightsFilename(LTXModel::distilled) << "), dev (40 steps, CFG 4.0, "
                       << unifiedWeightsFilename(LTXModel::dev) << ")\nConstraints: width/height % 32 == 0 (two-stage: % 64), frames = 8n+1\n";
+            return 0;
+        }
+        if (sub == "options") {  // ltx_option_info: the one table behind ltx_ctx_set_option; no GPU needed
+            const int n = ltx_option_info(-1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            std::cout << "libltxhip ABI revision " << ltx_abi_version() << ", " << n << " options (numerics: * = moves results by rounding / accumulation order)\n";
+            for (int i = 0; i < n; ++i) {
+                const char *name = nullptr, *doc = nullptr;
+                int d = 0, lo = 0, hi = 0, num = 0;
+                ltx_option_info(i, &name, &d, &lo, &hi, &num, &doc);
+                std::cout << "  " << (num ? "* " : "  ") << name << " = " << d << "  [" << lo << ", " << hi << "]  " << doc << "\n";
+            }
             return 0;
         }
         if (sub == "download") throw ValidationError("download is not available: this path has no network access");

@@ -135,7 +135,7 @@ public final class LTXPipelineHIP {
         try stg.withUnsafeBufferPointer { stgPtr in
             try (imageLatent ?? []).withUnsafeBufferPointer { img in
                 try (injectionNoise ?? []).withUnsafeBufferPointer { inj in
-                    var opt = ltx_denoise_options(cfg_scale: config.cfgScale, guidance_rescale: config.guidanceRescale, stg_scale: config.stgScale,
+                    var opt = ltx_denoise_options(struct_size: UInt32(MemoryLayout<ltx_denoise_options>.size), cfg_scale: config.cfgScale, guidance_rescale: config.guidanceRescale, stg_scale: config.stgScale,
                                                   stg_blocks: stgPtr.baseAddress, n_stg_blocks: Int32(stgPtr.count), ge_gamma: config.geGamma,
                                                   cond_latent: imageLatent == nil ? nil : img.baseAddress,
                                                   image_cond_noise_scale: config.imageCondNoiseScale,

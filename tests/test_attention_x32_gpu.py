@@ -1,4 +1,4 @@
-"""The 32x32x16 attention stream (attn_fwd_kernel_x32_asm, tools/gen_attn_x32.py; LTX_ATTN_IMPL=5) against an f32 softmax reference.
+"""The 32x32x16 attention stream (attn_fwd_kernel_x32_asm, tools/gen_attn_x32.py; option "attn_impl" = 5) against an f32 softmax reference.
 
 It takes unmasked launches with prescaled Q (scale <= 0 at the ABI: Q carries (1/sqrt(128)) * log2(e), LTXAttention.swift:192-214
 with the scale folded into the q-norm + RoPE pass) and whole 64-key tiles; any number of query rows. What is new against the
@@ -30,8 +30,10 @@ LN2 = math.log(2.0)
 
 
 @pytest.fixture
-def x32(monkeypatch):
-    monkeypatch.setenv("LTX_ATTN_IMPL", "5")
+def x32(ltx):
+    ltx.set_option("attn_impl", 5)
+    yield
+    ltx.set_option("attn_impl", 0)
 
 
 def _run(ctx, qd, kd, vt, H, Tq):

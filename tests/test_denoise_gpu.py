@@ -195,3 +195,41 @@ def test_context_cache_keys_do_not_collide_across_modes(ltx, oracle, gpu_ctx, mo
         c = prompts[p] if "cfg_scale" in kw else prompts[p][1:2]
         got = run(c, versions[p], **kw)
         assert np.array_equal(got, want[(p, m)]), (p, m)
+
+
+def test_denoise_options_struct_size_is_honoured(ltx, oracle, gpu_ctx, model):
+    """ABI revision 2 (round-4 advice): ltx_denoise_options starts with the size the CALLER compiled. 0 (a revision-1 host, or a struct
+    nobody initialised) is refused with a message that names the fix; a size that stops before `step_stats` (a host built before that
+    field existed) runs and the library does NOT touch the bytes behind the declared size - here a poisoned pointer that would fault if
+    it were written through."""
+    import ctypes as C
+
+    from importlib import import_module
+
+    lib_mod = import_module("ltx-video-swift-mlx_amd._lib")
+    cfg, ocfg, w = model
+    F, H, W, S = 1, 4, 4, 16
+    noise, cx = _inputs(oracle, ocfg, F, H, W, S, 9)
+    sig = np.ascontiguousarray(ltx.sigmas(True, 8, F * H * W), dtype=np.float32)
+    lat0 = np.ascontiguousarray(noise * sig[0], dtype=np.float32)
+    bits = np.ascontiguousarray(ltx.f32_to_bf16_bits(cx))
+    cb = lib_mod.PROGRESS_CB(lambda s, t, sg, u: None)
+
+    def call(size, step_stats=None):
+        lat = lat0.copy()
+        o = lib_mod.DenoiseOptions(size, 1.0, 0.0, 0.0, None, 0, 0.0, None, 0.0, None, 0, step_stats)
+        rc = ltx.lib.ltx_denoise(gpu_ctx._h, lat.ctypes.data_as(C.c_void_p), F, H, W, sig.ctypes.data_as(C.POINTER(C.c_float)), len(sig),
+                                 bits.ctypes.data_as(C.c_void_p), None, S, C.byref(o), cb, None)
+        return rc, lat
+
+    rc, _ = call(0)
+    assert rc == 2 and "struct_size" in ltx.lib.ltx_last_error(gpu_ctx._h).decode()
+    full = C.sizeof(lib_mod.DenoiseOptions)
+    rc, ref = call(full)
+    assert rc == 0
+    short = lib_mod.DenoiseOptions.step_stats.offset   # the revision-2 core: everything up to and including `shard`
+    rc, got = call(short, step_stats=C.c_void_p(0x10))  # behind the declared size: must not be read
+    assert rc == 0 and np.array_equal(got, ref)
+    stats = np.zeros((len(sig) - 1, 4), np.float32)
+    rc, got = call(full, step_stats=stats.ctypes.data_as(C.c_void_p))
+    assert rc == 0 and np.array_equal(got, ref) and np.abs(stats[:, 1]).min() > 0

@@ -1,5 +1,5 @@
 """Kernels that were built, measured and NOT selected: the generated-assembly one-wave-per-SIMD GEMMs (tile_cfg
-71-74), the phased 8-wave GEMM (41/42) and the plain-HIP layout reference of the 48-query attention kernel (LTX_ATTN_IMPL=3). They
+71-74), the phased 8-wave GEMM (41/42) and the plain-HIP layout reference of the 48-query attention kernel (option "attn_impl" = 3). They
 are not in the product library; these tests need the experiments build:
 
     make -C ltx-video-swift-mlx_amd/csrc EXPERIMENTS=1
@@ -84,29 +84,32 @@ def test_gemm_pingpong_integer_exact(gpu_ctx, cfg, M, N, K, reps):
         assert np.array_equal(got, ref), f"rep {r}: {np.count_nonzero(got != ref)} wrong, max diff {np.abs(got - ref).max()}"
 
 
-def test_attention_layout_reference_kernel(gpu_ctx, monkeypatch):
+def test_attention_layout_reference_kernel(ltx, gpu_ctx):
     """attn_fwd_kernel_w48_ref (plain HIP): pins the LDS images / operand mapping the assembly kernel uses - delta softmax, exact V rows."""
     from test_kernels_gpu import _attn_inputs
 
-    monkeypatch.setenv("LTX_ATTN_IMPL", "3")
-    B, H, Tq, Tk = 1, 2, 192, 512
-    D = H * 128
-    rng = np.random.default_rng(0)
-    sel = rng.integers(0, Tk, (H, Tq))
-    q = np.zeros((B, Tq, D), np.float32)
-    k = np.zeros((B, Tk, D), np.float32)
-    codes = rng.choice([-1.0, 1.0], (H, Tk, 128)).astype(np.float32)
-    for h in range(H):
-        k[0, :, h * 128:(h + 1) * 128] = codes[h]
-        q[0, :, h * 128:(h + 1) * 128] = codes[h][sel[h]] * 8.0
-    v = rng.integers(-8, 9, (B, Tk, D)).astype(np.float32)
-    qd, kd, vd, vt = _attn_inputs(rng, B, H, Tq, Tk, q=q, k=k, v=v)
-    o = torch.empty((B, Tq, D), device="cuda", dtype=torch.bfloat16)
-    gpu_ctx.op_attention(qd, kd, vt, None, H, o, 1.0 / math.sqrt(128.0))
-    torch.cuda.synchronize()
-    got = as_f32(o)
-    for h in range(H):
-        assert np.abs(got[0, :, h * 128:(h + 1) * 128] - v[0, sel[h], h * 128:(h + 1) * 128]).max() <= 1e-2
+    ltx.set_option("attn_impl", 3)
+    try:
+        B, H, Tq, Tk = 1, 2, 192, 512
+        D = H * 128
+        rng = np.random.default_rng(0)
+        sel = rng.integers(0, Tk, (H, Tq))
+        q = np.zeros((B, Tq, D), np.float32)
+        k = np.zeros((B, Tk, D), np.float32)
+        codes = rng.choice([-1.0, 1.0], (H, Tk, 128)).astype(np.float32)
+        for h in range(H):
+            k[0, :, h * 128:(h + 1) * 128] = codes[h]
+            q[0, :, h * 128:(h + 1) * 128] = codes[h][sel[h]] * 8.0
+        v = rng.integers(-8, 9, (B, Tk, D)).astype(np.float32)
+        qd, kd, vd, vt = _attn_inputs(rng, B, H, Tq, Tk, q=q, k=k, v=v)
+        o = torch.empty((B, Tq, D), device="cuda", dtype=torch.bfloat16)
+        gpu_ctx.op_attention(qd, kd, vt, None, H, o, 1.0 / math.sqrt(128.0))
+        torch.cuda.synchronize()
+        got = as_f32(o)
+        for h in range(H):
+            assert np.abs(got[0, :, h * 128:(h + 1) * 128] - v[0, sel[h], h * 128:(h + 1) * 128]).max() <= 1e-2
+    finally:
+        ltx.set_option("attn_impl", 0)
 
 
 @pytest.mark.parametrize("M,N,K,split", [(128, 64, 64, 1), (128, 4096, 4096, 1), (128, 4096, 4096, 4), (77, 200, 1024, 2), (1, 64, 256, 1),

@@ -34,6 +34,40 @@ def test_abi_exports_match_header(ltx):
     assert set(lib_mod.SIGNATURES) == declared
 
 
+def test_abi_revision_and_option_table(ltx):
+    """Round 5 (ABI revision 2): the launcher switches are ONE table behind ltx_ctx_set_option - no GPU needed to read or move them - the
+    library's soname carries the revision, ltx_denoise_options starts with its size, and the product library contains no getenv of an
+    LTX_* name (only the -DLTX_EXPERIMENTS build seeds the table from the environment)."""
+    import subprocess
+
+    from importlib import import_module
+
+    lib_mod = import_module("ltx-video-swift-mlx_amd._lib")
+    assert ltx.lib.ltx_abi_version() == 2
+    hdr = open(os.path.join(ROOT, "include", "ltxhip.h")).read()
+    assert re.search(r"#define LTX_ABI_VERSION 2\b", hdr)
+    assert lib_mod.DenoiseOptions._fields_[0][0] == "struct_size" and lib_mod.DenoiseOptions.struct_size.offset == 0
+    table = ltx.option_table()
+    names = [t[0] for t in table]
+    assert len(names) == len(set(names)) >= 20 and {"qk_f32", "split_f32", "finish_rows", "conv_persist", "sp_overlap"} <= set(names)
+    for name, default, lo, hi, numerics, doc in table:
+        assert lo <= default <= hi and doc and ltx.get_option(name) == default, name   # nothing in the environment moved a default
+    assert dict((t[0], t[4]) for t in table)["qk_f32"] is True and dict((t[0], t[4]) for t in table)["finish_norm"] is False
+    with ltx.options(qk_f32=1, finish_rows=4):
+        assert ltx.get_option("qk_f32") == 1 and ltx.get_option("finish_rows") == 4
+    assert ltx.get_option("qk_f32") == 0 and ltx.get_option("finish_rows") == 1
+    for bad in (("nope", 1), ("finish_rows", 0), ("qk_f32", 2)):
+        with pytest.raises(ltx.LTXError):
+            ltx.set_option(*bad)
+    # soname = ABI revision; no LTX_* string that looks like an environment hook is left in the product library's read-only data
+    dyn = subprocess.run(["readelf", "-d", lib_mod.SO_PATH], capture_output=True, text=True).stdout
+    if "experiments=0" in ltx.lib.ltx_build_info().decode():
+        assert "libltxhip.so.2" in dyn, dyn
+        blob = open(lib_mod.SO_PATH, "rb").read()
+        for old in (b"LTX_QK_F32", b"LTX_SPLIT_F32", b"LTX_FINISH_ROWS", b"LTX_CONV_PERSIST", b"LTX_ATTN_IMPL", b"LTX_GEMM_FORCE", b"LTX_SP_OVERLAP"):
+            assert old not in blob, old
+
+
 # ---- R1 ----
 @pytest.mark.parametrize("whf,expect", [((256, 256, 9), (2, 8, 8)), ((768, 512, 25), (4, 16, 24)),
                                         ((1536, 1024, 25), (4, 32, 48)), ((768, 512, 201), (26, 16, 24)),

@@ -258,15 +258,13 @@ def test_attention_late_maximum(gpu_ctx):
 
 
 @pytest.fixture
-def attn_impl(monkeypatch):
-    """Force one attention kernel through the launcher's A/B switch (LTX_ATTN_IMPL: 1 = 4-wave, 2 = ping-pong, 3 = plain-HIP layout
-    reference of the 48-query kernel, 4 = its assembly main loop; unset = the launcher's grid-fill choice)."""
+def attn_impl(ltx):
+    """Force one attention kernel through the launcher's A/B switch (option "attn_impl": 1 = 4-wave, 2 = ping-pong, 3 = plain-HIP layout
+    reference of the 48-query kernel, 4 = its assembly main loop; 0 = the launcher's grid-fill choice)."""
     def force(impl):
-        if impl is None:
-            monkeypatch.delenv("LTX_ATTN_IMPL", raising=False)
-        else:
-            monkeypatch.setenv("LTX_ATTN_IMPL", str(impl))
-    return force
+        ltx.set_option("attn_impl", 0 if impl is None else int(impl))
+    yield force
+    ltx.set_option("attn_impl", 0)
 
 
 def _attn_inputs(rng, B, H, Tq, Tk, q=None, k=None, v=None):

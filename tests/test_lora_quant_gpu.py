@@ -209,7 +209,7 @@ def test_q8_gemm_dequantises_in_its_b_stage(ltx, oracle, gpu_ctx, M, N, K, split
 
 
 def test_quantised_few_row_forward_is_the_scratch_path_forward(ltx, oracle, tmp_path):
-    """The whole forward at few tokens (every Linear's codes de-quantised in the GEMMs) against the same model with LTX_QB_OFF=1
+    """The whole forward at few tokens (every Linear's codes de-quantised in the GEMMs) against the same model with option "qb_off" = 1
     semantics, i.e. against a many-row-style scratch de-quantisation: here checked through the oracle - both must meet the 8-bit
     tolerance - and through determinism (two forwards bit-identical)."""
     cfg, ocfg, w, path, inp = _setup(ltx, oracle, tmp_path, seed=61)

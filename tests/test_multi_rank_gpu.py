@@ -299,14 +299,14 @@ def test_native_rccl_group_of_one(ltx, oracle, gpu_ctx, weights, tmp_path):
         n0 = ctx.dist_info()["collectives"]
         ctx.dit_forward_dev(tokens, cdev, ts, None, F, H, W, va, ctx_version=0)
         assert ctx.dist_info()["collectives"] == n0
-        os.environ["LTX_SP_SELFTEST"] = "1"
+        ctx.set_option("sp_selftest", 1)
         try:
             for _ in range(3):
                 ctx.dit_forward_dev(tokens, cdev, ts, None, F, H, W, vb, ctx_version=0)
                 torch.cuda.synchronize()
                 assert torch.equal(va, vb)
         finally:
-            del os.environ["LTX_SP_SELFTEST"]
+            ctx.set_option("sp_selftest", 0)
         assert ctx.dist_info()["collectives"] == n0 + 3 * 2 * 3  # K and V^T gathers of three blocks, three forwards
         with pytest.raises(ltx.LTXError):  # CFG sharding needs two ranks
             ctx.denoise_dev(l0, sig, torch.cat([cdev, cdev]), None, F, H, W, cfg_scale=2.0, shard=ltx.SHARD_CFG)

@@ -45,7 +45,7 @@ def main():
             for impl in impls:  # interleaved rounds in one process (A/B)
                 if impl in bad:
                     continue
-                os.environ["LTX_ATTN_IMPL"] = impl
+                ltx.set_option("attn_impl", int(impl))
                 try:
                     ctx.op_attention(Q, K, Vt, bias, H, O, 0.0)  # prescaled Q, as the DiT launches it
                 except Exception:

@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo' if os.path.exists('/root/repo/tests') else os.en
 ltx = importlib.import_module('ltx-video-swift-mlx_amd')
 ctx = ltx.Context(0)
 def run(impl, T, S, H, seed=0):
-    os.environ['LTX_ATTN_IMPL'] = impl
+    ltx.set_option('attn_impl', int(impl))
     g = torch.Generator(device='cuda').manual_seed(seed)
     Q = torch.randn(1, T, H*128, device='cuda', generator=g).to(torch.bfloat16)
     K = torch.randn(1, S, H*128, device='cuda', generator=g).to(torch.bfloat16)

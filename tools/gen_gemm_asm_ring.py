@@ -418,7 +418,7 @@ class Gen:
 
 def main():
     g = Gen()
-    lines = g.build()
+    lines = ["s_mov_b32 s76, m0"] + g.build() + ["s_mov_b32 m0, s76"]   # m0 saved / restored instead of clobbered (see gen_attn_w48.py)
     here = os.path.dirname(os.path.abspath(__file__))
     d = os.path.join(here, "..", "ltx-video-swift-mlx_amd", "csrc")
     base = "gemm_asm_hybrid_192x128" if BDIRECT else "gemm_asm_ring_192x128"
@@ -426,7 +426,7 @@ def main():
         f.write("// GENERATED by tools/gen_gemm_asm_ring.py - do not edit. gfx950 assembly main loop of gemm_bf16_kernel_asm_ring (gemm.hip).\n")
         for ln in lines:
             f.write('"' + ln + '\\n\\t"\n')
-    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(MI * NI * 4)] + [f"s{i}" for i in range(36, 76)] + ["m0", "vcc", "scc", "memory"]
+    clob = [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(MI * NI * 4)] + [f"s{i}" for i in range(36, 77)] + ["vcc", "scc", "memory"]
     with open(os.path.join(d, base + "_clobbers.inc"), "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm_ring.py - do not edit. Registers the assembly main loop assigns by hand.\n")
         for i in range(0, len(clob), 12):
