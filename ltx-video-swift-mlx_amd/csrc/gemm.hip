@@ -1231,6 +1231,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
 
 
 #include "conv_halo.inc"
+#include "conv_halo2.inc"
 
 #ifdef LTX_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------
@@ -2331,19 +2332,53 @@ static bool conv_halo_takes(const GemmArgs& a) {
     return w_ok && !a.ep.out_bf16_t && !a.ep.gate;  // (its epilogue is the scalar-gate form)
 }
 template <int BN>
+static void launch_conv_halo(const GemmArgs& a, hipStream_t stream);
+// conv_halo2.inc: the 384 x 128 tile of two image rows (W == 192: the VAE decoder's 128-channel stage at 768 x 512)
+static bool conv_halo2_takes(const GemmArgs& a) {
+    if (ltx_opt(OPT_CONV_TALL) == 0 || !conv_halo_takes(a)) return false;
+    const Conv3dGeom& q = a.geom;
+    return q.W == 192 && q.H % 2 == 0 && a.N == 128 && a.M % 384 == 0 && a.tile_count == 0 && a.tile0 == 0 && !a.ep.d2s && a.ldb % 8 == 0 &&
+           (long)q.F * q.H * 192 * q.C < (1L << 31);
+}
+static void launch_conv_halo2(const GemmArgs& a, hipStream_t stream) {
+    constexpr int smem = 4 * 25 * 1024 + 1024 + 3 * 128 * ROW_BYTES;
+    static PerDeviceOnce attr_set;
+    attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)conv3d_halo2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
+    const int tall = a.M / 384;
+    const int ncu = device_cu_count() & ~7;
+    // Whole rounds of tall tiles, one workgroup per CU walking its XCD's chunk; what is left over (768 x 512: 1600 = 6 x 256 + 64 tall
+    // tiles) would keep a quarter of the chip busy for a seventh round, so it runs as 192-row tiles of conv_halo.inc behind the main launch
+    // (128 tiles = half a round of tiles half the size).
+    int main_tiles = tall;
+    if (ncu >= 8 && tall > ncu && tall % ncu != 0 && tall % ncu <= ncu / 2) main_tiles = tall / ncu * ncu;
+    GemmArgs b = a;
+    b.tile_count = main_tiles == tall ? 0 : main_tiles;
+    const int grid = (main_tiles > ncu && ncu >= 8) ? ncu : main_tiles;
+    hipLaunchKernelGGL(conv3d_halo2_kernel<true>, dim3(grid), dim3(512), smem, stream, b);
+    HIP_CHECK(hipGetLastError());
+    if (main_tiles < tall) {
+        GemmArgs t = a;
+        t.tile0 = 2 * main_tiles;
+        t.tile_count = 2 * (tall - main_tiles);
+        launch_conv_halo<128>(t, stream);
+    }
+}
+template <int BN>
 static void launch_conv_halo(const GemmArgs& a, hipStream_t stream) {
     constexpr int smem = 2 * 32 * 1024 + 6 * BN * ROW_BYTES;
     static PerDeviceOnce attr_set;
     attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)conv3d_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
     const int all_tiles = ((a.M + 191) / 192) * ((a.N + BN - 1) / BN);
     const int tiles = a.tile_count ? a.tile_count : all_tiles;
-    LTX_REQUIRE(tiles <= all_tiles, "conv halo: tile window of %d tiles outside %d", tiles, all_tiles);
+    LTX_REQUIRE(a.tile0 >= 0 && a.tile0 + tiles <= all_tiles && (a.tile0 == 0 || a.N <= BN), "conv halo: tile window [%d, %d) outside %d", a.tile0, a.tile0 + tiles, all_tiles);
     // persistent above one round: one workgroup per CU walks the tiles of its XCD's chunk and requests the next tile's first operands
     // before the epilogue of the current one (conv_halo.inc); option "conv_persist" = 0 restores one workgroup per tile (A/B)
     const bool persist = ltx_opt(OPT_CONV_PERSIST) != 0;
     const int ncu = device_cu_count() & ~7;
     const int grid = (persist && tiles > ncu && ncu >= 8) ? ncu : tiles;
-    hipLaunchKernelGGL(conv3d_halo_kernel<BN>, dim3(grid), dim3(512), smem, stream, a);
+    GemmArgs b = a;
+    b.conv_stagger = ltx_opt(OPT_CONV_STAGGER) != 0;
+    hipLaunchKernelGGL(conv3d_halo_kernel<BN>, dim3(grid), dim3(512), smem, stream, b);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -2361,8 +2396,10 @@ void launch_gemm_bf16_cfg(const GemmArgs& a, int cfg, hipStream_t stream) {
     // cfg 0..2: v1 (2-stage, one barrier + full drain per K-tile); cfg 10..: v2 (ring + counted vmcnt)
     if (a.conv) {
         switch (cfg) {
-            case 21:  // 8 waves (4x2), per-wave 48x64: the halo-staged kernel where it applies, else the 4-slot ring
-                if (conv_halo_takes(a)) launch_conv_halo<128>(a, stream); else launch_v2<192, 128, 4, true, 4, 2>(a, stream);
+            case 21:  // 8 waves (4x2), per-wave 48x64: the halo-staged kernel where it applies (its tall form where THAT applies), else the 4-slot ring
+                if (conv_halo2_takes(a)) launch_conv_halo2(a, stream);
+                else if (conv_halo_takes(a)) launch_conv_halo<128>(a, stream);
+                else launch_v2<192, 128, 4, true, 4, 2>(a, stream);
                 break;
 #ifdef LTX_EXPERIMENTS  // measured, not selected for convs (VAE decode 19.4 ms with the 256x128 ring, 22.8 with the two-stage kernel, against 17.0)
             case 0: launch_one<128, 128, true>(a, stream); break;
@@ -2534,6 +2571,10 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         // r CUs while the others idle (the VAE's 256-channel stage: 832 tiles = 3.25 rounds, 19 % of every conv). Run the full
         // rounds as one launch and the remainder as a split-K launch over all CUs (window fields of GemmArgs).
         const bool no_tail = ltx_opt(OPT_CONV_NO_TAIL) != 0;  // A/B option "conv_no_tail"
+        if (!cc && conv_default == 21 && conv_halo2_takes(a)) {  // the tall kernel balances its own last round (launch_conv_halo2)
+            launch_gemm_bf16_cfg(a, 21, stream);
+            return;
+        }
         if (!no_tail && !cc && conv_default == 21 && a.split_k <= 1 && a.split_ws && !a.ep.d2s && a.N % 4 == 0 && !a.ep.gate && !a.ep.bias_m &&
             !a.ep.out_bf16_t && a.group_m > 0) {
             const int tiles_m = (a.M + 191) / 192, tiles_n = (a.N + 127) / 128, tiles = tiles_m * tiles_n;

@@ -209,3 +209,34 @@ def test_conv3d_vs_golden_fixture(gpu_ctx):
     torch.cuda.synchronize()
     ref = y[0].transpose(1, 2, 3, 0)
     assert np.abs(out.cpu().numpy() - ref).max() <= 1e-4  # inputs are bf16-exact: accumulation order only
+
+
+@pytest.mark.parametrize("F,H,Cin,causal", [(1, 2, 128, False), (2, 4, 64, True), (3, 6, 128, False), (5, 130, 128, True), (2, 258, 192, False)])
+def test_tall_conv_tile_integer_exact(ltx, gpu_ctx, F, H, Cin, causal):
+    """conv_halo2.inc (round 5): W == 192, N == 128 convs run as 384 x 128 tiles of TWO image rows - four staged rows per (frame tap,
+    channel half) serve the tile's 2 x 3 (row, dy) pairs, the K loop runs on across a workgroup's tiles. Small integers: any summation
+    order gives the same f32, so equality with torch's conv3d is exact. Shapes: one tile (both rows are their own reflections), reflect at
+    the top AND bottom of a frame inside one tile walk, causal and non-causal frame clamps, 64 / 128 / 192 channels (1 / 2 / 3 halves),
+    5 x 130 x 192 = 325 tall tiles (persistent walk with uneven XCD chunks) and 2 x 258 = 258 tiles: two whole-round launches + a 192-row
+    tail window through conv_halo.inc. The same launch with option conv_tall = 0 (the 192-row kernel) must give the same integers."""
+    import torch.nn.functional as F_
+
+    W, Cout = 192, 128
+    g = torch.Generator(device="cuda").manual_seed(F * 1000 + H)
+    x = torch.randint(-2, 3, (1, Cin, F, H, W), generator=g, device="cuda", dtype=torch.int8).float()
+    w = torch.randint(-2, 3, (Cout, Cin, 3, 3, 3), generator=g, device="cuda", dtype=torch.int8).float()
+    b = torch.randint(-4, 5, (Cout,), generator=g, device="cuda", dtype=torch.int8).float()
+    xd = x[0].permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)
+    wd = torch.from_numpy(relayout(w.cpu().numpy())).to(torch.bfloat16).cuda()
+    out = torch.full((F, H, W, Cout), float("nan"), device="cuda")
+    gpu_ctx.op_conv3d(xd, wd, b, out, causal=causal)
+    torch.cuda.synchronize()
+    xp = F_.pad(x, (1, 1, 1, 1, 0, 0), mode="reflect")
+    xp = torch.cat([xp[:, :, :1], xp[:, :, :1], xp], 2) if causal else torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], 2)
+    ref = F_.conv3d(xp.double(), w.double(), b.double())[0].permute(1, 2, 3, 0).float()
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+    old = torch.full_like(out, float("nan"))
+    with ltx.options(conv_tall=0):
+        gpu_ctx.op_conv3d(xd, wd, b, old, causal=causal)
+        torch.cuda.synchronize()
+    assert torch.equal(old, ref)
