@@ -2333,35 +2333,50 @@ static bool conv_halo_takes(const GemmArgs& a) {
 }
 template <int BN>
 static void launch_conv_halo(const GemmArgs& a, hipStream_t stream);
-// conv_halo2.inc: the 384 x 128 tile of two image rows (W == 192: the VAE decoder's 128-channel stage at 768 x 512)
-static bool conv_halo2_takes(const GemmArgs& a) {
-    if (ltx_opt(OPT_CONV_TALL) == 0 || !conv_halo_takes(a)) return false;
+// conv_halo2.inc: the 384 x 128 tile of NRT image rows -> 0 = not this launch, else NRT (2: W == 192, 4: W == 96)
+static int conv_halo2_takes(const GemmArgs& a) {
+    if (ltx_opt(OPT_CONV_TALL) == 0 || !conv_halo_takes(a)) return 0;
     const Conv3dGeom& q = a.geom;
-    return q.W == 192 && q.H % 2 == 0 && a.N == 128 && a.M % 384 == 0 && a.tile_count == 0 && a.tile0 == 0 && !a.ep.d2s && a.ldb % 8 == 0 &&
-           (long)q.F * q.H * 192 * q.C < (1L << 31);
+    const int nrt = q.W == 192 ? 2 : (q.W == 96 ? 4 : 0);
+    if (!nrt || q.H % nrt != 0 || a.N % 128 != 0 || a.M % 384 != 0 || a.tile_count != 0 || a.tile0 != 0 || a.ldb % 8 != 0) return 0;
+    if (nrt == 4 && q.C % 128 != 0) return 0;                       // (the row-slot rotation must come back to slot 0 or 4 at a tile boundary)
+    if (a.ep.d2s != 0 && a.ep.d2s != 1) return 0;                   // plain / fused-PixelNorm / depth-to-space epilogues (conv_out's d2s == 3 has N = 48)
+    if (a.ep.pn_out && a.N != 128) return 0;
+    if ((long)q.F * q.H * q.W * q.C >= (1L << 31) || (long)a.N * a.ldb >= (1L << 31)) return 0;  // 32-bit element offsets
+    return nrt;
 }
-static void launch_conv_halo2(const GemmArgs& a, hipStream_t stream) {
-    constexpr int smem = 4 * 25 * 1024 + 1024 + 3 * 128 * ROW_BYTES;
+template <int NRT>
+static void launch_conv_halo2_nrt(const GemmArgs& a, hipStream_t stream) {
+    constexpr int RSP = (384 / NRT + 2 + 7) / 8, NS = NRT == 2 ? 4 : 8;
+    constexpr int smem = NS * RSP * 1024 + 1024 + 3 * 128 * ROW_BYTES;
     static PerDeviceOnce attr_set;
-    attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)conv3d_halo2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
-    const int tall = a.M / 384;
+    attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)conv3d_halo2_kernel<NRT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
+    const int tiles_n = a.N / 128, rows_t = a.M / 384, tall = rows_t * tiles_n;
     const int ncu = device_cu_count() & ~7;
-    // Whole rounds of tall tiles, one workgroup per CU walking its XCD's chunk; what is left over (768 x 512: 1600 = 6 x 256 + 64 tall
-    // tiles) would keep a quarter of the chip busy for a seventh round, so it runs as 192-row tiles of conv_halo.inc behind the main launch
-    // (128 tiles = half a round of tiles half the size).
+    // Whole rounds of tall tiles, one workgroup per CU walking its XCD's chunk; what is left over (768 x 512, 128 channels: 1600 = 6 x 256
+    // + 64 tall tiles) would keep a quarter of the chip busy for a seventh round, so it runs as 192-row tiles of conv_halo.inc behind the
+    // main launch (128 tiles = half a round of tiles half the size). The window starts at a whole number of that kernel's supertiles
+    // (group_m row tiles x all column tiles) and of this kernel's row tiles.
     int main_tiles = tall;
-    if (ncu >= 8 && tall > ncu && tall % ncu != 0 && tall % ncu <= ncu / 2) main_tiles = tall / ncu * ncu;
+    if (ncu >= 8 && tall > ncu && tall % ncu != 0 && tall % ncu <= ncu / 2) {
+        const int m = tall / ncu * ncu;
+        const int gm = a.group_m > 0 ? a.group_m : 1;
+        if (m % tiles_n == 0 && (2 * (m / tiles_n)) % gm == 0) main_tiles = m;
+    }
     GemmArgs b = a;
     b.tile_count = main_tiles == tall ? 0 : main_tiles;
     const int grid = (main_tiles > ncu && ncu >= 8) ? ncu : main_tiles;
-    hipLaunchKernelGGL(conv3d_halo2_kernel<true>, dim3(grid), dim3(512), smem, stream, b);
+    hipLaunchKernelGGL(conv3d_halo2_kernel<NRT>, dim3(grid), dim3(512), smem, stream, b);
     HIP_CHECK(hipGetLastError());
     if (main_tiles < tall) {
         GemmArgs t = a;
-        t.tile0 = 2 * main_tiles;
-        t.tile_count = 2 * (tall - main_tiles);
+        t.tile0 = 2 * (main_tiles / tiles_n) * tiles_n;  // 192-row tiles in front of the window (conv_halo.inc's order: supertiles of group_m row tiles)
+        t.tile_count = 2 * rows_t * tiles_n - t.tile0;
         launch_conv_halo<128>(t, stream);
     }
+}
+static void launch_conv_halo2(const GemmArgs& a, hipStream_t stream) {
+    if (conv_halo2_takes(a) == 2) launch_conv_halo2_nrt<2>(a, stream); else launch_conv_halo2_nrt<4>(a, stream);
 }
 template <int BN>
 static void launch_conv_halo(const GemmArgs& a, hipStream_t stream) {
@@ -2370,7 +2385,8 @@ static void launch_conv_halo(const GemmArgs& a, hipStream_t stream) {
     attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)conv3d_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
     const int all_tiles = ((a.M + 191) / 192) * ((a.N + BN - 1) / BN);
     const int tiles = a.tile_count ? a.tile_count : all_tiles;
-    LTX_REQUIRE(a.tile0 >= 0 && a.tile0 + tiles <= all_tiles && (a.tile0 == 0 || a.N <= BN), "conv halo: tile window [%d, %d) outside %d", a.tile0, a.tile0 + tiles, all_tiles);
+    // (a window with tile0 > 0 - the tail behind the tall kernel's whole rounds - starts at a whole number of supertiles: launch_conv_halo2_nrt)
+    LTX_REQUIRE(a.tile0 >= 0 && a.tile0 + tiles <= all_tiles, "conv halo: tile window [%d, %d) outside %d", a.tile0, a.tile0 + tiles, all_tiles);
     // persistent above one round: one workgroup per CU walks the tiles of its XCD's chunk and requests the next tile's first operands
     // before the epilogue of the current one (conv_halo.inc); option "conv_persist" = 0 restores one workgroup per tile (A/B)
     const bool persist = ltx_opt(OPT_CONV_PERSIST) != 0;

@@ -211,17 +211,21 @@ def test_conv3d_vs_golden_fixture(gpu_ctx):
     assert np.abs(out.cpu().numpy() - ref).max() <= 1e-4  # inputs are bf16-exact: accumulation order only
 
 
-@pytest.mark.parametrize("F,H,Cin,causal", [(1, 2, 128, False), (2, 4, 64, True), (3, 6, 128, False), (5, 130, 128, True), (2, 258, 192, False)])
-def test_tall_conv_tile_integer_exact(ltx, gpu_ctx, F, H, Cin, causal):
-    """conv_halo2.inc (round 5): W == 192, N == 128 convs run as 384 x 128 tiles of TWO image rows - four staged rows per (frame tap,
-    channel half) serve the tile's 2 x 3 (row, dy) pairs, the K loop runs on across a workgroup's tiles. Small integers: any summation
-    order gives the same f32, so equality with torch's conv3d is exact. Shapes: one tile (both rows are their own reflections), reflect at
-    the top AND bottom of a frame inside one tile walk, causal and non-causal frame clamps, 64 / 128 / 192 channels (1 / 2 / 3 halves),
-    5 x 130 x 192 = 325 tall tiles (persistent walk with uneven XCD chunks) and 2 x 258 = 258 tiles: two whole-round launches + a 192-row
-    tail window through conv_halo.inc. The same launch with option conv_tall = 0 (the 192-row kernel) must give the same integers."""
+@pytest.mark.parametrize("F,H,W,Cin,Cout,causal", [(1, 2, 192, 128, 128, False), (2, 4, 192, 64, 128, True), (3, 6, 192, 128, 128, False),
+                                                    (5, 130, 192, 128, 128, True), (2, 258, 192, 192, 128, False), (2, 6, 192, 128, 256, False),
+                                                    (1, 4, 96, 128, 128, False), (2, 8, 96, 256, 256, True), (3, 132, 96, 128, 384, False),
+                                                    (2, 516, 96, 128, 256, True)])
+def test_tall_conv_tile_integer_exact(ltx, gpu_ctx, F, H, W, Cin, Cout, causal):
+    """conv_halo2.inc (round 5): convs with W == 192 (W == 96) run as 384 x 128 tiles of TWO (FOUR) image rows - four (six) staged rows
+    per (frame tap, channel half) serve the tile's (row, dy) pairs, the K loop runs on across a workgroup's tiles, row slots rotate from
+    group to group (W == 96). Small integers: any summation order gives the same f32, so equality with torch's conv3d is exact. Shapes:
+    one tile (every row its own reflection), reflect at the top AND bottom of a frame inside one tile walk, causal and non-causal frame
+    clamps, 64 / 128 / 192 / 256 channels (1 - 4 halves; W == 96 needs an even number), several column tiles (the weights change from
+    tile to tile while the K loop runs on), 325 tall tiles (persistent walk with uneven XCD chunks), 258 row tiles and 2 x 516 / 4 x 2 column
+    tiles = 516: whole-round launches + a 192-row tail window through conv_halo.inc. The same launch with option conv_tall = 0 (the
+    192-row kernel) must give the same integers."""
     import torch.nn.functional as F_
 
-    W, Cout = 192, 128
     g = torch.Generator(device="cuda").manual_seed(F * 1000 + H)
     x = torch.randint(-2, 3, (1, Cin, F, H, W), generator=g, device="cuda", dtype=torch.int8).float()
     w = torch.randint(-2, 3, (Cout, Cin, 3, 3, 3), generator=g, device="cuda", dtype=torch.int8).float()
