@@ -55,6 +55,7 @@ int main() {
         g.geom.blk_rg = 0;
     }
     if (getenv("CONV_STAGGER")) ltx_opt_set(ltx_opt_find("conv_stagger"), atoi(getenv("CONV_STAGGER")));
+    if (getenv("CONV_TALL")) ltx_opt_set(ltx_opt_find("conv_tall"), atoi(getenv("CONV_TALL")));
     const int cfg = N <= 64 ? 27 : 21;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -65,7 +66,8 @@ int main() {
     (void)hipEventRecord(e1);
     (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-    const int tiles = (int)((P + 191) / 192) * ((N + 127) / 128);
+    const bool tall = conv_halo2_takes(g) != 0;  // (option conv_tall, CONV_TALL=0 turns it off): 384-row tiles, stamps of the main launch only
+    const int tiles = tall ? (int)(P / 384) * (N / 128) / 256 * 256 : (int)((P + 191) / 192) * ((N + 127) / 128);
     if (tiles > 16383) printf("(more tiles than stamp slots: statistics over the first 16383)\n");
     printf("conv %d -> %d at %dx%dx%d: %d tiles, %.1f us per launch, %.0f TFLOP/s\n", C, N, F, H, W, tiles, ms * 1e3 / reps, 2.0 * P * N * 27 * C / (ms / reps * 1e-3) / 1e12);
     static unsigned long long st[16384][10];
@@ -83,6 +85,7 @@ int main() {
            (tmax - tmin) * 0.01, n, pro / n * 0.01, loop / n * 0.01, epi / n * 0.01, drain / n * 0.01, (pro + loop + epi) / n * 0.01);
     printf("  K loop: %.0f shader cycles per tile (s_memtime) over %.2f us wall = %.3f GHz in the loop; %.0f cycles per K-tile of %d\n", cyc / n, loop / n * 0.01,
            cyc / n / (loop / n * 10.0), cyc / n / (27.0 * C / 64.0), 27 * C / 64);
+    if (tall) printf("  (tall kernel: 384 x 128 tiles, a K-tile is 48 MFMAs per wave = 1536 cycles of MFMA issue per SIMD; the 192-row tail window of the launch is not in these statistics)\n");
     printf("  inside the epilogue interval: next tile's addresses %.2f us | epilogue up to the request of the next tile %.2f us | issuing that request %.2f us | rest %.2f us\n",
            tset / n * 0.01, thook0 / n * 0.01, thook / n * 0.01, (epi - tset - thook0 - thook) / n * 0.01);
     double gap = 0; long ngap = 0; double gmax = 0;
