@@ -58,9 +58,9 @@ PEAK_BF16_TFLOPS = 2500.0
 SUSTAINED_BF16_TFLOPS = 2000.0
 HBM_PEAK_GBPS = 8000.0
 # (file, key): since round 4 one collection carries the dense GEMM launches ("gemm_all") and the VAE conv launches ("conv_all") side by side
-TRAFFIC_FILES = (("r04_pmc_traffic_v3.json", "gemm_all"), ("r04_pmc_traffic_v2.json", "gemm_all"), ("r04_pmc_traffic.json", "gemm_all"), ("r03_pmc_traffic.json", "gemm_all"), ("r02_pmc_traffic_v2.json", "gemm_all"),
+TRAFFIC_FILES = (("r05_pmc_traffic.json", "gemm_all"), ("r04_pmc_traffic_v3.json", "gemm_all"), ("r04_pmc_traffic_v2.json", "gemm_all"), ("r04_pmc_traffic.json", "gemm_all"), ("r03_pmc_traffic.json", "gemm_all"), ("r02_pmc_traffic_v2.json", "gemm_all"),
                  ("r02_pmc_traffic.json", "gemm_all"), ("r01_pmc_traffic.json", "gemm_all"))
-VAE_TRAFFIC_FILES = (("r04_pmc_traffic_v3.json", "conv_all"), ("r04_pmc_traffic_v2.json", "conv_all"), ("r04_pmc_traffic.json", "conv_all"), ("r03_pmc_traffic_vae_v2.json", "gemm_all"), ("r03_pmc_traffic_vae.json", "gemm_all"),
+VAE_TRAFFIC_FILES = (("r05_pmc_traffic.json", "conv_all"), ("r04_pmc_traffic_v3.json", "conv_all"), ("r04_pmc_traffic_v2.json", "conv_all"), ("r04_pmc_traffic.json", "conv_all"), ("r03_pmc_traffic_vae_v2.json", "gemm_all"), ("r03_pmc_traffic_vae.json", "gemm_all"),
                      ("r02_pmc_traffic_vae.json", "gemm_all"))
 
 
@@ -832,7 +832,7 @@ def bench_vae(ctx, ltx, torch, dev, F, H, W, iters=3):
         vtraffic, vsrc = pmc_traffic(VAE_TRAFFIC_FILES)  # fabric-side bytes per conv launch, two --pmc passes of tools/bench_vae.py
         res["conv_kernel_tflops"] = round(ach, 1)
         res["conv_ms"] = round(c["ms"] / iters, 3)
-        res["roofline"] = {"bound": "mfma", "kernel": "conv3d_halo_kernel + gemm_bf16_kernel_v2<conv>", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+        res["roofline"] = {"bound": "mfma", "kernel": "conv3d_halo2_kernel + conv3d_halo_kernel + gemm_bf16_kernel_v2<conv>", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": vtraffic, "traffic_source": vsrc,
                            "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / max(1, c["launches"]), 2),
                            "whole_decode_frac": round(12.96 / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4),

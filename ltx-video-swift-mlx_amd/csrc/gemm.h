@@ -103,8 +103,8 @@ struct GemmArgs {
     // B's LDS-DMA loads with the non-temporal policy (once-read weights of a few-row launch: they should not displace the activations
     // every column tile re-reads from the L2). Set by launch_gemm_bf16 for its few-row path; 128x64 ring instance only.
     int b_nt = 0;
-    // halo-staged conv kernel: the second wave of every SIMD issues its LDS-DMA pieces half a barrier interval after the first (round 5;
-    // set by the launcher from option "conv_stagger"; bit-neutral)
+    // 8-wave ring kernels (halo-staged conv, dense and conv ring GEMM): the second wave of every SIMD issues its LDS-DMA pieces half a
+    // barrier interval after the first (round 5; set by the launchers from options "conv_stagger" / "gemm_stagger"; bit-neutral)
     int conv_stagger = 0;
     // 192x256 kernel's split-K only: the CALLER allows the partial tiles to cross the workspace as bf16 (round 4; half the bytes of the
     // partial round trip). An extra rounding of each K range's share before the f32 finish that a plain f32-accumulating GEMM (the

@@ -1123,6 +1123,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     const unsigned long long st1 = wall_clock64();
 #endif
     load_frags(0, foff0, fa0, fb0);
+    const bool late = NW == 8 && g.conv_stagger && wave >= NW / 2;  // wave-uniform (GemmArgs::conv_stagger: option "gemm_stagger" for dense launches)
 
     // One K-tile. STEADY iterations are branch-free so that each half is ONE scheduling region in which the LDS
     // fragment reads and the LDS-DMA issues are interleaved one-for-one with MFMAs (sched_group_barrier): their issue
@@ -1164,7 +1165,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         mfma_first(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (STEADY) {
-            stage(pslot, kt0 + kt + PD);
+            // staggered staging (round 5, as conv_halo.inc): of the two waves that share a SIMD (w, w + NW / 2) the second issues its
+            // LDS-DMA pieces behind this half's MFMAs instead of in front of them, so that the two are not held by their pieces at the
+            // same time. Same loads, same per-wave order, same barrier interval: the counted waits do not change.
+            if (!late) stage(pslot, kt0 + kt + PD);
             load_frags(nslot, foff0, fa0, fb0);
             mfma_rest(fa1, fb1);
             if constexpr (!QB) {
@@ -1180,6 +1184,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - 1 - (MI + NI) - LPT, 1);
             }
+            if (late) stage(pslot, kt0 + kt + PD);
         } else {
             if (kt + 1 < nk) load_frags(nslot, foff0, fa0, fb0);
             mfma_rest(fa1, fb1);
@@ -2145,8 +2150,10 @@ void launch_v2(const GemmArgs& a, hipStream_t stream) {
         LTX_REQUIRE(!a.win_rows || (!e.gate && !e.bias_m && !e.out_bf16_t && a.win_row0 + a.win_rows <= a.M),
                     "gemm split-K: a row window takes neither per-row gates / biases nor the transposed output");
     }
+    GemmArgs ab = a;
+    ab.conv_stagger = ltx_opt(CONV ? OPT_CONV_STAGGER : OPT_GEMM_STAGGER) != 0;
     hipLaunchKernelGGL((gemm_bf16_kernel_v2<BM, BN, NSTAGE, CONV, WGM, WGN, QB>), dim3(tiles, a.split_k > 1 ? a.split_k : 1),
-                       dim3(WGM * WGN * 64), smem, stream, a);
+                       dim3(WGM * WGN * 64), smem, stream, ab);
     HIP_CHECK(hipGetLastError());
     if (a.split_k > 1) {
         const int rows = a.win_rows ? a.win_rows : a.M;

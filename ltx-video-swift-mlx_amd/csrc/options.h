@@ -32,6 +32,7 @@ enum LtxOpt {
     OPT_CONV_PERSIST,     // 0 = halo kernel one workgroup per tile
     OPT_CONV_BLOCK,       // 0 = plain tile order for single-column convs
     OPT_CONV_TALL,        // 0 = no 384 x 128 two-image-row tiles (conv_halo2.inc) for the W == 192 convs
+    OPT_GEMM_STAGGER,     // the same for the dense 8-wave ring GEMM kernels
     OPT_CONV_STAGGER,     // 0 = both waves of a SIMD issue their LDS-DMA pieces at the same point of the halo kernel's K loop (as before round 5)
     OPT_B_NT,             // -1 = launcher's choice; 0 / 1 = non-temporal weight loads of the few-row GEMM off / on
     OPT_ATTN_PLAIN_ORDER, // 1 = (query block, head, batch) workgroup order as before round 3

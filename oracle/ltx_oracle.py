@@ -222,9 +222,26 @@ def position_grid(frames, height, width, fps=24.0):
     return np.stack([t, h, w], 0).astype(F32)
 
 
+_ROPE_CACHE = {}
+
+
 def rope_tables(frames, height, width, dim=4096, num_heads=32, theta=10000.0, max_pos=(20, 2048, 2048)):
     """cos, sin as [T][dim/2] f32 (== the reference's [B,H,T,64] tensors flattened per token: head h owns columns
-    h*64 .. h*64+63)."""
+    h*64 .. h*64+63). The tables depend on the latent shape only: the last one computed is kept (read-only), so the eight steps of a
+    denoise loop do not each spend a second in math.cos / math.sin (the reference caches them per shape too, LTXTransformer.swift:30-31)."""
+    key = (frames, height, width, dim, num_heads, float(theta), tuple(max_pos))
+    hit = _ROPE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    cos, sin = _rope_tables(frames, height, width, dim, num_heads, theta, max_pos)
+    cos.setflags(write=False)
+    sin.setflags(write=False)
+    _ROPE_CACHE.clear()
+    _ROPE_CACHE[key] = (cos, sin)
+    return cos, sin
+
+
+def _rope_tables(frames, height, width, dim, num_heads, theta, max_pos):
     grid = position_grid(frames, height, width).astype(np.float64)  # (3, T)
     n_pos = 3
     n_elem = 2 * n_pos

@@ -60,7 +60,7 @@ def main():
         wb = 1024.0 * (sum(w) / len(w)) if w else 0.0
         out["kernels"][k] = {"launches": max(len(f), len(w)), "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
         m = re.search(r"ELb([01])E", k)  # first bool template argument of gemm_bf16_kernel_v2 = CONV
-        is_conv = k.startswith("conv3d_halo_kernel") or (k.startswith("gemm_bf16_kernel_v2") and m is not None and m.group(1) == "1")
+        is_conv = k.startswith("conv3d_halo") or (k.startswith("gemm_bf16_kernel_v2") and m is not None and m.group(1) == "1")
         if is_conv:
             conv_f += 2.0 * 1024.0 * sum(f)
             conv_w += 1024.0 * sum(w)
