@@ -357,7 +357,7 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
     // multiply-high forms, and the residual gathers of slab mi + 1 are requested before slab mi is transposed.
     if (ep.d2s == 1 && n0 + BN <= g.N && ep.out_f32 && !ep.out_bf16 && !ep.bias_m && ep.act == LTX_ACT_NONE && !ep.round_bf16 &&
         ((g.N >> 3) % WN) == 0 && ((g.geom.C >> 3) & 3) == 0 && (long)g.M * g.geom.W < (1L << 32) &&
-        (long)g.geom.F * g.geom.H * g.geom.H < (1L << 32)) {
+        (long)g.geom.F * g.geom.H * g.geom.H < (1L << 32) && g.geom.H >= 2 && g.geom.W >= 2) {  // (magic_u32(1) does not exist: round-4 advice)
         constexpr int NIT = (16 * LPR) / 64, RPI = 64 / LPR;
         const int cout = g.N >> 3, cd2s = g.geom.C >> 3;
         const int H = g.geom.H, W = g.geom.W;
@@ -425,7 +425,7 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
     // ---- the decoder's final un-patchify store (d2s == 3; conv_out: 48 of the tile's 64 columns exist): the same treatment - the
     // column part (pixel row b, offset inside its 12 floats) is per-lane constant, rows split with two multiply-high forms
     if (ep.d2s == 3 && (g.N & 3) == 0 && ep.out_f32 && !ep.out_bf16 && !ep.bias_m && ep.act == LTX_ACT_NONE && !ep.round_bf16 && !ep.resid &&
-        (long)g.M * g.geom.W < (1L << 32) && (long)g.geom.F * g.geom.H * g.geom.H < (1L << 32)) {
+        (long)g.M * g.geom.W < (1L << 32) && (long)g.geom.F * g.geom.H * g.geom.H < (1L << 32) && g.geom.H >= 2 && g.geom.W >= 2) {
         constexpr int NIT = (16 * LPR) / 64, RPI = 64 / LPR;
         hook();
         const int H = g.geom.H, W = g.geom.W;

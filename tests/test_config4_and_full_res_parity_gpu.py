@@ -309,3 +309,66 @@ def test_context_cache_keys_do_not_collide_on_high_bits(ltx):
         assert torch.equal(v, outs[0])
     finally:
         ctx.close()
+
+
+def test_conv_kernel_variants_agree_bit_for_bit_per_epilogue(ltx, oracle, vae_from_oracle_weights):
+    """Round-4 advice: the persistent halo kernel requests the next tile's operands from inside the epilogue, so every epilogue variant
+    must be exercised with the persistent walk forced (more tiles than CUs) against one workgroup per tile. With the launcher's switches
+    behind ltx_ctx_set_option (round 5) that is one process: `conv_persist` 0 / 1 (and `conv_stagger` 0 / 1) must not move a bit, on the
+    192-row kernel (`conv_tall` = 0) for: residual + fused PixelNorm output (128 channels), plain residual with a split-K tail window (256
+    channels), the depth-to-space store of an upsampler (d2s == 1), and the whole decode, which ends in conv_out's un-patchify store
+    (d2s == 3) and has partial last tiles. The tall kernel (`conv_tall` = 1) has no per-tile form; its staggered twin is compared too."""
+    ctx, w = vae_from_oracle_weights
+    rng = np.random.default_rng(7)
+
+    def res_block(group, block, F, H, W):
+        C = oracle.VAE_CHANNELS[group]
+        x = torch.from_numpy(rng.standard_normal((F, H, W, C), dtype=np.float32)).cuda()
+
+        def run(**opts):
+            y = x.clone()
+            with ctx.options(**opts):
+                ctx.vae_res_block_dev(group, block, y, F, H, W)
+                torch.cuda.synchronize()
+            return y
+
+        return run
+
+    def upsample(group, F, H, W):
+        C = oracle.VAE_CHANNELS[group]
+        x = torch.from_numpy(rng.standard_normal((F, H, W, C), dtype=np.float32)).cuda()
+
+        def run(**opts):
+            out = torch.empty((2 * F - 1, 2 * H, 2 * W, C // 2), dtype=torch.float32, device="cuda")
+            with ctx.options(**opts):
+                ctx.vae_upsample_dev(group, x, F, H, W, out)
+                torch.cuda.synchronize()
+            return out
+
+        return run
+
+    def decode(F, H, W):
+        lat = torch.from_numpy(rng.standard_normal((1, 128, F, H, W), dtype=np.float32)).cuda()
+
+        def run(**opts):
+            frames = torch.empty((8 * (F - 1) + 1, H * 32, W * 32, 3), dtype=torch.float32, device="cuda")
+            with ctx.options(**opts):
+                ctx.vae_decode_dev(lat, F, H, W, frames)
+                torch.cuda.synchronize()
+            return frames
+
+        return run
+
+    cases = {"res-block 128 ch (PixelNorm + residual epilogue)": res_block(3, 1, 5, 64, 192),
+             "res-block 256 ch (plain residual, tail window)": res_block(2, 0, 13, 64, 96),
+             "upsampler 256 ch (depth-to-space store)": upsample(2, 5, 32, 96),
+             "whole decode 2x8x12 (un-patchify store, partial tiles)": decode(2, 8, 12)}
+    for name, run in cases.items():
+        base = run(conv_tall=0)
+        assert bool(torch.isfinite(base).all()), name
+        for opts in ({"conv_persist": 0}, {"conv_stagger": 0}, {"conv_persist": 0, "conv_stagger": 0}):
+            assert torch.equal(run(conv_tall=0, **opts), base), (name, opts)
+        tall = run()
+        assert torch.equal(run(conv_stagger=0), tall), name
+        r = float((tall - base).norm() / base.norm())
+        assert r <= 2e-3, (name, r)  # the tall kernel sums its K-tiles in another order: rounding only
