@@ -188,6 +188,15 @@ class LTXPipeline {
 
     bool isLoaded() const { return ditLoaded_ && vaeLoaded_; }  // LTXPipeline.swift:171-173
 
+    // Launcher switches of libltxhip (ltx_ctx_set_option: the library never reads the environment; process-wide; `ltx-video options`
+    // lists them). No reference counterpart. E.g. setOption("qk_f32", 1) + setOption("split_f32", 1): the reference's rounding points exactly.
+    void setOption(const std::string& key, int value) { check(ltx_ctx_set_option(ctx_, key.c_str(), value)); }
+    int option(const std::string& key) const {
+        int v = 0;
+        if (ltx_ctx_get_option(ctx_, key.c_str(), &v) != 0) throw LTXError(LTXError::invalidConfiguration, ltx_last_error(ctx_));
+        return v;
+    }
+
     // loadModels (LTXPipeline.swift:217-361), transformer + VAE parts. transformerConfig: nullptr = reference defaults.
     void loadModels(const std::string& ltxWeightsPath, const std::string& vaeWeightsPath,
                     const ltx_transformer_config* transformerConfig = nullptr) {

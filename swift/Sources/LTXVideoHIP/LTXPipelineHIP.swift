@@ -78,6 +78,14 @@ public final class LTXPipelineHIP {
         try check(ltx_dit_load(ctx, ltxWeights, nil, quantBits, 64))
         try check(ltx_vae_load(ctx, vaeWeights, nil))
     }
+    /// Launcher switches of libltxhip (`ltx_ctx_set_option`; the library never reads the environment; process-wide).
+    /// No reference counterpart. `setOption("qk_f32", 1)` + `setOption("split_f32", 1)`: the reference's rounding points exactly.
+    public func setOption(_ key: String, _ value: Int32) throws { try check(ltx_ctx_set_option(ctx, key, value)) }
+    public func option(_ key: String) throws -> Int32 {
+        var v: Int32 = 0
+        try check(ltx_ctx_get_option(ctx, key, &v))
+        return v
+    }
     public func loadConnector(from unifiedWeights: String) throws { try check(ltx_connector_load(ctx, unifiedWeights, nil)) }
     public func loadVAEEncoder(from vaeWeights: String) throws { try check(ltx_vae_encoder_load(ctx, vaeWeights, 0)) }
     /// One process per GPU: the RCCL communicator of this pipeline's group (include/ltxhip.h, "Multi-GPU"). `uniqueId` = the 128

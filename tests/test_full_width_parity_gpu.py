@@ -320,5 +320,4 @@ def test_the_library_ignores_the_environment(ltx, two_layer, monkeypatch):
         monkeypatch.setenv(k, "1")
     ctx.dit_forward_dev(lat, c, ts, None, F, H, W, b, ctx_version=0, mask_all_ones=True)
     torch.cuda.synchronize()
-    assert torch.equal(a, b)
-    assert "experiments=0" in ltx.lib.ltx_build_info().decode() or True  # (the experiments build seeds its table once, at load)
+    assert torch.equal(a, b)  # (true of the experiments build too: it seeds its table once, at its first launch, which is long past)
