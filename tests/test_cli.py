@@ -48,6 +48,20 @@ def test_cli_validation_messages(ltx, args, msg):
     assert rc != 0 and msg in err
 
 
+def test_cli_lists_and_validates_library_options(ltx):
+    """Round 5: the library's launcher switches are reachable from the compiled host only through the ABI (`ltx-video options` prints
+    ltx_option_info's table; `--hip-option name=value` calls ltx_ctx_set_option before anything else) - no GPU needed for either."""
+    rc, out, _ = run("options")
+    assert rc == 0 and "ABI revision 2" in out
+    names = [ln.split("=")[0].replace("*", "").strip() for ln in out.splitlines()[1:]]
+    assert names == [t[0] for t in ltx.option_table()] and "* qk_f32 = 0" in out and "  finish_norm = 1" in out
+    rc, out, _ = run("generate", "x", "--dry-run", "--hip-option", "qk_f32=1", "--hip-option", "conv_tall=0")
+    assert rc == 0 and out.strip().endswith("Validation passed (dry run mode)")
+    for bad, msg in (("no_such=1", "unknown option"), ("finish_rows=9", "outside"), ("qk_f32", "expects name=value")):
+        rc, _, err = run("generate", "x", "--dry-run", "--hip-option", bad)
+        assert rc == 64 and msg in err, (bad, err)
+
+
 @pytest.mark.gpu
 def test_cli_generate_end_to_end(ltx, oracle, tmp_path):
     """generate with a reduced-depth DiT, statistics-only VAE file and explicit embeddings: plumbing + file contract."""
