@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Random-shape sweep of the GEMM epilogues and the attention dispatcher against f32 references (torch on the CPU): a wider net
-than the fixed cases of tests/test_kernels_gpu.py, same tolerances. Usage: python tools/fuzz_kernels.py [cases] [seed]"""
+"""Random-shape sweep of the GEMM epilogues and the attention dispatcher against f32 references (torch on the CPU), and of the conv3d
+launcher (192-row halo kernel, tall kernel, ring kernel, tail windows) against torch's conv3d on integer data: a wider net than the fixed
+cases of tests/test_kernels_gpu.py / tests/test_vae_gpu.py, same tolerances. Usage: python tools/fuzz_kernels.py [cases] [seed]"""
 import importlib
 import math
 import os
@@ -86,8 +87,55 @@ def run(ctx, cases, seed, verbose=True):
     return bad
 
 
+def run_conv(ctx, cases, seed, verbose=True):
+    """conv3d launches of random shape on small-integer data against torch's conv3d: EXACT equality (any summation order gives the same
+    f32). Half the cases have W in {192, 96} with an even / fourfold H and Cout a multiple of 128, i.e. the tall kernel of conv_halo2.inc
+    (two / four image rows per tile, rotating row slots, whole-round launch + tail window); the rest take the 192-row halo kernel, the ring
+    kernel and its split-K tail windows (odd H, W = 48, ragged widths, Cout = 48 ...)."""
+    import torch.nn.functional as F_
+
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(cases):
+        tall = bool(rng.integers(0, 2))
+        if tall:
+            W = int(rng.choice([192, 96]))
+            nrt = 2 if W == 192 else 4
+            H = nrt * int(rng.integers(1, 40))
+            Cin = int(rng.choice([128, 256])) if W == 96 else int(rng.choice([64, 128, 192, 256]))
+            Cout = 128 * int(rng.integers(1, 4))
+            F = int(rng.integers(1, 5))
+        else:
+            W = int(rng.choice([48, 96, 192, 24, 50, 200]))
+            H = int(rng.integers(2, 40))
+            Cin = 64 * int(rng.integers(1, 5))
+            Cout = int(rng.choice([48, 64, 96, 128, 132, 256]))
+            F = int(rng.integers(1, 5))
+        causal = bool(rng.integers(0, 2))
+        g = torch.Generator(device="cuda").manual_seed(int(rng.integers(0, 2 ** 31)))
+        x = torch.randint(-2, 3, (1, Cin, F, H, W), generator=g, device="cuda", dtype=torch.int8).float()
+        w = torch.randint(-2, 3, (Cout, Cin, 3, 3, 3), generator=g, device="cuda", dtype=torch.int8).float()
+        b = torch.randint(-4, 5, (Cout,), generator=g, device="cuda", dtype=torch.int8).float()
+        xd = x[0].permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)
+        wd = w.reshape(Cout, Cin, 27).permute(0, 2, 1).contiguous().to(torch.bfloat16)   # [O][27][I], the ABI's conv weight layout
+        out = torch.full((F, H, W, Cout), float("nan"), device="cuda")
+        ctx.op_conv3d(xd, wd, b, out, causal=causal)
+        torch.cuda.synchronize()
+        xp = F_.pad(x, (1, 1, 1, 1, 0, 0), mode="reflect")
+        xp = torch.cat([xp[:, :, :1], xp[:, :, :1], xp], 2) if causal else torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], 2)
+        ref = F_.conv3d(xp.double(), w.double(), b.double())[0].permute(1, 2, 3, 0).float()
+        ok = bool(torch.equal(out, ref))
+        if not ok:
+            bad += 1
+        if verbose:
+            print(f"conv3d {Cin:3d} -> {Cout:3d} at {F}x{H}x{W} causal={causal}{' (tall tile)' if tall else ''}: {'exact' if ok else 'FAIL max err %.3g' % float((out - ref).abs().max())}", flush=True)
+    return bad
+
+
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    n_bad = run(ltx.Context(0), n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    print(f"{2 * n_cases} cases, {n_bad} failures")
+    the_ctx = ltx.Context(0)
+    n_bad = run(the_ctx, n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    n_bad += run_conv(the_ctx, n_cases // 2, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{2 * n_cases + n_cases // 2} cases, {n_bad} failures")
     sys.exit(1 if n_bad else 0)
