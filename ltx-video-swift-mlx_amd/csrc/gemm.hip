@@ -2340,11 +2340,11 @@ static bool conv_halo_takes(const GemmArgs& a) {
 }
 template <int BN>
 static void launch_conv_halo(const GemmArgs& a, hipStream_t stream);
-// conv_halo2.inc: the 384 x 128 tile of NRT image rows -> 0 = not this launch, else NRT (2: W == 192, 4: W == 96)
+// conv_halo2.inc: the 384 x 128 tile of NRT image rows -> 0 = not this launch, else NRT (1: W == 384, 2: W == 192, 4: W == 96)
 static int conv_halo2_takes(const GemmArgs& a) {
     if (ltx_opt(OPT_CONV_TALL) == 0 || !conv_halo_takes(a)) return 0;
     const Conv3dGeom& q = a.geom;
-    const int nrt = q.W == 192 ? 2 : (q.W == 96 ? 4 : 0);
+    const int nrt = (q.W == 384 && ltx_opt(OPT_CONV_TALL) != 2) ? 1 : (q.W == 192 ? 2 : (q.W == 96 ? 4 : 0));  // (2: A/B without the W == 384 instance)
     if (!nrt || q.H % nrt != 0 || a.N % 128 != 0 || a.M % 384 != 0 || a.tile_count != 0 || a.tile0 != 0 || a.ldb % 8 != 0) return 0;
     if (nrt == 4 && q.C % 128 != 0) return 0;                       // (the row-slot rotation must come back to slot 0 or 4 at a tile boundary)
     if (a.ep.d2s != 0 && a.ep.d2s != 1) return 0;                   // plain / fused-PixelNorm / depth-to-space epilogues (conv_out's d2s == 3 has N = 48)
@@ -2354,7 +2354,7 @@ static int conv_halo2_takes(const GemmArgs& a) {
 }
 template <int NRT>
 static void launch_conv_halo2_nrt(const GemmArgs& a, hipStream_t stream) {
-    constexpr int RSP = (384 / NRT + 2 + 7) / 8, NS = NRT == 2 ? 4 : 8;
+    constexpr int RSP = (384 / NRT + 2 + 7) / 8, NS = NRT == 1 ? 2 : (NRT == 2 ? 4 : 8);
     constexpr int smem = NS * RSP * 1024 + 1024 + 3 * 128 * ROW_BYTES;
     static PerDeviceOnce attr_set;
     attr_set.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)conv3d_halo2_kernel<NRT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); });
@@ -2383,7 +2383,10 @@ static void launch_conv_halo2_nrt(const GemmArgs& a, hipStream_t stream) {
     }
 }
 static void launch_conv_halo2(const GemmArgs& a, hipStream_t stream) {
-    if (conv_halo2_takes(a) == 2) launch_conv_halo2_nrt<2>(a, stream); else launch_conv_halo2_nrt<4>(a, stream);
+    const int nrt = conv_halo2_takes(a);
+    if (nrt == 1) launch_conv_halo2_nrt<1>(a, stream);
+    else if (nrt == 2) launch_conv_halo2_nrt<2>(a, stream);
+    else launch_conv_halo2_nrt<4>(a, stream);
 }
 template <int BN>
 static void launch_conv_halo(const GemmArgs& a, hipStream_t stream) {

@@ -35,3 +35,32 @@ def test_production_gemm_kernels_have_no_scratch(tmp_path):
         assert int(scratch) == 0 and int(spills) == 0, f"{name}: private segment {scratch} bytes, {spills} spilled VGPRs"
     assert halo == 2, "both instances of the halo-staged conv kernel must be checked (round 4: it carried an 80-byte indexed scratch array since round 3, unnoticed)"
     assert seen >= 10, f"only {seen} GEMM kernels found in the metadata"  # 4 two-stage + 3 ring (dense) + 192x256 + 2 conv ring
+
+
+@pytest.mark.timeout(600)
+def test_tall_conv_kernel_has_no_scratch_access_inside_its_counted_waits(tmp_path):
+    """conv_halo2.inc holds 96 accumulators and two fragment sets per wave: the compiler may spill a few loop-invariant registers of the
+    EPILOGUE (it does: 5-6), but a scratch reload inside the K loop is a VMEM load among the LDS-DMA ring's counted `vmcnt` waits - the
+    compiler then drains the ring in front of it. Structure of every instance: barrier 0 = top of the tile loop, barriers 1 .. 9 = the
+    mid-tile barriers of a nine-K-tile group, barrier 10 = end of the K loop. No scratch instruction may sit between barrier 0 and 10."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "gemm.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S",
+                    "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "gemm.hip")], check=True, capture_output=True)
+    lines = out.read_text().splitlines()
+    for nrt in (1, 2, 4):
+        label = f"_ZN12_GLOBAL__N_119conv3d_halo2_kernelILi{nrt}EEEv8GemmArgs:"
+        start = next(i for i, ln in enumerate(lines) if ln.startswith(label))
+        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+        body = lines[start:end]
+        barriers = [i for i, ln in enumerate(body) if ln.strip().startswith("s_barrier")]
+        assert len(barriers) >= 11, (nrt, len(barriers))
+        waits = [ln.strip() for ln in body[barriers[0]:barriers[10]] if "s_waitcnt vmcnt(" in ln]
+        # the nine counted mid-tile waits + the full wait of the __syncthreads() that ends the K loop, and nothing else
+        assert len(waits) == 10 and all("lgkmcnt(0)" in w for w in waits) and waits[-1].startswith("s_waitcnt vmcnt(0)"), (nrt, waits)
+        assert sorted(set(int(w.split("(")[1].split(")")[0]) for w in waits[:9])) == [2, 2 + {1: 7, 2: 4, 4: 2}[nrt]], (nrt, waits)
+        loop = body[barriers[0]:barriers[10]]
+        assert not [ln for ln in loop if "scratch_" in ln], f"NRT = {nrt}: scratch access inside the K loop"
+        assert sum("v_mfma_f32_16x16x32_bf16" in ln for ln in loop) == 9 * 48, nrt

@@ -1,7 +1,7 @@
 """The tall halo-staged conv kernel (csrc/conv_halo2.inc, round 5) keeps NRT + 2 image rows per (frame tap, channel half) group in a ring of
 row slots that rotates from group to group, stages rows and weight tiles behind the mid-tile barrier of fixed positions of a nine-K-tile
 group, and orders all of it with counted `s_waitcnt vmcnt(N)` immediates (2 weight pieces + the row pieces of the previous iteration
-stay in flight). This test replays the schedule on a model, for both instances (two image rows of 192 voxels / four of 96), several
+stay in flight). This test replays the schedule on a model, for all three instances (one image row of 384 voxels / two of 192 / four of 96), several
 channel counts and a walk over three tiles (the K loop runs on across tiles: the next tile's first rows and weights are staged by the
 current tile's last group), and checks what the assembly generators' checkers prove on their streams:
 
@@ -23,13 +23,13 @@ SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 def _constants(nrt):
     text = open(SRC).read()
-    m = re.search(r"return NRT == 2 \? \(([^)]*)\)\s*:\s*\(([^)]*)\);", text)
+    m = re.search(r"return NRT == 1 \? \(([^)]*)\)\s*:\s*NRT == 2 \? \(([^)]*)\)\s*:\s*\(([^)]*)\);", text)
     assert m, "halo2_row_id changed: update this model"
     table = {}
-    for q, rid in re.findall(r"q == (\d+) \? (\d+)", m.group(1 if nrt == 2 else 2)):
+    for q, rid in re.findall(r"q == (\d+) \? (\d+)", m.group({1: 1, 2: 2, 4: 3}[nrt])):
         table[int(q)] = int(rid)
-    assert re.search(r"NS = NRT == 2 \? 4 : 8, RPG = NRT \+ 2;", text) and re.search(r"B_BYTES = BN \* ROW_BYTES, NB = 3;", text)
-    ns, rpg, nb = (4 if nrt == 2 else 8), nrt + 2, 3
+    assert re.search(r"NS = NRT == 1 \? 2 : \(NRT == 2 \? 4 : 8\), RPG = NRT \+ 2;", text) and re.search(r"B_BYTES = BN \* ROW_BYTES, NB = 3;", text)
+    ns, rpg, nb = {1: 2, 2: 4, 4: 8}[nrt], nrt + 2, 3
     rsp = (384 // nrt + 2 + 7) // 8
     ppw = (rsp + 7) // 8
     assert '"n"(PREV_ROW ? BPW + PPW : BPW)' in text and "lgkmcnt(0)\\n\\ts_barrier" in text, "mid-tile wait changed: update this model"
@@ -170,7 +170,7 @@ def _replay(nrt, cpt, ntiles=3, table_override=None, no_lgkm=False):
     return len(issued)
 
 
-@pytest.mark.parametrize("nrt,cpt", [(2, 1), (2, 2), (2, 3), (2, 4), (4, 2), (4, 4), (4, 8)])
+@pytest.mark.parametrize("nrt,cpt", [(1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (2, 3), (2, 4), (4, 2), (4, 4), (4, 8)])
 def test_tall_kernel_schedule_is_covered_by_its_counted_waits(nrt, cpt):
     _replay(nrt, cpt)
 

@@ -214,11 +214,11 @@ def test_conv3d_vs_golden_fixture(gpu_ctx):
 @pytest.mark.parametrize("F,H,W,Cin,Cout,causal", [(1, 2, 192, 128, 128, False), (2, 4, 192, 64, 128, True), (3, 6, 192, 128, 128, False),
                                                     (5, 130, 192, 128, 128, True), (2, 258, 192, 192, 128, False), (2, 6, 192, 128, 256, False),
                                                     (1, 4, 96, 128, 128, False), (2, 8, 96, 256, 256, True), (3, 132, 96, 128, 384, False),
-                                                    (2, 516, 96, 128, 256, True)])
+                                                    (2, 516, 96, 128, 256, True), (2, 5, 384, 128, 128, False), (3, 131, 384, 64, 256, True)])
 def test_tall_conv_tile_integer_exact(ltx, gpu_ctx, F, H, W, Cin, Cout, causal):
     """conv_halo2.inc (round 5): convs with W == 192 (W == 96) run as 384 x 128 tiles of TWO (FOUR) image rows - four (six) staged rows
     per (frame tap, channel half) serve the tile's (row, dy) pairs, the K loop runs on across a workgroup's tiles, row slots rotate from
-    group to group (W == 96). Small integers: any summation order gives the same f32, so equality with torch's conv3d is exact. Shapes:
+    group to group (W == 96); with W == 384 the tile is ONE image row in two alternating slots (seven row pieces per wave, an odd H). Small integers: any summation order gives the same f32, so equality with torch's conv3d is exact. Shapes:
     one tile (every row its own reflection), reflect at the top AND bottom of a frame inside one tile walk, causal and non-causal frame
     clamps, 64 / 128 / 192 / 256 channels (1 - 4 halves; W == 96 needs an even number), several column tiles (the weights change from
     tile to tile while the K loop runs on), 325 tall tiles (persistent walk with uneven XCD chunks), 258 row tiles and 2 x 516 / 4 x 2 column
