@@ -2350,6 +2350,9 @@ static int conv_halo2_takes(const GemmArgs& a) {
     if (a.ep.d2s != 0 && a.ep.d2s != 1) return 0;                   // plain / fused-PixelNorm / depth-to-space epilogues (conv_out's d2s == 3 has N = 48)
     if (a.ep.pn_out && a.N != 128) return 0;
     if ((long)q.F * q.H * q.W * q.C >= (1L << 31) || (long)a.N * a.ldb >= (1L << 31)) return 0;  // 32-bit element offsets
+    // A tall tile is two 192-row tiles on ONE CU: a launch whose tall tiles cover at most half the chip finishes sooner as 192-row tiles
+    // on twice the CUs (small clips; the stages of a 256 x 256 decode). Option value 3 takes the tall kernel regardless (tests of small shapes).
+    if (ltx_opt(OPT_CONV_TALL) != 3 && 2L * (a.M / 384) * (a.N / 128) <= device_cu_count()) return 0;
     return nrt;
 }
 template <int NRT>

@@ -233,12 +233,17 @@ def test_tall_conv_tile_integer_exact(ltx, gpu_ctx, F, H, W, Cin, Cout, causal):
     xd = x[0].permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)
     wd = torch.from_numpy(relayout(w.cpu().numpy())).to(torch.bfloat16).cuda()
     out = torch.full((F, H, W, Cout), float("nan"), device="cuda")
-    gpu_ctx.op_conv3d(xd, wd, b, out, causal=causal)
-    torch.cuda.synchronize()
+    with ltx.options(conv_tall=3):   # 3: the tall kernel for every qualifying shape (by default only launches of more than half a round take it)
+        gpu_ctx.op_conv3d(xd, wd, b, out, causal=causal)
+        torch.cuda.synchronize()
     xp = F_.pad(x, (1, 1, 1, 1, 0, 0), mode="reflect")
     xp = torch.cat([xp[:, :, :1], xp[:, :, :1], xp], 2) if causal else torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], 2)
     ref = F_.conv3d(xp.double(), w.double(), b.double())[0].permute(1, 2, 3, 0).float()
     assert torch.equal(out, ref), float((out - ref).abs().max())
+    auto = torch.full_like(out, float("nan"))
+    gpu_ctx.op_conv3d(xd, wd, b, auto, causal=causal)   # the launcher's own choice
+    torch.cuda.synchronize()
+    assert torch.equal(auto, ref)
     old = torch.full_like(out, float("nan"))
     with ltx.options(conv_tall=0):
         gpu_ctx.op_conv3d(xd, wd, b, old, causal=causal)

@@ -119,8 +119,9 @@ def run_conv(ctx, cases, seed, verbose=True):
         xd = x[0].permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)
         wd = w.reshape(Cout, Cin, 27).permute(0, 2, 1).contiguous().to(torch.bfloat16)   # [O][27][I], the ABI's conv weight layout
         out = torch.full((F, H, W, Cout), float("nan"), device="cuda")
-        ctx.op_conv3d(xd, wd, b, out, causal=causal)
-        torch.cuda.synchronize()
+        with ctx.options(conv_tall=3 if tall else 1):   # 3: the tall kernel whatever the tile count (the launcher keeps small launches on 192-row tiles)
+            ctx.op_conv3d(xd, wd, b, out, causal=causal)
+            torch.cuda.synchronize()
         xp = F_.pad(x, (1, 1, 1, 1, 0, 0), mode="reflect")
         xp = torch.cat([xp[:, :, :1], xp[:, :, :1], xp], 2) if causal else torch.cat([xp[:, :, :1], xp, xp[:, :, -1:]], 2)
         ref = F_.conv3d(xp.double(), w.double(), b.double())[0].permute(1, 2, 3, 0).float()
