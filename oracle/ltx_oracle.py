@@ -424,19 +424,27 @@ def dit_param_shapes(cfg):
     return s
 
 
-def attention(w, prefix, x, cfg, context=None, bias=None, rope=None, kv_bf16=False):
-    """LTXAttention.callAsFunction (LTXAttention.swift:160-218)."""
+def attention(w, prefix, x, cfg, context=None, bias=None, rope=None, kv_bf16=False, kv_cache=None):
+    """LTXAttention.callAsFunction (LTXAttention.swift:160-218). kv_cache (a dict owned by the caller, cross-attention only): the keys
+    and values of a text context do not depend on the step, so a denoise loop computes them once per block - the same arrays every step
+    (the reference recomputes them; the result is the same, bit for bit)."""
     H = cfg.num_heads
     ctx = x if context is None else context
     q = linear(x, w[prefix + "to_q.weight"], w[prefix + "to_q.bias"])
-    k = linear(ctx, w[prefix + "to_k.weight"], w[prefix + "to_k.bias"])
-    v = linear(ctx, w[prefix + "to_v.weight"], w[prefix + "to_v.bias"])
-    if kv_bf16:  # cross-attention K/V come out of bf16 x bf16 Linears in the reference
-        k, v = bf16_round(k), bf16_round(v)
     q = rms_norm(q, w[prefix + "q_norm.weight"], cfg.norm_eps)
-    k = rms_norm(k, w[prefix + "k_norm.weight"], cfg.norm_eps)
-    if kv_bf16:
-        k = bf16_round(k)
+    hit = kv_cache.get(prefix) if (kv_cache is not None and context is not None) else None
+    if hit is not None:
+        k, v = hit
+    else:
+        k = linear(ctx, w[prefix + "to_k.weight"], w[prefix + "to_k.bias"])
+        v = linear(ctx, w[prefix + "to_v.weight"], w[prefix + "to_v.bias"])
+        if kv_bf16:  # cross-attention K/V come out of bf16 x bf16 Linears in the reference
+            k, v = bf16_round(k), bf16_round(v)
+        k = rms_norm(k, w[prefix + "k_norm.weight"], cfg.norm_eps)
+        if kv_bf16:
+            k = bf16_round(k)
+        if kv_cache is not None and context is not None:
+            kv_cache[prefix] = (k, v)
     if rope is not None:
         q = apply_split_rope(q, rope[0], rope[1], H)
         k = apply_split_rope(k, rope[0], rope[1], H)
@@ -451,7 +459,7 @@ def feed_forward(w, prefix, x):
 
 
 def transformer_block(w, i, x, ctx, temb, cfg, rope, bias, cross_scale=1.0, skip_attn=False, skip_ff=False,
-                      first_norm_bf16=False):
+                      first_norm_bf16=False, kv_cache=None):
     """BasicTransformerBlock.callAsFunction (LTXTransformerBlock.swift:187-232). temb [B,1,6,D] or [B,T,6,D]."""
     p = f"transformer_blocks.{i}."
     ada = w[p + "scale_shift_table"][None, None].astype(F32) + temb  # [B,1,6,D]
@@ -463,7 +471,7 @@ def transformer_block(w, i, x, ctx, temb, cfg, rope, bias, cross_scale=1.0, skip
             n = bf16_round(n)
         n = n * (F32(1) + scale_msa) + shift_msa
         x = x + attention(w, p + "attn1.", n, cfg, rope=rope) * gate_msa
-    cross = attention(w, p + "attn2.", x, cfg, context=ctx, bias=bias, kv_bf16=True)
+    cross = attention(w, p + "attn2.", x, cfg, context=ctx, bias=bias, kv_bf16=True, kv_cache=kv_cache)
     if cross_scale != 1.0:
         cross = cross * F32(cross_scale)
     x = x + cross
@@ -488,7 +496,7 @@ def mask_to_bias(mask):
 
 
 def dit_forward(w, cfg, latent, context, timesteps, mask, F, H, W, cross_scale=None, stg_blocks=(), skip_ff_blocks=(),
-                num_layers=None):
+                num_layers=None, text_cache=None):
     """LTXTransformer.callAsFunction (LTXTransformer.swift:235-486).
     latent [B,T,C] (bf16-representable f32), context [B,S,Cc] (bf16-representable), timesteps [B] sigma, or [B,T]
     per-token sigmas (image-to-video: prepareTimestep flattens them and reshapes to [B,T,6,D], LTXTransformer.swift:105-124)."""
@@ -503,14 +511,21 @@ def dit_forward(w, cfg, latent, context, timesteps, mask, F, H, W, cross_scale=N
     emb_ts = linear(silu(e), w["adaln_single.emb.linear_2.weight"], w["adaln_single.emb.linear_2.bias"])  # [B*n,D]
     ada = linear(silu(emb_ts), w["adaln_single.linear.weight"], w["adaln_single.linear.bias"])  # [B*n,6D]
     temb = ada.reshape(B, n_tok, 6, D)
-    ctx = caption_projection(w, context).reshape(B, -1, D)
+    # text_cache (a dict owned by the caller, one per text context): the caption projection and the cross-attention K / V of every block
+    # are computed on the first forward and reused by the later steps of a denoise loop
+    if text_cache is not None and "ctx" in text_cache:
+        ctx = text_cache["ctx"]
+    else:
+        ctx = caption_projection(w, context).reshape(B, -1, D)
+        if text_cache is not None:
+            text_cache["ctx"] = ctx
     bias = mask_to_bias(mask)
     rope = rope_tables(F, H, W, D, cfg.num_heads, cfg.rope_theta, cfg.max_pos)
     L = cfg.num_layers if num_layers is None else num_layers
     for i in range(L):
         cs = 1.0 if cross_scale is None else cross_scale
         x = transformer_block(w, i, x, ctx, temb, cfg, rope, bias, cs, skip_attn=(i in stg_blocks),
-                              skip_ff=(i in skip_ff_blocks), first_norm_bf16=(i == 0))
+                              skip_ff=(i in skip_ff_blocks), first_norm_bf16=(i == 0), kv_cache=text_cache)
     # processOutput (LTXTransformer.swift:208-224)
     ss = w["scale_shift_table"][None, None].astype(F32) + emb_ts.reshape(B, n_tok, 1, D)
     shift, scale = ss[:, :, 0], ss[:, :, 1]
@@ -567,6 +582,7 @@ def denoise(w, cfg, latent, sigmas_, context, mask, F, H, W, cfg_scale=1.0, resc
     image; frame 0 is that latent (:2092-2094), optionally re-noised per step with cond_noise[step] * scale * sigma^2
     (:2225-2229), its tokens carry timestep 0 (:2237-2252) and the Euler step skips it (:2344-2357)."""
     prev_v = None
+    text_caches = {}  # per text context (positive / negative): caption projection + cross-attention K / V, computed at the first step
     i2v = cond_latent is not None
     if i2v:
         latent = latent.copy()
@@ -584,7 +600,7 @@ def denoise(w, cfg, latent, sigmas_, context, mask, F, H, W, cfg_scale=1.0, resc
             ts = np.array([sg], F32)
 
         def fwd(c, m, **kw):
-            v = dit_forward(w, cfg, tok, c, ts, m, F, H, W, num_layers=num_layers, **kw)
+            v = dit_forward(w, cfg, tok, c, ts, m, F, H, W, num_layers=num_layers, text_cache=text_caches.setdefault(id(c), {}), **kw)
             return unpatchify(v, F, H, W).astype(F32)
 
         if cfg_scale > 1.0:

@@ -185,3 +185,26 @@ def test_oracle_matches_golden_fixtures(oracle):
     e = np.load(os.path.join(GOLD, "vae_encoder_tiny.npz"))
     we = oracle.synth_vae_encoder_weights(base=int(e["base"]), seed=int(e["seed"]))
     assert np.allclose(oracle.vae_encode(we, e["pixels"], base=int(e["base"])), e["latent"], rtol=1e-4, atol=1e-5)
+
+
+def test_denoise_text_cache_is_bit_neutral(oracle):
+    """oracle.denoise keeps the caption projection and the cross-attention K / V of a text context across the steps of a loop (they do
+    not depend on the step; the GPU suite's longest tests are bounded by the oracle's host time). The loop must equal, bit for bit, the same
+    steps done by hand through dit_forward without a cache - CFG pair included (two contexts, two caches)."""
+    cfg = oracle.DiTConfig(num_layers=2, num_heads=2, caption_channels=64)
+    w = oracle.synth_dit_weights(cfg, seed=3)
+    rng = np.random.default_rng(0)
+    F, H, W, S = 1, 2, 3, 5
+    lat = rng.standard_normal((1, 128, F, H, W)).astype(np.float32)
+    pos = oracle.bf16_round(rng.standard_normal((1, S, 64)).astype(np.float32))
+    neg = oracle.bf16_round(rng.standard_normal((1, S, 64)).astype(np.float32))
+    sig = oracle.sigmas(False, 3, F * H * W)
+    got = oracle.denoise(w, cfg, lat * sig[0], sig, pos, None, F, H, W, cfg_scale=3.0, neg_context=neg)
+    x = lat * sig[0]
+    for st in range(len(sig) - 1):
+        tok = oracle.bf16_round(oracle.patchify(x))
+        ts = np.array([sig[st]], np.float32)
+        vp = oracle.unpatchify(oracle.dit_forward(w, cfg, tok, pos, ts, None, F, H, W), F, H, W).astype(np.float32)
+        vn = oracle.unpatchify(oracle.dit_forward(w, cfg, tok, neg, ts, None, F, H, W), F, H, W).astype(np.float32)
+        x = oracle.euler_step(x, oracle.apply_cfg(vn, vp, 3.0), float(sig[st]), float(sig[st + 1]))
+    assert np.array_equal(got, x)
