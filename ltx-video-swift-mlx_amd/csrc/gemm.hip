@@ -1121,6 +1121,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     }
 #ifdef GEMM_V2_STAMPS
     const unsigned long long st1 = wall_clock64();
+    const unsigned long long cy1 = __builtin_amdgcn_s_memtime();  // shader cycles next to wall time: the clock the part holds in the loop (round 5)
 #endif
     load_frags(0, foff0, fa0, fb0);
     const bool late = NW == 8 && g.conv_stagger && wave >= NW / 2;  // wave-uniform (GemmArgs::conv_stagger: option "gemm_stagger" for dense launches)
@@ -1209,6 +1210,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
     __syncthreads();
 #ifdef GEMM_V2_STAMPS
     const unsigned long long st2 = wall_clock64();
+    const unsigned long long cy2 = __builtin_amdgcn_s_memtime();
 #endif
     if (g.split_k > 1) {
         GemmArgs gs = g;  // raw partial tile -> workspace slice of this split
@@ -1227,7 +1229,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bf16_kernel_v2(const Gemm
         if (lane == 0 && (blockIdx.x == 7 || blockIdx.x == 200) && wave < 4) {
             unsigned long long* d = &g_gemm_stamps[blockIdx.x == 7 ? wave : 4][0];
             if (blockIdx.x == 7 || wave == 0) {
-                d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = st4;
+                d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = st4; d[5] = cy2 - cy1;
             }
         }
     }

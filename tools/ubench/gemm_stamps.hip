@@ -2,6 +2,7 @@
 // Build from the repo root (after `python3 tools/gen_gemm_asm.py --stamps`):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DGEMM_ASM_STAMPS -Iinclude -Iltx-video-swift-mlx_amd/csrc -o tools/ubench/gemm_stamps tools/ubench/gemm_stamps.hip
 #include "../../ltx-video-swift-mlx_amd/csrc/gemm.hip"
+#include "../../ltx-video-swift-mlx_amd/csrc/options.cpp"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -10,6 +11,7 @@
 Profiler* prof_current() { return nullptr; }
 ProfRec* Profiler::begin(int, double, hipStream_t) { return nullptr; }
 void Profiler::end(ProfRec*, hipStream_t) {}
+void launch_norm_mod(const float*, long, const float*, const float*, long, int, bf16_t*, long, int, int, int, float, int, hipStream_t, const int*) { abort(); }
 
 int main() {
     const int M = getenv("GEMM_M") ? atoi(getenv("GEMM_M")) : 1536, N = getenv("GEMM_N") ? atoi(getenv("GEMM_N")) : 8192, K = getenv("GEMM_K") ? atoi(getenv("GEMM_K")) : 4096;
@@ -54,8 +56,9 @@ int main() {
     if (cfg == 21 || cfg == 25) {
         printf("tile_cfg 21 / 25 (ring kernel), wall-clock stamps in ns (100 MHz counter):\nblock wave | prologue (first tile landed)   main loop   epilogue issue   stores drained | total\n");
         for (int w = 0; w < 5; ++w)
-            printf("  %3d  %d  | %10llu %20llu %14llu %14llu       | %llu\n", w < 4 ? 7 : 200, w < 4 ? w : 0, 10 * (st[w][1] - st[w][0]), 10 * (st[w][2] - st[w][1]),
-                   10 * (st[w][3] - st[w][2]), 10 * (st[w][4] - st[w][3]), 10 * (st[w][4] - st[w][0]));
+            printf("  %3d  %d  | %10llu %20llu %14llu %14llu       | %llu   main loop: %llu cycles = %.0f per K-tile at %.3f GHz\n", w < 4 ? 7 : 200, w < 4 ? w : 0,
+                   10 * (st[w][1] - st[w][0]), 10 * (st[w][2] - st[w][1]), 10 * (st[w][3] - st[w][2]), 10 * (st[w][4] - st[w][3]), 10 * (st[w][4] - st[w][0]),
+                   st[w][5], (double)st[w][5] / (K / 64), (double)st[w][5] / (10.0 * (st[w][2] - st[w][1])));
         return 0;
     }
 #endif
