@@ -395,6 +395,18 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
             }
         };
         fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        // fused PixelNorm of the upsampled voxel (round 5): with cout == BN a tile's 128 columns are ALL channels of one sub-position's
+        // voxel, so the first res-block of the next stage gets its input (PixelNorm + modulation + SiLU of the value just stored) from
+        // here instead of from a row pass over the whole f32 stream; same exchange between the two waves of a row block as above
+        const bool pn = PN && ep.pn_out != nullptr && cout == BN;  // workgroup-uniform
+        float* pns = (float*)(smem + WGM * WGN * (16 * WN * 4));
+        f32x4 pn_s4 = f32x4{1.f, 1.f, 1.f, 1.f}, pn_h4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PN) {
+            if (pn && ep.pn_scale) {
+                pn_s4 = *(const f32x4*)(ep.pn_scale + c);
+                pn_h4 = *(const f32x4*)(ep.pn_shift + c);
+            }
+        }
         static_for<0, MI>([&](auto mi_c) {
             constexpr int mi = decltype(mi_c)::value;
             constexpr int buf = mi & 1;
@@ -411,6 +423,8 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
                     for (int r = 0; r < 4; ++r) scr[((lane >> 4) * 4 + r) * WN + ni * 16 + (lane & 15)] = slab[ni][r];
                 });
             }
+            f32x4 pn_v[PN ? NIT : 1];
+            float pn_s2[PN ? NIT : 1];
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int row = it * RPI + lane / LPR;
@@ -418,6 +432,38 @@ LTX_DEVFN void gemm_epilogue_with(Get&& get, const GemmArgs& g, int m0, int n0, 
                 v += bias;
                 v += rs[buf][it];
                 if (orow[buf][it] >= 0) *(f32x4*)(ocol + orow[buf][it] * ep.ld_f32) = v;
+                if constexpr (PN) {
+                    if (pn) {
+                        pn_v[it] = v;
+                        pn_s2[it] = row16_allsum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+                    }
+                }
+            }
+            if constexpr (PN) {
+                if (pn) {
+                    static_assert(!PN || (WGN == 2 && LPR == 16), "fused PixelNorm: two waves per tile row, 16 lanes per 64-column half row");
+                    float* mine = pns + (buf * WGM * WGN + wave) * 16;
+                    const float* other = pns + (buf * WGM * WGN + (wave ^ 1)) * 16;
+                    if ((lane & (LPR - 1)) == 0) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) mine[it * RPI + (lane / LPR)] = pn_s2[it];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int row = it * RPI + lane / LPR;
+                        const float inv = __builtin_amdgcn_rsqf((pn_s2[it] + other[row]) * (1.0f / (float)BN) + 1e-8f);
+                        f32x4 y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = silu_f(pn_v[it][e] * inv * pn_s4[e] + pn_h4[e]);
+                        if (orow[buf][it] >= 0) {
+                            uint2 pk;
+                            pk.x = pack_bf16x2(y[0], y[1]);
+                            pk.y = pack_bf16x2(y[2], y[3]);
+                            *(uint2*)(ep.pn_out + orow[buf][it] * ep.ld_pn + c) = pk;
+                        }
+                    }
+                }
             }
         });
         return;
@@ -2350,7 +2396,7 @@ static int conv_halo2_takes(const GemmArgs& a) {
     if (!nrt || q.H % nrt != 0 || a.N % 128 != 0 || a.M % 384 != 0 || a.tile_count != 0 || a.tile0 != 0 || a.ldb % 8 != 0) return 0;
     if (nrt == 4 && q.C % 128 != 0) return 0;                       // (the row-slot rotation must come back to slot 0 or 4 at a tile boundary)
     if (a.ep.d2s != 0 && a.ep.d2s != 1) return 0;                   // plain / fused-PixelNorm / depth-to-space epilogues (conv_out's d2s == 3 has N = 48)
-    if (a.ep.pn_out && a.N != 128) return 0;
+    if (a.ep.pn_out && !(a.N == 128 || (a.ep.d2s == 1 && a.N == 8 * 128))) return 0;
     if ((long)q.F * q.H * q.W * q.C >= (1L << 31) || (long)a.N * a.ldb >= (1L << 31)) return 0;  // 32-bit element offsets
     // A tall tile is two 192-row tiles on ONE CU: a launch whose tall tiles cover at most half the chip finishes sooner as 192-row tiles
     // on twice the CUs (small clips; the stages of a 256 x 256 decode). Option value 3 takes the tall kernel regardless (tests of small shapes).
@@ -2590,8 +2636,11 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         const int conv_default = (a.N <= 64 && a.split_k <= 1) ? 27 : 21;
         if (a.ep.pn_out) {
             // the fused PixelNorm output needs every channel of a row in ONE 128-column tile and the epilogue in the GEMM launch
-            LTX_REQUIRE(a.N == 128 && a.split_k <= 1 && !a.ep.d2s && (a.ep.pn_scale == nullptr) == (a.ep.pn_shift == nullptr),
-                        "gemm: fused PixelNorm output needs N == 128 (got %d), no split-K and no depth-to-space store", a.N);
+            // (round 5: or, with the depth-to-space store of an upsampler, N == 8 x 128: a tile is one sub-position's 128 channels; only the
+            // halo-staged kernels carry that epilogue)
+            LTX_REQUIRE(((a.N == 128 && !a.ep.d2s) || (a.ep.d2s == 1 && a.N == 8 * 128 && conv_halo_takes(a))) && a.split_k <= 1 &&
+                            (a.ep.pn_scale == nullptr) == (a.ep.pn_shift == nullptr),
+                        "gemm: fused PixelNorm output needs N == 128 (got %d; 1024 with a depth-to-space store on a halo-staged launch) and no split-K", a.N);
             // (A last partial round - the 128-channel stage at 768x512 is 3200 tiles = 12.5 rounds - is NOT worth a launch of its own here:
             // running the 128 remaining tiles as 256 half-height tiles behind the whole rounds measured +0.28 ms per decode, round 3.
             // Tiles are dispatched as CUs free up, so the ragged end costs half a tile, less than a launch boundary.)

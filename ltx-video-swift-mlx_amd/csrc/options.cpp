@@ -31,6 +31,7 @@ const LtxOptInfo kInfo[OPT_COUNT] = {
     {"conv_block", 1, 0, 1, 0, "0: plain tile order for single-column convs"},
     {"conv_tall", 1, 0, 3, 1, "0: no 384 x 128 conv tiles of whole image rows for W == 384 / 192 / 96 (results then equal the 192-row kernel's bit for bit); 1: where they cover more than half the chip; 2: the same, not for W == 384; 3: wherever the shape allows"},
     {"gemm_stagger", 0, 0, 1, 0, "1: the second wave of every SIMD issues its LDS-DMA pieces half a barrier interval late in the dense ring GEMM kernel (measured: no gain); 0: both waves of a SIMD issue their LDS-DMA pieces at the same point of the dense ring GEMM kernel's K loop"},
+    {"conv_d2s_pn", 1, 0, 1, 1, "0: the first PixelNorm of the VAE decoder's 128-channel stage as a row pass of its own instead of in the upsampler conv's epilogue"},
     {"conv_stagger", 1, 0, 1, 0, "0: both waves of a SIMD issue their LDS-DMA pieces at the same point of the halo conv kernel's K loop"},
     {"b_nt", -1, -1, 1, 0, "-1: launcher's choice; 0 / 1: non-temporal weight loads of the few-row GEMM off / on"},
     {"attn_plain_order", 0, 0, 1, 0, "1: (query block, head, batch) workgroup order"},

@@ -34,6 +34,7 @@ enum LtxOpt {
     OPT_CONV_TALL,        // 0 = no 384 x 128 tiles of whole image rows (conv_halo2.inc) for the W == 384 / 192 / 96 convs; 1 = launches of more than
                           // half a round of them; 2 = the same, not for W == 384; 3 = every launch whose shape allows (tests)
     OPT_GEMM_STAGGER,     // the same for the dense 8-wave ring GEMM kernels
+    OPT_CONV_D2S_PN,      // 0 = the 128-channel stage's first PixelNorm as a row pass of its own (default 1: in the upsampler conv's epilogue)
     OPT_CONV_STAGGER,     // 0 = both waves of a SIMD issue their LDS-DMA pieces at the same point of the halo kernel's K loop (as before round 5)
     OPT_B_NT,             // -1 = launcher's choice; 0 / 1 = non-temporal weight loads of the few-row GEMM off / on
     OPT_ATTN_PLAIN_ORDER, // 1 = (query block, head, batch) workgroup order as before round 3

@@ -357,6 +357,7 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
     // two bf16 buffers (the conv reads one while it writes the other). Wider stages keep the separate row pass.
     bf16_t* hb2 = m->hb2.as<bf16_t>();
     const int C3 = m->channels[3];
+    bool hin_ready = false;  // the upsampler in front of this group already wrote the first res-block's input
     for (int g = 0; g < 4; ++g) {
         const int C = m->groups[g].C;
         const bool fuse = C == 128;
@@ -380,8 +381,9 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
             } else if (r == 4 && g < 3) {
                 copy = true;  // the group's last conv also emits the bf16 copy of the stream that the upsampler's conv reads
             }
-            res_block(m->groups[g].blocks[r], md, C, d, x, t1, hin, hout, r == 0, nsc, nsh, copy, st, skws, skn);
+            res_block(m->groups[g].blocks[r], md, C, d, x, t1, hin, hout, r == 0 && !hin_ready, nsc, nsh, copy, st, skws, skn);
         }
+        hin_ready = false;
         if (g < 3) {
             // depth-to-space upsampler (VideoDecoder.swift:215-251): conv on the raw stream, D2S, drop frame 0, + D2S(x)
             if (!fuse) {
@@ -393,6 +395,19 @@ int decode_tile(ltx_ctx* ctx, VaeModel* m, const float* latent, long chan_stride
             e.d2s = 1;
             e.resid_src = x;
             e.ld_resid = C;
+            // The upsampler in front of the 128-channel stage (round 5): a 128-column tile of this launch is one sub-position with ALL
+            // channels of its voxel, so the epilogue also emits the first res-block's input - PixelNorm + its modulation + SiLU - where a
+            // row pass re-read the whole upsampled f32 stream (315 MB at 768x512). Only where a halo-staged kernel takes the launch (they
+            // carry that epilogue) and the conv's input is not the buffer the next stage starts from.
+            const bool halo_w = (d.W <= 192 && d.W >= 48 && 192 % d.W == 0) || d.W % 192 == 0;
+            if (C / 2 == 128 && m->groups[g + 1].C == 128 && halo_w && d.H >= 2 && hin != hb && ltx_opt(OPT_CONV_D2S_PN) != 0) {
+                const float* nmd = mods + mod_ofs_group[g + 1];
+                e.pn_out = hb;
+                e.ld_pn = 128;
+                e.pn_scale = nmd + 1 * 128;
+                e.pn_shift = nmd + 0 * 128;
+                hin_ready = true;
+            }
             conv3d(hin, d, m->up[g], e, st);
             d.F = 2 * d.F - 1;
             d.H *= 2;

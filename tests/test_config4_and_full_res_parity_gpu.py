@@ -372,3 +372,8 @@ def test_conv_kernel_variants_agree_bit_for_bit_per_epilogue(ltx, oracle, vae_fr
         assert torch.equal(run(conv_tall=3, conv_stagger=0), tall), name
         r = float((tall - base).norm() / base.norm())
         assert r <= 2e-3, (name, r)  # the tall kernel sums its K-tiles in another order: rounding only
+    # the 128-channel stage's first PixelNorm in the upsampler conv's epilogue (round 5) or as the row pass it replaced: the same values
+    # up to the order of the 128-term sum of squares and the bf16 rounding of the result
+    dec = cases["whole decode 2x8x12 (un-patchify store, partial tiles)"]
+    fused, separate = dec(), dec(conv_d2s_pn=0)
+    assert float((fused - separate).abs().max()) <= 2e-2 and float((fused - separate).norm() / separate.norm()) <= 2e-3
