@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const bf16_t* __restr
 // keys (tools/gen_attn_x32.py: layout, register map, pipeline). The LDS images and the K-row permutation are those of
 // attn_fwd_kernel above (the plain-HIP 32x32 kernel pins them through the parity tests); C++ only prepares per-lane offsets.
 // Takes unmasked launches with prescaled Q and Tk % 64 == 0; any Tq (rows past Tq are clamped on load and dropped by the O
-// descriptor). MEASURED, NOT SELECTED (experiments build, LTX_ATTN_IMPL=5): its tile step takes 2071 cycles against 2428 of the
+// descriptor). MEASURED, NOT SELECTED (experiments build, option "attn_impl" = 5): its tile step takes 2071 cycles against 2428 of the
 // 16x16x32 stream, but the part holds 1.47 GHz under it against 1.86 GHz (32x32x16 MFMAs draw more per FLOP): 495 vs 459 us at
 // T = 6144, 40.2 vs 38.5 us at T = 1536, 3.65 vs 3.40 ms per DiT step (profiles/r03_attn_x32_stamps.txt).
 // ---------------------------------------------------------------------------------------------------------------
@@ -960,7 +960,7 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
     //   T=6144:      1536 (6.9)                  | 768 (6.54)           | 1024 (5.0)                  -> assembly (491 vs 641 / 658 us)
     // The assembly kernel takes unmasked launches with Tq % 192 == 0 and Tk % 256 == 0 (the DiT's self- and cross-attention at
     // every BASELINE configuration); masked launches stay on the 4-wave kernel (its per-key bias loads sit in the softmax phase
-    // of the ping-pong kernel, measured slower). LTX_ATTN_IMPL=1 / 2 / 4 force the 4-wave / ping-pong / assembly kernel, 3 the
+    // of the ping-pong kernel, measured slower). Option "attn_impl" = 1 / 2 / 4 forces the 4-wave / ping-pong / assembly kernel, 3 the
     // plain-HIP layout reference of the assembly kernel (same-process A/B runs).
     {
         const long wg4 = (long)((a.Tq + 127) / 128) * a.H * a.B;
@@ -990,7 +990,7 @@ void launch_attention(const AttnArgs& a_in, hipStream_t stream) {
         const long wg48 = (long)((a.Tq + W48_Q - 1) / W48_Q) * a.H * a.B;
         const double cost48 = (double)((wg48 + 255) / 256) * 1.25;
 #ifdef LTX_EXPERIMENTS
-        // the 32x32 stream (LTX_ATTN_IMPL=5 only: measured slower than the 16x16 stream on every BASELINE shape)
+        // the 32x32 stream ("attn_impl" = 5 only: measured slower than the 16x16 stream on every BASELINE shape)
         if (impl && impl[0] == '5') {
             const bool x32_ok = !a.bias && a.q_prescaled && a.Tk % KV_TILE == 0;
             LTX_REQUIRE(x32_ok, "attention: attn_impl = 5 takes unmasked launches with prescaled Q and Tk %% 64 == 0 (Tq=%d Tk=%d)", a.Tq, a.Tk);

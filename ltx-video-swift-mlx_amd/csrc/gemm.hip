@@ -2558,7 +2558,7 @@ int gemm_suggest_split_k(int M, int N, int K) {
 
 // At most one round of 192x128 ring tiles with a long reduction (the FFN's second GEMM at 1536 tokens: 256 tiles, K = 16384) runs as K
 // ranges of the 192x256 kernel, whose main loop reads half the fragments per MFMA, plus the finish pass: 36.46 -> 35.75 ms per headline
-// step on one box. -> number of ranges, 0 = not this launch. LTX_DTL_SPLITK=0 turns it off; LTX_DTL_SPLITK_MINK = least K per range
+// step on one box. -> number of ranges, 0 = not this launch. Option "dtl_splitk" = 0 turns it off; "dtl_splitk_mink" = least K per range
 // (8192; with 2048 the three K = 4096 launches of a block split too and the step LOSES 1.3 ms).
 // Partial tiles of such a launch cross the workspace as bf16 ONLY when the caller asked for it (GemmArgs::split_bf16 - the DiT sets it for
 // its FFN-down Linear, nothing else does: a generic or ABI launch keeps f32 partials, round-4 advice) and option "split_f32" is 0.
@@ -2789,7 +2789,7 @@ void launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     // the fourth round runs 64 workgroups, K-long, on a quarter of the chip (19 % of the launch). Rows are independent, so such a launch is
     // split by rows into a head whose tiles are a whole number of rounds (48 row tiles = 768 tiles) and a tail (4 row tiles = 768 rows)
     // that goes through this function again - as 128 tiles of 192x128 on the ring kernel it takes half the time of the K-long quarter
-    // round. Same kernels per output element as an unsplit launch of each part: bit-identical to those; LTX_GEMM_ROWSPLIT=0 = off (A/B).
+    // round. Same kernels per output element as an unsplit launch of each part: bit-identical to those; option "gemm_rowsplit" = 0 = off (A/B).
     const bool rowsplit_on = ltx_opt(OPT_GEMM_ROWSPLIT) != 0;
     if (best == 75 && rowsplit_on && !a.ep.out_bf16_t && !a.ep.bias_m && a.split_k <= 1) {
         const int ncu = device_cu_count();
