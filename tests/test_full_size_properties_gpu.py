@@ -60,6 +60,13 @@ def test_full_size_forward_is_deterministic_and_batch_consistent(ltx, full):
     # forwards sit 2.4e-3 from the oracle, tests/test_depth_parity_gpu.py)
     rel = float((v2[0] - v[0][0]).norm() / v[0][0].norm())
     assert rel <= 3e-3, rel
+    # round-4 advice: the bound was 2e-3 until the bf16 split partials; with f32 partials (option split_f32 = 1) it still is
+    with ctx.options(split_f32=1):
+        a1 = torch.empty((1, T, 128), dtype=torch.float32, device="cuda")
+        ctx.dit_forward_dev(lat1, c1, ts1, None, F, H, W, a1, ctx_version=13, mask_all_ones=True)
+        torch.cuda.synchronize()
+    rel32 = float((v2[0] - a1[0]).norm() / a1[0].norm())
+    assert rel32 <= 2.2e-3, rel32
 
 
 def test_full_size_context_cache_is_output_identical(ltx, full):
