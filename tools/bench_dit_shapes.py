@@ -16,7 +16,9 @@ ctx = ltx.Context(0)
 ctx.dit_init_synthetic(None, seed=1234)
 if "--q8" in sys.argv:
     ctx.dit_quantize(8)
-    print("qint8 transformer" + (" (LTX_QB_OFF: every launch through the scratch matrix)" if os.environ.get("LTX_QB_OFF") else ""), flush=True)
+    if "--qb-off" in sys.argv:
+        ctx.set_option("qb_off", 1)
+    print("qint8 transformer" + (" (option qb_off: every launch through the scratch matrix)" if "--qb-off" in sys.argv else ""), flush=True)
 S = 1024
 for name, B, F, H, W in (("config 1  256x256x9   T=128 ", 1, 2, 8, 8), ("config 2  768x512x25  T=1536", 1, 4, 16, 24),
                          ("config 3  CFG pair    T=1536", 2, 4, 16, 24), ("config 4  1536x1024x25 T=6144", 1, 4, 32, 48),
