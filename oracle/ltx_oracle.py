@@ -576,11 +576,13 @@ def euler_step(latent, velocity, sigma, sigma_next):
 
 def denoise(w, cfg, latent, sigmas_, context, mask, F, H, W, cfg_scale=1.0, rescale=0.0, stg_scale=0.0,
             stg_blocks=(29,), ge_gamma=0.0, neg_context=None, neg_mask=None, num_layers=None, cond_latent=None,
-            image_cond_noise_scale=0.0, cond_noise=None, step_stats=None):
+            image_cond_noise_scale=0.0, cond_noise=None, step_stats=None, velocity_tokens=None):
     """generateVideo's loop (LTXPipeline.swift:800-956), T2V. latent [1,C,F,H,W] f32 already scaled by sigmas[0].
     Image-to-video (denoise(...) :2191-2401 with conditioningMask / conditionedLatent): cond_latent [1,C,1,H,W] is the encoded
     image; frame 0 is that latent (:2092-2094), optionally re-noised per step with cond_noise[step] * scale * sigma^2
-    (:2225-2229), its tokens carry timestep 0 (:2237-2252) and the Euler step skips it (:2344-2357)."""
+    (:2225-2229), its tokens carry timestep 0 (:2237-2252) and the Euler step skips it (:2344-2357).
+    velocity_tokens (test hook): a list that receives (step, token input [1,T,C], raw transformer output [1,T,C]) of every forward, so that
+    a test can hold ONE forward of the loop against the HIP forward on the same input without a second oracle run."""
     prev_v = None
     text_caches = {}  # per text context (positive / negative): caption projection + cross-attention K / V, computed at the first step
     i2v = cond_latent is not None
@@ -601,6 +603,8 @@ def denoise(w, cfg, latent, sigmas_, context, mask, F, H, W, cfg_scale=1.0, resc
 
         def fwd(c, m, **kw):
             v = dit_forward(w, cfg, tok, c, ts, m, F, H, W, num_layers=num_layers, text_cache=text_caches.setdefault(id(c), {}), **kw)
+            if velocity_tokens is not None:
+                velocity_tokens.append((step, tok, v))
             return unpatchify(v, F, H, W).astype(F32)
 
         if cfg_scale > 1.0:
